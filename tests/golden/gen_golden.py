@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by IMPORTING the reference (this container only).
+
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.npz, *.json
+
+The reference (gaozhihan/PreDiff, /root/reference) has no tests and no golden vectors
+(SURVEY.md F2); these fixtures are what pins the oracle (oracle/) and, through it, the
+HIP path.  Weights are regenerated from (seed, key) by tests/_weights.py in both the
+generator and the tests, so only inputs/outputs are stored.  Nothing here is reference
+source: the files hold numeric inputs and the outputs the reference produced for them.
+"""
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from _ref_import import import_reference  # noqa: E402
+from _weights import seeded_state_dict, seeded_input  # noqa: E402
+from _cases import (ATTN_CASES, MASK_CASES, REORDER_CASES, TINY_UNET_CFGS, TINY_VAE_CFG, V1_UNET_CFG,  # noqa: E402
+                    V1_VAE_CFG, RESBLOCK3D_CASES)
+
+R = import_reference()
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+def reseed(module, seed):
+    module.load_state_dict(seeded_state_dict(module.state_dict(), seed))
+    return module.eval()
+
+
+# ------------------------------------------------------------------ integer / index functions
+def gen_reorder_and_masks():
+    arrs = {}
+    for i, (shape, cuboid, strategy) in enumerate(REORDER_CASES):
+        T, H, W = shape
+        ids = torch.arange(T * H * W, dtype=torch.float32).view(1, T, H, W, 1)
+        r = R.ct.cuboid_reorder(ids, cuboid, strategy)
+        arrs[f"reorder_{i}"] = r[0, :, :, 0].long()
+        back = R.ct.cuboid_reorder_reverse(r, cuboid, strategy, shape)
+        assert torch.equal(back, ids)
+    for i, (shape, cuboid, shift, strategy, padding_type) in enumerate(MASK_CASES):
+        cub, sh = R.ct.update_cuboid_size_shift_size(shape, cuboid, shift, strategy)
+        m = R.ct.compute_cuboid_self_attention_mask(tuple(shape), cub, sh, tuple(strategy), padding_type, "cpu")
+        arrs[f"mask_{i}"] = m.to(torch.bool)
+        arrs[f"mask_{i}_clamped"] = np.asarray(list(cub) + list(sh))
+    save("cuboid_index", **arrs)
+
+
+# ------------------------------------------------------------------ layers
+def gen_attention_layers():
+    arrs = {}
+    for i, c in enumerate(ATTN_CASES):
+        layer = R.ct.CuboidSelfAttentionLayer(dim=c["dim"], num_heads=c["heads"], cuboid_size=c["cuboid"],
+                                              shift_size=c["shift"], strategy=c["strategy"],
+                                              padding_type=c["padding_type"], use_relative_pos=True)
+        reseed(layer, 100 + i)
+        x = seeded_input(f"attn{i}", (c["B"],) + tuple(c["shape"]) + (c["dim"],), 1)
+        y = layer(x)
+        if c["dim"] >= 256:      # v1-size cases: keep a strided slice + a checksum (file size)
+            arrs[f"y_{i}_slice"] = y[:, :, ::2, ::2, ::4].contiguous()
+            arrs[f"y_{i}_abs_sum"] = y.double().abs().sum().reshape(1)
+        else:
+            arrs[f"y_{i}"] = y
+        arrs[f"relidx_{i}"] = layer.relative_position_index
+    save("attn_layer", **arrs)
+
+
+def gen_small_layers():
+    arrs = {}
+    # FFN (gelu / leaky / gated)
+    for i, (act, gated) in enumerate([("gelu", False), ("leaky", False), ("gelu", True)]):
+        m = R.ct.PositionwiseFFN(units=32, hidden_size=128, activation=act, gated_proj=gated, pre_norm=True,
+                                 dropout=0.0, activation_dropout=0.0)
+        reseed(m, 200 + i)
+        x = seeded_input(f"ffn{i}", (2, 3, 4, 4, 32), 1)
+        arrs[f"ffn_{i}"] = m(x)
+    # PatchMerging3D: even and odd (padded) spatial size
+    for i, (shape, ptype) in enumerate([((3, 8, 8), "zeros"), ((3, 7, 6), "zeros"), ((3, 7, 6), "nearest")]):
+        m = R.ct.PatchMerging3D(dim=16, out_dim=32, downsample=(1, 2, 2), padding_type=ptype)
+        reseed(m, 210 + i)
+        x = seeded_input(f"pm{i}", (2,) + shape + (16,), 1)
+        arrs[f"pm_{i}"] = m(x)
+    # Upsample3DLayer
+    m = R.ct.Upsample3DLayer(dim=32, out_dim=16, target_size=(3, 8, 8), kernel_size=3)
+    reseed(m, 220)
+    arrs["up_0"] = m(seeded_input("up0", (2, 3, 4, 4, 32), 1))
+    # PosEmbed
+    m = R.ct.PosEmbed(embed_dim=16, maxT=5, maxH=8, maxW=8)
+    reseed(m, 230)
+    arrs["pos_0"] = m(seeded_input("pos0", (2, 5, 8, 8, 16), 1))
+    # timestep embedding
+    t = torch.tensor([0, 1, 17, 500, 999])
+    arrs["temb_t"] = t
+    arrs["temb_64"] = R.mutils.timestep_embedding(t, 64)
+    arrs["temb_33"] = R.mutils.timestep_embedding(t, 33)
+    # TimeEmbedLayer
+    m = R.time_embed.TimeEmbedLayer(base_channels=64, time_embed_channels=256)
+    reseed(m, 240)
+    arrs["tel_0"] = m(arrs["temb_64"])
+    save("small_layers", **arrs)
+
+
+def gen_resblock3d():
+    arrs = {}
+    for i, c in enumerate(RESBLOCK3D_CASES):
+        m = R.time_embed.TimeEmbedResBlock(channels=c["cin"], dropout=0.0, emb_channels=c["emb"],
+                                           out_channels=c["cout"], use_embed=c["emb"] is not None,
+                                           use_scale_shift_norm=c["ssn"], dims=3)
+        reseed(m, 300 + i)
+        x = seeded_input(f"rb{i}", (2, c["cin"]) + tuple(c["shape"]), 1)      # NCTHW for the reference
+        emb = seeded_input(f"rbe{i}", (2, c["emb"]), 1) if c["emb"] is not None else None
+        arrs[f"y_{i}"] = m(x, emb).permute(0, 2, 3, 4, 1).contiguous()        # stored channels-last
+    save("resblock3d", **arrs)
+
+
+# ------------------------------------------------------------------ UNet
+def unet_kwargs(cfg):
+    return dict(cfg)
+
+
+def gen_tiny_unets():
+    arrs = {}
+    schema = {}
+    for name, cfg in TINY_UNET_CFGS.items():
+        net = R.CuboidTransformerUNet(**cfg)
+        reseed(net, 400 + zlib.crc32(name.encode()) % 97)
+        B = 2
+        x = seeded_input(name + "x", (B,) + tuple(cfg["target_shape"]), 2)
+        cond = seeded_input(name + "c", (B,) + tuple(cfg["input_shape"]), 3)
+        t = torch.tensor([7, 431])
+        arrs[f"{name}_out"] = net(x, t, cond)
+        schema[name] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    save("tiny_unet", **arrs)
+    with open(os.path.join(HERE, "tiny_unet_schema.json"), "w") as f:
+        json.dump(schema, f)
+
+
+def gen_v1_unet():
+    """Full-size v1 config (136.8 M params): schema + one forward, stored as slices + statistics."""
+    net = R.CuboidTransformerUNet(**V1_UNET_CFG)
+    sd = net.state_dict()
+    schema = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()}
+    with open(os.path.join(HERE, "v1_unet_schema.json"), "w") as f:
+        json.dump(schema, f)
+    reseed(net, 1234)
+    x = seeded_input("v1x", (1, 6, 16, 16, 64), 2)
+    cond = seeded_input("v1c", (1, 7, 16, 16, 64), 3)
+    t = torch.tensor([500])
+    out = net(x, t, cond)
+    save("v1_unet", out_slice=out[0, :, ::4, ::4, ::8].contiguous(), out_mean=out.mean().reshape(1),
+         out_std=out.std().reshape(1), out_abs_sum=out.double().abs().sum().reshape(1),
+         out_full_f16=out.to(torch.float16))
+
+
+# ------------------------------------------------------------------ VAE
+def gen_vae():
+    arrs = {}
+    rb = R.tresnet.ResnetBlock2D(in_channels=32, out_channels=32, temb_channels=None, groups=8, eps=1e-6)
+    reseed(rb, 500)
+    arrs["rb_same"] = rb(seeded_input("vrb0", (2, 32, 8, 8), 1), None)
+    rb = R.tresnet.ResnetBlock2D(in_channels=32, out_channels=64, temb_channels=None, groups=8, eps=1e-6)
+    reseed(rb, 501)
+    arrs["rb_diff"] = rb(seeded_input("vrb1", (2, 32, 8, 8), 1), None)
+    ds = R.tresnet.Downsample2D(32, use_conv=True, out_channels=32, padding=0, name="op")
+    reseed(ds, 502)
+    arrs["down"] = ds(seeded_input("vds", (2, 32, 8, 8), 1))
+    us = R.tresnet.Upsample2D(32, use_conv=True, out_channels=32)
+    reseed(us, 503)
+    arrs["up"] = us(seeded_input("vus", (2, 32, 4, 4), 1))
+    at = R.tattn.AttentionBlock(64, num_head_channels=None, norm_num_groups=8, eps=1e-6)
+    reseed(at, 504)
+    arrs["attn"] = at(seeded_input("vat", (2, 64, 4, 4), 1))
+    mom = seeded_input("vmom", (2, 8, 4, 4), 1) * 25.0
+    d = R.DiagonalGaussianDistribution(mom)
+    arrs["dist_mode"] = d.mode()
+    arrs["dist_logvar"] = d.logvar
+    vae = R.AutoencoderKL(**TINY_VAE_CFG)
+    reseed(vae, 510)
+    x = seeded_input("vaex", (3, 1, 32, 32), 1, kind="uniform")
+    post = vae.encode(x)
+    arrs["tiny_moments"] = post.parameters
+    arrs["tiny_mode"] = post.mode()
+    z = seeded_input("vaez", (3, TINY_VAE_CFG["latent_channels"], 8, 8), 1)
+    arrs["tiny_dec"] = vae.decode(z)
+    with open(os.path.join(HERE, "tiny_vae_schema.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in vae.state_dict().items()}, f)
+    save("vae", **arrs)
+    # full-size v1 VAE: schema + one frame through encode/decode
+    vae = R.AutoencoderKL(**V1_VAE_CFG)
+    with open(os.path.join(HERE, "v1_vae_schema.json"), "w") as f:
+        json.dump({k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in vae.state_dict().items()}, f)
+    reseed(vae, 4321)
+    x = seeded_input("v1vaex", (1, 1, 128, 128), 1, kind="uniform")
+    mode = vae.encode(x).mode()
+    z = seeded_input("v1vaez", (1, 64, 16, 16), 1)
+    dec = vae.decode(z)
+    save("v1_vae", mode_f16=mode.to(torch.float16), mode_abs_sum=mode.double().abs().sum().reshape(1),
+         dec_f16=dec.to(torch.float16), dec_abs_sum=dec.double().abs().sum().reshape(1))
+
+
+# ------------------------------------------------------------------ diffusion
+def build_tiny_ldm(use_alignment=False):
+    cfg = TINY_UNET_CFGS["axial"]
+    net = R.CuboidTransformerUNet(**cfg)
+    reseed(net, 600)
+    vae = R.AutoencoderKL(**TINY_VAE_CFG)
+    reseed(vae, 601)
+    T_out, H, W, C = cfg["target_shape"]
+    ldm = R.LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(T_out, H * 4, W * 4, 1),
+                            timesteps=1000, beta_schedule="linear", use_ema=False,
+                            latent_shape=tuple(cfg["target_shape"]), first_stage_model=vae,
+                            cond_stage_model="__is_first_stage__", scale_factor=1.0)
+    return ldm.eval(), cfg
+
+
+def gen_diffusion():
+    ldm, cfg = build_tiny_ldm()
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+             "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2"]
+    arrs = {n: getattr(ldm, n) for n in names}
+    for sched in ["cosine", "sqrt_linear", "sqrt"]:
+        arrs["betas_" + sched] = R.dutils.make_beta_schedule(sched, 1000)
+    for S in (10, 50, 100):
+        steps = R.dutils.make_ddim_timesteps("uniform", S, 1000, verbose=False)
+        arrs[f"ddim_steps_{S}"] = steps
+        ac = ldm.alphas_cumprod.double().numpy()
+        for eta in (0.0, 1.0):
+            sig, a, ap = R.dutils.make_ddim_sampling_parameters(ac, np.minimum(steps, 999), eta, verbose=False)
+            arrs[f"ddim_sigma_{S}_{int(eta)}"] = sig
+            arrs[f"ddim_a_{S}"] = a
+            arrs[f"ddim_aprev_{S}"] = ap
+    arrs["ddim_steps_quad_20"] = R.dutils.make_ddim_timesteps("quad", 20, 1000, verbose=False)
+    save("schedule", **arrs)
+
+    # one p_sample at several t with a recorded noise draw
+    T_in = cfg["input_shape"][0]
+    B = 2
+    lat = (B,) + tuple(cfg["target_shape"])
+    zc = seeded_input("dzc", (B,) + tuple(cfg["input_shape"]), 5)
+    zt = seeded_input("dzt", lat, 6)
+    arrs = {}
+    for tt in (999, 500, 1, 0):
+        t = torch.full((B,), tt, dtype=torch.long)
+        torch.manual_seed(77)
+        out = ldm.p_sample(zt=zt, zc=zc, t=t)
+        torch.manual_seed(77)
+        noise = torch.randn(lat)
+        arrs[f"psample_{tt}"] = out
+        arrs[f"psample_noise_{tt}"] = noise
+        arrs[f"eps_{tt}"] = ldm.apply_model(zt, t, zc)
+    save("p_sample", **arrs)
+
+    # sample(): VAE-encode context, last-3-steps loop (latent_diffusion.py:651-655), decode
+    y = seeded_input("dy", (B, T_in, 32, 32, 1), 8, kind="uniform")
+    torch.manual_seed(123)
+    dec, inter = ldm.sample(cond={"y": y}, batch_size=B, timesteps=3, return_intermediates=True,
+                            return_decoded=True)
+    torch.manual_seed(123)
+    lat_out = ldm.sample(cond={"y": y}, batch_size=B, timesteps=3, return_decoded=False)
+    torch.manual_seed(123)
+    tape = [torch.randn(lat) for _ in range(4)]
+    save("sample3", decoded=dec, latent=lat_out, tape=torch.stack(tape), zc=ldm.cond_stage_forward({"y": y}))
+
+
+def main():
+    which = sys.argv[1:] or ["index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion"]
+    if "index" in which:
+        gen_reorder_and_masks()
+    if "attn" in which:
+        gen_attention_layers()
+    if "small" in which:
+        gen_small_layers()
+    if "resblock" in which:
+        gen_resblock3d()
+    if "tiny_unet" in which:
+        gen_tiny_unets()
+    if "v1_unet" in which:
+        gen_v1_unet()
+    if "vae" in which:
+        gen_vae()
+    if "diffusion" in which:
+        gen_diffusion()
+
+
+if __name__ == "__main__":
+    main()
