@@ -1,0 +1,159 @@
+/*
+ * prediff_hip.h -- C ABI of libprediff_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * PreDiff sampling hot path (Earthformer-UNet denoiser, KL-VAE, DDPM/DDIM step epilogue).
+ *
+ * The reference (gaozhihan/PreDiff) is pure Python/PyTorch and has no FFI: the boundary it offers is the
+ * Python call convention of its nn.Modules.  Each entry point below replaces the ATen op
+ * sequence of the cited reference function; the prediff_amd Python modules (same class names / ctor kwargs / state_dict
+ * schema as the reference) are the only callers.  All pointers are caller-owned DEVICE pointers, layouts are
+ * channels-last, no entry point allocates, every launch goes to the given stream and every function returns
+ * 0 on success or a negative pd_status (the Python side raises).  Paths below are relative to
+ * /root/reference/src/prediff/.
+ */
+#ifndef PREDIFF_HIP_H
+#define PREDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pd_stream_t;   /* hipStream_t */
+typedef uint16_t pd_bf16;    /* raw bfloat16 bits */
+
+enum pd_status { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_UNSUPPORTED = -2, PD_ERR_LAUNCH = -3 };
+enum pd_act { PD_ACT_NONE = 0, PD_ACT_GELU = 1, PD_ACT_SILU = 2, PD_ACT_LEAKY = 3, PD_ACT_RELU = 4 };
+
+int pd_abi_version(void);
+const char* pd_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * pd_igemm: implicit-GEMM on the MFMA pipes (bf16 x bf16 -> fp32 accumulate).
+ *   out[m, n] = act(alpha * sum_{tap, c} A[src(m, tap), c] * W[tap, n, c] + bias[n] + rowvec[m / rows_per_sample, n])
+ *               (* mul[m, n]) (+ residual[m % res_period, n])
+ * With taps == 1 it is nn.Linear (cuboid_transformer.py:849 qkv, :951 proj, :201-203 ffn_1/ffn_2, :294
+ * reduction; cuboid_transformer_unet.py:492 final_proj; taming/attention.py:145-147,180).  With taps == 27 it
+ * is nn.Conv3d 3x3x3 pad 1 on (B,T,H,W,C) (models/time_embed.py:92,119); with taps == 9 nn.Conv2d 3x3 incl. the
+ * nearest x2 up-sampling fused in the gather (cuboid_transformer.py:373-375, taming/resnet.py:128-141) and the
+ * stride-2 / pad (0,1,0,1) down-sampling (taming/resnet.py:183-188).  split != 0 runs the 3-product
+ * bf16 hi/lo decomposition (fp32-class accuracy) on {A, A_lo} x {W, W_lo}.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct pd_igemm_args {
+  const pd_bf16* A;        /* activations, channels-last rows of lda elements */
+  const pd_bf16* A_lo;     /* split mode: low part (else NULL) */
+  const pd_bf16* W;        /* weights packed [tap][N][ldw] (K contiguous) */
+  const pd_bf16* W_lo;
+  const float* bias;       /* [N] or NULL */
+  const float* rowvec;     /* [n_samples][ld_rowvec] or NULL (timestep-embedding add) */
+  const float* residual;   /* fp32 [*, ld_res] or NULL */
+  const float* mul;        /* fp32 [M, ld_mul] or NULL (gated FFN) */
+  float* out_f32;          /* [M, ld_out] or NULL */
+  pd_bf16* out_bf16;       /* [M, ld_outb] or NULL */
+  pd_bf16* out_bf16_lo;    /* split mode low part of the bf16 output or NULL */
+  int64_t a_batch_stride, w_batch_stride, out_batch_stride, outb_batch_stride, res_batch_stride;  /* grid.z */
+  int64_t w_tap_stride;    /* elements between taps of W */
+  int32_t nbatch;
+  int32_t M, N, Cin, taps; /* Cin: K per tap, multiple of 64 (zero padded) */
+  int32_t lda, ldw;
+  int32_t B, Ti, Hi, Wi, To, Ho, Wo;      /* conv geometry (input dims before up-sampling) */
+  int32_t KT, KH, KW, st, sh, sw, pt, ph, pw, ut, uh, uw;
+  int32_t rows_per_sample, ld_rowvec, ld_res, res_period, ld_mul, act, ld_out, ld_outb, split;
+  float alpha;
+  int32_t tile;            /* 0 = auto, 1 = 128x128, 2 = 64x64 */
+  int32_t vec_epilogue;    /* set by the library */
+} pd_igemm_args;
+int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
+
+/* nn.LayerNorm(eps, affine) over the last dim C of fp32 rows -> bf16 (hi[, lo]) rows of ld_out elements
+ * (pad columns [C, ld_out) are written as zero).  cuboid_transformer.py:813 (attn pre-norm), :197 (FFN pre-norm). */
+int pd_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                 int64_t rows, int C, int ld_out, float eps, pd_stream_t stream);
+
+/* PatchMerging3D gather + LayerNorm(prod(ds)*C): x (B,T,H,W,C) fp32 -> (B,T/dt,H/dh,W/dw, dt*dh*dw*C) bf16, zero padding at
+ * the far edge.  cuboid_transformer.py:274-293. */
+int pd_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                             int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
+                             pd_stream_t stream);
+
+/* nn.GroupNorm(G, C, eps) [+ optional (1+scale)*y+shift] [+ SiLU] over channels-last x (B, S, C) fp32 -> bf16 rows of
+ * ld_out elements.  `partials` is caller workspace of B*nchunk*G*2 doubles (nchunk from pd_groupnorm_nchunk).
+ * models/time_embed.py:89-93,115-120,155-166; taming/resnet.py:457-458,478-485; taming/vae.py:82-84. */
+int pd_groupnorm_nchunk(int S, int C);
+int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, const float* ss_scale,
+                      const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo,
+                      int B, int S, int C, int G, int ld_out, float eps, int silu, pd_stream_t stream);
+
+/* fp32 rows -> bf16 (hi[, lo]) rows with optional row gather (rows_per_sample_out rows taken from offset row_off inside
+ * each rows_per_sample_in block) and zero padded columns.  Used for un-normalised GEMM inputs
+ * (cuboid_transformer_unet.py:492 x[:, in_len:], time_embed.py:169 skip_connection input, cuboid_transformer.py:373). */
+int pd_cast_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t n_samples, int rows_per_sample_in, int row_off,
+                 int rows_per_sample_out, int C, int ld_in, int ld_out, pd_stream_t stream);
+
+/* Cuboid self-attention core: softmax(scale * q k^T + rel_pos_bias [masked]) v per (sample, cuboid, head).
+ * qkv: (B, ntok, 3*C) rows [q | k | v], head h at columns h*hd; tok_index[(nc, vol)] = flat token id or -1 for a padded
+ * slot (zero q/k/v that still takes softmax mass); bias (heads, vol, vol) fp32; mask (nc, vol, vol) u8 or NULL.
+ * Output o: (B, ntok, C) bf16 (and/or fp32) in natural token order.  MFMA path (vol <= 16, bf16 qkv) or generic fp32 path.
+ * cuboid_transformer.py:839-861,947-949,956-962 + 388-467 (reorder) + 470-560 (mask, masked_softmax). */
+typedef struct pd_cuboid_attn_args {
+  const pd_bf16* qkv_bf16;   /* one of qkv_bf16 / qkv_f32 */
+  const float* qkv_f32;
+  const int32_t* tok_index;
+  const float* bias;
+  const uint8_t* mask;
+  pd_bf16* out_bf16;
+  pd_bf16* out_bf16_lo;
+  float* out_f32;
+  int32_t B, ntok, C, heads, nc, vol, ld_qkv, ld_out;
+  float scale;
+  int32_t force_generic;
+} pd_cuboid_attn_args;
+int pd_cuboid_attention(const pd_cuboid_attn_args* a, pd_stream_t stream);
+
+/* Row softmax of fp32 scores (rows, n) -> bf16 probabilities (taming/attention.py:176, computed in fp32). */
+int pd_softmax_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t rows, int n, int ld_in, int ld_out,
+                    pd_stream_t stream);
+
+/* Denoiser stem: cat([cond, x], T) + observation-indicator channel -> fp32 (B, T_in+T_out, H, W, C+1) rows of ld_out
+ * elements.  cuboid_transformer_unet.py:425-428. */
+int pd_unet_build_input(const float* x, const float* cond, float* out, int B, int T_in, int T_out, int HW, int C,
+                        int ld_out, pd_stream_t stream);
+
+/* Sinusoidal timestep embedding [cos(t f_k) | sin(t f_k)] (models/utils.py:68-88), t int64 (B,) -> fp32 (B, dim).
+ * freqs: dim/2 fp32 frequencies exp(-ln(max_period) k / half), computed once on the host exactly as the reference does. */
+int pd_timestep_embedding(const int64_t* t, const float* freqs, float* out, int B, int dim, pd_stream_t stream);
+
+/* Small dense layer for M <= 64 rows: out = act_out(W act_in(x) + b), fp32 throughout (TimeEmbedLayer models/time_embed.py:15-24,
+ * emb_layers :105-113).  W (N, K) row-major fp32. */
+int pd_linear_small(const float* x, const float* W, const float* b, float* out, int M, int K, int N, int act_in,
+                    int act_out, pd_stream_t stream);
+
+/* x[b, s, c] += table[s, c] (PosEmbed with the three tables pre-summed; cuboid_transformer.py:65-90) */
+int pd_add_rowtable(float* x, const float* table, int64_t n_samples, int rows_per_sample, int C, pd_stream_t stream);
+
+/* out = a + b (U-Net skip add, cuboid_transformer_unet.py:473-474) */
+int pd_add(const float* a, const float* b, float* out, int64_t n, pd_stream_t stream);
+
+/* DDPM ancestral step from the predicted noise (latent_diffusion.py:553-566,592-596,620-631):
+ *   z0 = c_recip[t] z - c_recipm1[t] eps ; mean = c1[t] z0 + c2[t] z [- exp(.5 logvar[t]) shift] ;
+ *   out = mean + (t != 0) exp(.5 logvar[t]) temperature noise.   coef: 5 fp32 tables of length T:
+ *   [sqrt_recip_ac | sqrt_recipm1_ac | post_mean_coef1 | post_mean_coef2 | post_logvar_clipped]. */
+int pd_ddpm_step(const float* zt, const float* eps, const float* noise, const float* mean_shift, const int64_t* t,
+                 const float* coef, int T, float* out, int B, int64_t per_sample, float temperature, int clip_denoised,
+                 pd_stream_t stream);
+
+/* DDIM step (no reference implementation; stable-diffusion lineage of diffusion/utils.py:42-70):
+ *   z0 = (z - sqrt(1-a_t) eps)/sqrt(a_t) ; out = sqrt(a_prev) z0 + sqrt(1-a_prev-sigma^2) eps + sigma noise.
+ *   coef (B,3) fp32 per sample: [a_t, a_prev, sigma]. */
+int pd_ddim_step(const float* zt, const float* eps, const float* noise, const float* coef, float* out, int B,
+                 int64_t per_sample, pd_stream_t stream);
+
+/* Layout glue for the frame-wise VAE: fp32 NCHW <-> channels-last NHWC (taming/autoencoder_kl.py:80-113 callers,
+ * latent_diffusion.py:361-380,423-432). */
+int pd_nchw_to_nhwc(const float* x, float* out, int N, int C, int HW, int ld_out, pd_stream_t stream);
+int pd_nhwc_to_nchw(const float* x, float* out, int N, int C, int HW, int ld_in, pd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PREDIFF_HIP_H */

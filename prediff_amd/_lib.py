@@ -1,0 +1,248 @@
+"""ctypes binding of libprediff_hip.so (include/prediff_hip.h) + thin tensor-level wrappers.
+
+PyTorch is used here only as the owner of device memory and streams: every wrapper passes raw
+device pointers and the current HIP stream to the C ABI.  There is NO fallback: if the shared
+library is missing or a kernel reports an error, an exception is raised.
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprediff_hip.so")
+
+ACT = {"none": 0, None: 0, "identity": 0, "gelu": 1, "silu": 2, "leaky": 3, "relu": 4}
+
+
+class PrediffHipError(RuntimeError):
+    pass
+
+
+class IgemmArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("A", "A_lo", "W", "W_lo", "bias", "rowvec", "residual", "mul", "out_f32", "out_bf16", "out_bf16_lo")] + \
+               [(n, C.c_int64) for n in
+                ("a_batch_stride", "w_batch_stride", "out_batch_stride", "outb_batch_stride", "res_batch_stride",
+                 "w_tap_stride")] + \
+               [(n, C.c_int32) for n in
+                ("nbatch", "M", "N", "Cin", "taps", "lda", "ldw", "B", "Ti", "Hi", "Wi", "To", "Ho", "Wo",
+                 "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw", "ut", "uh", "uw",
+                 "rows_per_sample", "ld_rowvec", "ld_res", "res_period", "ld_mul", "act", "ld_out", "ld_outb", "split")] + \
+               [("alpha", C.c_float), ("tile", C.c_int32), ("vec_epilogue", C.c_int32)]
+
+
+class CuboidAttnArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("qkv_bf16", "qkv_f32", "tok_index", "bias", "mask", "out_bf16", "out_bf16_lo", "out_f32")] + \
+               [(n, C.c_int32) for n in ("B", "ntok", "C", "heads", "nc", "vol", "ld_qkv", "ld_out")] + \
+               [("scale", C.c_float), ("force_generic", C.c_int32)]
+
+
+_lib = None
+
+_PROTOS = {
+    "pd_abi_version": (C.c_int, []),
+    "pd_last_error": (C.c_char_p, []),
+    "pd_igemm": (C.c_int, [C.POINTER(IgemmArgs), C.c_void_p]),
+    "pd_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "pd_patch_merge_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_void_p]),
+    "pd_groupnorm_nchunk": (C.c_int, [C.c_int, C.c_int]),
+    "pd_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 +
+                          [C.c_float, C.c_int, C.c_void_p]),
+    "pd_cast_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 6 + [C.c_void_p]),
+    "pd_cuboid_attention": (C.c_int, [C.POINTER(CuboidAttnArgs), C.c_void_p]),
+    "pd_softmax_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 3 + [C.c_void_p]),
+    "pd_unet_build_input": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]),
+    "pd_timestep_embedding": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
+    "pd_linear_small": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
+    "pd_add_rowtable": (C.c_int, [C.c_void_p] * 2 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "pd_add": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]),
+    "pd_ddpm_step": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "pd_ddim_step": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_void_p]),
+    "pd_nchw_to_nhwc": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "pd_nhwc_to_nchw": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PrediffHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C prediff_amd/csrc`. prediff_amd has no non-HIP execution path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            f = getattr(l, name)      # AttributeError if a declared symbol is missing
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise PrediffHipError(f"{what} failed (status {rc}): {lib().pd_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t: torch.Tensor, dtype=None):
+    if not t.is_cuda:
+        raise PrediffHipError("prediff_amd kernels need CUDA(HIP) tensors; got a CPU tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise PrediffHipError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise PrediffHipError("expected a contiguous tensor")
+    return t
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+# --------------------------------------------------------------------------------------------------
+# wrappers
+# --------------------------------------------------------------------------------------------------
+def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=None,
+          A_lo=None, W_lo=None, bias=None, rowvec=None, rows_per_sample=0, residual=None, res_period=0,
+          ld_res=None, mul=None, act="none", alpha=1.0, out_f32=None, out_bf16=None, out_bf16_lo=None,
+          ld_out=None, ld_outb=None, nbatch=1, a_batch_stride=0, w_batch_stride=0, out_batch_stride=0,
+          outb_batch_stride=0, res_batch_stride=0, tile=0):
+    """Thin wrapper around pd_igemm.  `geom` = dict(B,Ti,Hi,Wi,To,Ho,Wo,KT,KH,KW,st,sh,sw,pt,ph,pw,ut,uh,uw) or None
+    for a plain linear layer."""
+    a = IgemmArgs()
+    a.A, a.A_lo, a.W, a.W_lo = ptr(A), ptr(A_lo), ptr(W), ptr(W_lo)
+    a.bias, a.rowvec, a.residual, a.mul = ptr(bias), ptr(rowvec), ptr(residual), ptr(mul)
+    a.out_f32, a.out_bf16, a.out_bf16_lo = ptr(out_f32), ptr(out_bf16), ptr(out_bf16_lo)
+    a.a_batch_stride, a.w_batch_stride = a_batch_stride, w_batch_stride
+    a.out_batch_stride, a.outb_batch_stride, a.res_batch_stride = out_batch_stride, outb_batch_stride, res_batch_stride
+    a.w_tap_stride = w_tap_stride
+    a.nbatch, a.M, a.N, a.Cin, a.taps = nbatch, M, N, Cin, taps
+    a.lda = lda if lda is not None else Cin
+    a.ldw = ldw if ldw is not None else Cin
+    if geom is None:
+        geom = dict(B=1, Ti=1, Hi=1, Wi=M, To=1, Ho=1, Wo=M, KT=1, KH=1, KW=1, st=1, sh=1, sw=1, pt=0, ph=0, pw=0,
+                    ut=1, uh=1, uw=1)
+    for k, v in geom.items():
+        setattr(a, k, v)
+    a.rows_per_sample = rows_per_sample
+    a.ld_rowvec = N if rowvec is None else rowvec.shape[-1]
+    a.ld_res = ld_res if ld_res is not None else N
+    a.res_period = res_period
+    a.ld_mul = N
+    a.act = ACT[act]
+    a.ld_out = ld_out if ld_out is not None else N
+    a.ld_outb = ld_outb if ld_outb is not None else N
+    a.split = 1 if A_lo is not None else 0
+    a.alpha = alpha
+    a.tile = tile
+    _check(lib().pd_igemm(C.byref(a), stream_ptr()), "pd_igemm")
+
+
+def conv_geom(B, in_thw, kernel, stride=(1, 1, 1), pad=(1, 1, 1), up=(1, 1, 1), out_thw=None):
+    Ti, Hi, Wi = in_thw
+    KT, KH, KW = kernel
+    if out_thw is None:
+        out_thw = tuple((s * u + 2 * p - k) // st + 1 for s, u, p, k, st in zip(in_thw, up, pad, kernel, stride))
+    To, Ho, Wo = out_thw
+    return dict(B=B, Ti=Ti, Hi=Hi, Wi=Wi, To=To, Ho=Ho, Wo=Wo, KT=KT, KH=KH, KW=KW, st=stride[0], sh=stride[1],
+                sw=stride[2], pt=pad[0], ph=pad[1], pw=pad[2], ut=up[0], uh=up[1], uw=up[2])
+
+
+def layernorm(x, gamma, beta, out, out_lo, rows, Cn, ld_out, eps=1e-5):
+    _check(lib().pd_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(out_lo), rows, Cn, ld_out, eps, stream_ptr()),
+           "pd_layernorm")
+
+
+def patch_merge_layernorm(x, gamma, beta, out, out_lo, B, T, H, W, Cn, ds, ld_out, eps=1e-5):
+    _check(lib().pd_patch_merge_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(out_lo), B, T, H, W, Cn,
+                                          ds[0], ds[1], ds[2], ld_out, eps, stream_ptr()), "pd_patch_merge_layernorm")
+
+
+def groupnorm_nchunk(S, Cn):
+    return lib().pd_groupnorm_nchunk(S, Cn)
+
+
+def groupnorm_silu(x, gamma, beta, partials, out, out_lo, B, S, Cn, G, ld_out, eps, silu=True, ss_scale=None,
+                   ss_shift=None, ld_ss=0):
+    _check(lib().pd_groupnorm_silu(ptr(x), ptr(gamma), ptr(beta), ptr(ss_scale), ptr(ss_shift), ld_ss, ptr(partials),
+                                   ptr(out), ptr(out_lo), B, S, Cn, G, ld_out, eps, 1 if silu else 0, stream_ptr()),
+           "pd_groupnorm_silu")
+
+
+def cast_rows(x, out, out_lo, n_samples, rows_in, row_off, rows_out, Cn, ld_in, ld_out):
+    _check(lib().pd_cast_rows(ptr(x), ptr(out), ptr(out_lo), n_samples, rows_in, row_off, rows_out, Cn, ld_in, ld_out,
+                              stream_ptr()), "pd_cast_rows")
+
+
+def cuboid_attention(*, qkv_bf16=None, qkv_f32=None, tok_index, bias, mask, out_bf16=None, out_bf16_lo=None,
+                     out_f32=None, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out, scale, force_generic=False):
+    a = CuboidAttnArgs()
+    a.qkv_bf16, a.qkv_f32, a.tok_index, a.bias, a.mask = ptr(qkv_bf16), ptr(qkv_f32), ptr(tok_index), ptr(bias), ptr(mask)
+    a.out_bf16, a.out_bf16_lo, a.out_f32 = ptr(out_bf16), ptr(out_bf16_lo), ptr(out_f32)
+    a.B, a.ntok, a.C, a.heads, a.nc, a.vol, a.ld_qkv, a.ld_out = B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out
+    a.scale = scale
+    a.force_generic = 1 if force_generic else 0
+    _check(lib().pd_cuboid_attention(C.byref(a), stream_ptr()), "pd_cuboid_attention")
+
+
+def softmax_rows(x, out, out_lo, rows, n, ld_in, ld_out):
+    _check(lib().pd_softmax_rows(ptr(x), ptr(out), ptr(out_lo), rows, n, ld_in, ld_out, stream_ptr()), "pd_softmax_rows")
+
+
+def unet_build_input(x, cond, out, B, T_in, T_out, HW, Cn, ld_out):
+    _check(lib().pd_unet_build_input(ptr(x), ptr(cond), ptr(out), B, T_in, T_out, HW, Cn, ld_out, stream_ptr()),
+           "pd_unet_build_input")
+
+
+def timestep_freqs(dim, max_period=10000.0, device="cpu"):
+    """exp(-ln(max_period) * arange(half) / half) in fp32, the reference's own expression (models/utils.py:79-81)."""
+    import math
+    half = dim // 2
+    return torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(device)
+
+
+def timestep_embedding(t, freqs, out, B, dim):
+    _check(lib().pd_timestep_embedding(ptr(t), ptr(freqs), ptr(out), B, dim, stream_ptr()), "pd_timestep_embedding")
+
+
+def linear_small(x, W, b, out, M, K, N, act_in="none", act_out="none"):
+    _check(lib().pd_linear_small(ptr(x), ptr(W), ptr(b), ptr(out), M, K, N, ACT[act_in], ACT[act_out], stream_ptr()),
+           "pd_linear_small")
+
+
+def add_rowtable(x, table, n_samples, rows, Cn):
+    _check(lib().pd_add_rowtable(ptr(x), ptr(table), n_samples, rows, Cn, stream_ptr()), "pd_add_rowtable")
+
+
+def add(a, b, out, n):
+    _check(lib().pd_add(ptr(a), ptr(b), ptr(out), n, stream_ptr()), "pd_add")
+
+
+def ddpm_step(zt, eps, noise, mean_shift, t, coef, T, out, B, per_sample, temperature=1.0, clip_denoised=False):
+    _check(lib().pd_ddpm_step(ptr(zt), ptr(eps), ptr(noise), ptr(mean_shift), ptr(t), ptr(coef), T, ptr(out), B,
+                              per_sample, temperature, 1 if clip_denoised else 0, stream_ptr()), "pd_ddpm_step")
+
+
+def ddim_step(zt, eps, noise, coef, out, B, per_sample):
+    _check(lib().pd_ddim_step(ptr(zt), ptr(eps), ptr(noise), ptr(coef), ptr(out), B, per_sample, stream_ptr()),
+           "pd_ddim_step")
+
+
+def nchw_to_nhwc(x, out, N, Cn, HW, ld_out):
+    _check(lib().pd_nchw_to_nhwc(ptr(x), ptr(out), N, Cn, HW, ld_out, stream_ptr()), "pd_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(x, out, N, Cn, HW, ld_in):
+    _check(lib().pd_nhwc_to_nchw(ptr(x), ptr(out), N, Cn, HW, ld_in, stream_ptr()), "pd_nhwc_to_nchw")

@@ -1,0 +1,66 @@
+// Shared device helpers for libprediff_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/prediff_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+extern "C" void pd_set_error(const char* fmt, ...);
+
+#define PD_CHECK_ARG(cond, ...)                       \
+  do {                                                \
+    if (!(cond)) {                                    \
+      pd_set_error(__VA_ARGS__);                      \
+      return PD_ERR_ARG;                              \
+    }                                                 \
+  } while (0)
+
+#define PD_CHECK_LAUNCH()                                                 \
+  do {                                                                    \
+    hipError_t e__ = hipGetLastError();                                   \
+    if (e__ != hipSuccess) {                                              \
+      pd_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return PD_ERR_LAUNCH;                                               \
+    }                                                                     \
+  } while (0)
+
+// fp32 -> bf16 bits, round to nearest even (NaN kept quiet).
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// hi/lo bf16 decomposition: x ~= hi + lo with ~16 mantissa bits.
+__device__ __forceinline__ void f2bf_split(float f, uint16_t& hi, uint16_t& lo) {
+  hi = f2bf(f);
+  lo = f2bf(f - bf2f(hi));
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case PD_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case PD_ACT_SILU: return v / (1.0f + expf(-v));
+    case PD_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;
+    case PD_ACT_RELU: return v > 0.f ? v : 0.f;
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,284 @@
+// Normalisation / cast kernels: fp32 residual stream in, bf16 (hi[/lo]) GEMM operands out.  All HBM-bound:
+// one pass over the row (LayerNorm) or two passes over the sample (GroupNorm: stats, then apply+SiLU+cast).
+#include "common.h"
+
+// -------------------------------------------------------------------------------------------------
+// LayerNorm over C (affine), one wave per row, two-pass in registers (exact mean / centered variance).
+// cuboid_transformer.py:813 / :197 (nn.LayerNorm eps 1e-5, models/utils.py:192-221)
+// -------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 16;   // up to 64*4*16 = 4096 channels per row
+
+template <bool GATHER>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, pd_bf16* __restrict__ out,
+                                                        pd_bf16* __restrict__ out_lo, int64_t rows, int C, int ld_out,
+                                                        float eps,
+                                                        // patch-merge gather geometry (GATHER only)
+                                                        int T, int H, int W, int Cs, int dt, int dh, int dw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = (C + 255) >> 8;   // float4 vectors per lane
+  float4 v[LN_MAXV];
+  // source row decode for the patch-merge gather: row = ((b*To + to)*Ho + ho)*Wo + wo
+  int64_t gb = 0;
+  int to = 0, ho = 0, wo = 0;
+  if (GATHER) {
+    const int To = (T + dt - 1) / dt, Ho = (H + dh - 1) / dh, Wo = (W + dw - 1) / dw;
+    int64_t r = row;
+    wo = (int)(r % Wo); r /= Wo;
+    ho = (int)(r % Ho); r /= Ho;
+    to = (int)(r % To); gb = r / To;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    if (j >= nv) break;
+    const int c = j * 256 + lane * 4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      if (GATHER) {
+        // element e = ((it*dh + ih)*dw + iw)*Cs + cs   (cuboid_transformer.py:286-292)
+        const int sub = c / Cs, cs = c - sub * Cs;
+        const int iw = sub % dw, ih = (sub / dw) % dh, it = sub / (dw * dh);
+        const int tt = to * dt + it, hh = ho * dh + ih, ww = wo * dw + iw;
+        if (tt < T && hh < H && ww < W)
+          t = *(const float4*)(x + ((((gb * T + tt) * H + hh) * W + ww) * (int64_t)Cs + cs));
+      } else {
+        t = *(const float4*)(x + row * (int64_t)C + c);
+      }
+    }
+    v[j] = t;
+    s += t.x + t.y + t.z + t.w;
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    if (j >= nv) break;
+    const int c = j * 256 + lane * 4;
+    if (c < C) {
+      const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
+      q += a * a + b * b + cc * cc + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    if (j >= nv) break;
+    const int c = j * 256 + lane * 4;
+    if (c >= ld_out) continue;
+    float y[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+      const float4 g = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+      y[0] = (v[j].x - mean) * rstd * g.x + be.x;
+      y[1] = (v[j].y - mean) * rstd * g.y + be.y;
+      y[2] = (v[j].z - mean) * rstd * g.z + be.z;
+      y[3] = (v[j].w - mean) * rstd * g.w + be.w;
+    }
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f2bf_split(y[k], hi[k], lo[k]);
+    *(uint2*)(out + row * (int64_t)ld_out + c) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+    if (out_lo)
+      *(uint2*)(out_lo + row * (int64_t)ld_out + c) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+  }
+}
+
+extern "C" int pd_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                            int64_t rows, int C, int ld_out, float eps, pd_stream_t stream) {
+  PD_CHECK_ARG(x && gamma && beta && out, "pd_layernorm: null pointer");
+  PD_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 256 * LN_MAXV, "pd_layernorm: C=%d must be a multiple of 4 and <= %d", C, 256 * LN_MAXV);
+  PD_CHECK_ARG(ld_out >= C && (ld_out & 3) == 0 && ld_out <= ((C + 255) / 256) * 256,
+               "pd_layernorm: ld_out=%d must be >= C, multiple of 4 and within the last 256-column block", ld_out);
+  if (rows <= 0) return PD_OK;
+  hipLaunchKernelGGL((layernorm_kernel<false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                     out, out_lo, rows, C, ld_out, eps, 0, 0, 0, 0, 1, 1, 1);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+extern "C" int pd_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                                        int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
+                                        pd_stream_t stream) {
+  PD_CHECK_ARG(x && gamma && beta && out, "pd_patch_merge_layernorm: null pointer");
+  const int Cm = C * dt * dh * dw;
+  PD_CHECK_ARG((C & 3) == 0 && Cm <= 256 * LN_MAXV, "pd_patch_merge_layernorm: C=%d (merged %d) unsupported", C, Cm);
+  PD_CHECK_ARG(ld_out >= Cm && (ld_out & 3) == 0 && ld_out <= ((Cm + 255) / 256) * 256, "pd_patch_merge_layernorm: bad ld_out=%d", ld_out);
+  const int64_t rows = (int64_t)B * ((T + dt - 1) / dt) * ((H + dh - 1) / dh) * ((W + dw - 1) / dw);
+  hipLaunchKernelGGL((layernorm_kernel<true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                     out, out_lo, rows, Cm, ld_out, eps, T, H, W, C, dt, dh, dw);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// GroupNorm on channels-last (B, S, C): pass 1 partial (sum, sumsq) per (sample, chunk of positions, group),
+// pass 2 finalises mean/rstd per group in the block prologue (double), then normalise + affine [+ scale/shift]
+// [+ SiLU] + bf16 cast.  Deterministic (no atomics).
+// -------------------------------------------------------------------------------------------------
+constexpr int GN_ROWS = 64;   // positions per stats block
+
+extern "C" int pd_groupnorm_nchunk(int S, int C) { return (S + GN_ROWS - 1) / GN_ROWS; }
+
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, double* __restrict__ partials, int S, int C,
+                                                       int G) {
+  // grid (nchunk, B).  Thread t walks the chunk's [rows x C] elements with stride 256; channel-fastest, so a
+  // wave reads 256 contiguous bytes.  Per-group accumulation goes through LDS atomics on doubles? -> no: each thread
+  // keeps (sum, sumsq) per *its* channel only when 256 % C == 0 or C % 256 == 0; the general case uses the slow path.
+  extern __shared__ double sred[];   // [256][2] then [G][2]
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int r0 = chunk * GN_ROWS, r1 = min(S, r0 + GN_ROWS);
+  const int cpg = C / G;
+  const float* xb = x + ((int64_t)b * S + r0) * C;
+  const int n = (r1 - r0) * C;
+  const int tid = threadIdx.x;
+  double* out = partials + ((int64_t)b * nchunk + chunk) * G * 2;
+  if ((C <= 256 && 256 % C == 0) || (C % 256 == 0)) {
+    // fast path: a thread always sees channels == tid (mod 256) -> one group per thread when cpg divides nicely
+    float s = 0.f, q = 0.f;
+    if (C <= 256) {
+      for (int i = tid; i < n; i += 256) { const float v = xb[i]; s += v; q += v * v; }
+      sred[tid * 2] = s; sred[tid * 2 + 1] = q;
+      __syncthreads();
+      if (tid < G) {
+        double ss = 0, qq = 0;
+        for (int k = 0; k < 256; ++k)
+          if ((k % C) / cpg == tid) { ss += sred[k * 2]; qq += sred[k * 2 + 1]; }
+        out[tid * 2] = ss; out[tid * 2 + 1] = qq;
+      }
+    } else {
+      // C multiple of 256: thread handles channels tid, tid+256, ... ; groups differ per 256-column block when cpg < 256
+      const int nblk = C / 256;
+      for (int k = tid; k < G * 2; k += 256) sred[512 + k] = 0.0;
+      __syncthreads();
+      for (int cb = 0; cb < nblk; ++cb) {
+        float s2 = 0.f, q2 = 0.f;
+        const int c = cb * 256 + tid;
+        for (int r = 0; r < r1 - r0; ++r) { const float v = xb[(int64_t)r * C + c]; s2 += v; q2 += v * v; }
+        sred[tid * 2] = s2; sred[tid * 2 + 1] = q2;
+        __syncthreads();
+        // groups covered by this 256-column block: [cb*256/cpg, (cb*256+255)/cpg]
+        const int g0 = (cb * 256) / cpg, g1 = (cb * 256 + 255) / cpg;
+        if (tid <= g1 - g0) {
+          const int g = g0 + tid;
+          double ss = 0, qq = 0;
+          for (int k = 0; k < 256; ++k)
+            if ((cb * 256 + k) / cpg == g) { ss += sred[k * 2]; qq += sred[k * 2 + 1]; }
+          sred[512 + g * 2] += ss; sred[512 + g * 2 + 1] += qq;
+        }
+        __syncthreads();
+      }
+      for (int k = tid; k < G * 2; k += 256) out[k] = sred[512 + k];
+    }
+  } else {
+    // general path (e.g. C = 65 with 65 groups): one thread per (group) walks its channels
+    for (int g = tid; g < G; g += 256) {
+      double ss = 0, qq = 0;
+      for (int r = 0; r < r1 - r0; ++r)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { const double v = xb[(int64_t)r * C + c]; ss += v; qq += v * v; }
+      out[g * 2] = ss; out[g * 2 + 1] = qq;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ ss_scale,
+                                                       const float* __restrict__ ss_shift, int ld_ss,
+                                                       const double* __restrict__ partials, pd_bf16* __restrict__ out,
+                                                       pd_bf16* __restrict__ out_lo, int S, int C, int G, int ld_out, float eps,
+                                                       int silu, int nchunk) {
+  // grid (nchunk, B): same chunking as the stats pass.
+  extern __shared__ float smr[];   // [G][2] mean, rstd
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cpg = C / G;
+  const int tid = threadIdx.x;
+  for (int g = tid; g < G; g += 256) {
+    double ss = 0, qq = 0;
+    const double* pp = partials + (int64_t)b * nchunk * G * 2 + g * 2;
+    for (int k = 0; k < nchunk; ++k) { ss += pp[(int64_t)k * G * 2]; qq += pp[(int64_t)k * G * 2 + 1]; }
+    const double cnt = (double)S * cpg;
+    const double mean = ss / cnt;
+    double var = qq / cnt - mean * mean;
+    if (var < 0) var = 0;
+    smr[g * 2] = (float)mean;
+    smr[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int r0 = chunk * GN_ROWS, r1 = min(S, r0 + GN_ROWS);
+  const float* xb = x + ((int64_t)b * S + r0) * C;
+  pd_bf16* ob = out + ((int64_t)b * S + r0) * ld_out;
+  pd_bf16* obl = out_lo ? out_lo + ((int64_t)b * S + r0) * ld_out : nullptr;
+  const int n = (r1 - r0) * ld_out;
+  for (int i = tid; i < n; i += 256) {
+    const int r = i / ld_out, c = i - r * ld_out;
+    float y = 0.f;
+    if (c < C) {
+      const int g = c / cpg;
+      y = (xb[(int64_t)r * C + c] - smr[g * 2]) * smr[g * 2 + 1] * gamma[c] + beta[c];
+      if (ss_scale) y = y * (1.f + ss_scale[(int64_t)b * ld_ss + c]) + ss_shift[(int64_t)b * ld_ss + c];
+      if (silu) y = y / (1.f + expf(-y));
+    }
+    if (obl) {
+      uint16_t hi, lo;
+      f2bf_split(y, hi, lo);
+      ob[i] = hi; obl[i] = lo;
+    } else {
+      ob[i] = f2bf(y);
+    }
+  }
+}
+
+extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, const float* ss_scale,
+                                 const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo, int B, int S,
+                                 int C, int G, int ld_out, float eps, int silu, pd_stream_t stream) {
+  PD_CHECK_ARG(x && gamma && beta && partials && out, "pd_groupnorm_silu: null pointer");
+  PD_CHECK_ARG(G > 0 && C % G == 0 && ld_out >= C, "pd_groupnorm_silu: bad C/G/ld_out (%d,%d,%d)", C, G, ld_out);
+  PD_CHECK_ARG((ss_scale == nullptr) == (ss_shift == nullptr), "pd_groupnorm_silu: scale/shift must come together");
+  PD_CHECK_ARG(G <= 4096, "pd_groupnorm_silu: too many groups");
+  const int nchunk = pd_groupnorm_nchunk(S, C);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), (512 + 2 * G) * sizeof(double), s, x, partials, S, C, G);
+  PD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), 2 * G * sizeof(float), s, x, gamma, beta, ss_scale, ss_shift,
+                     ld_ss, partials, out, out_lo, S, C, G, ld_out, eps, silu, nchunk);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// fp32 -> bf16 row cast with row-slice gather and zero column padding
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cast_rows_kernel(const float* __restrict__ x, pd_bf16* __restrict__ out,
+                                                        pd_bf16* __restrict__ out_lo, int64_t n_out_rows, int rows_in, int row_off,
+                                                        int rows_out, int C, int ld_in, int ld_out) {
+  const int64_t total = n_out_rows * ld_out;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t ro = i / ld_out;
+    const int c = (int)(i - ro * ld_out);
+    const int64_t smp = ro / rows_out;
+    const int r = (int)(ro - smp * rows_out);
+    const float v = c < C ? x[(smp * rows_in + row_off + r) * (int64_t)ld_in + c] : 0.f;
+    if (out_lo) {
+      uint16_t hi, lo;
+      f2bf_split(v, hi, lo);
+      out[i] = hi; out_lo[i] = lo;
+    } else {
+      out[i] = f2bf(v);
+    }
+  }
+}
+
+extern "C" int pd_cast_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t n_samples, int rows_per_sample_in, int row_off,
+                            int rows_per_sample_out, int C, int ld_in, int ld_out, pd_stream_t stream) {
+  PD_CHECK_ARG(x && out, "pd_cast_rows: null pointer");
+  PD_CHECK_ARG(row_off >= 0 && row_off + rows_per_sample_out <= rows_per_sample_in && ld_in >= C && ld_out >= C, "pd_cast_rows: bad geometry");
+  const int64_t rows = n_samples * rows_per_sample_out;
+  if (rows <= 0) return PD_OK;
+  const int64_t total = rows * ld_out;
+  const unsigned grid = (unsigned)min((int64_t)4096, (total + 255) / 256);
+  hipLaunchKernelGGL(cast_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, out_lo, rows, rows_per_sample_in, row_off,
+                     rows_per_sample_out, C, ld_in, ld_out);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}

@@ -1,0 +1,106 @@
+"""Host-side geometry of cuboid self-attention: everything the HIP attention kernel needs as flat tables.
+
+The reference reorders activations with pad -> roll -> reshape/permute -> attention -> inverse
+(cuboid_transformer.py:821-847, 388-467, 470-528, 956-962).  Here the same mapping is evaluated
+once per layer on the host, in coordinate arithmetic, into
+    tok_index[cuboid, slot] : flat token id (t*H + h)*W + w feeding that slot, or -1 for a padded slot
+    mask[cuboid, slot_q, slot_k] : uint8, only materialised when some entry is 0
+    bias[head, slot_q, slot_k] : relative-position bias gathered from the learned table (per weight update)
+so that the device never materialises a reordered tensor.
+"""
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def clamp_cuboid(shape, cuboid, shift, strategy):
+    """Cuboid / shift actually used for a (T,H,W) input (cuboid_transformer.py:563-592)."""
+    cub, sh = list(cuboid), list(shift)
+    for ax in range(3):
+        if strategy[ax] == "d":
+            sh[ax] = 0
+        if shape[ax] <= cub[ax]:
+            cub[ax] = shape[ax]
+            sh[ax] = 0
+    return tuple(int(v) for v in cub), tuple(int(v) for v in sh)
+
+
+def relative_position_index(cuboid: Sequence[int]) -> torch.Tensor:
+    """The (vol, vol) int64 buffer registered by the reference layer (cuboid_transformer.py:719-734)."""
+    bt, bh, bw = (int(v) for v in cuboid)
+    idx = np.arange(bt * bh * bw)
+    t, h, w = idx // (bh * bw), (idx // bw) % bh, idx % bw
+    dt = t[:, None] - t[None, :] + bt - 1
+    dh = h[:, None] - h[None, :] + bh - 1
+    dw = w[:, None] - w[None, :] + bw - 1
+    return torch.from_numpy((dt * (2 * bh - 1) + dh) * (2 * bw - 1) + dw).long()
+
+
+def _slot_coords(padded: Tuple[int, int, int], cuboid, strategy):
+    """Per axis: (n_cuboids, block) array of padded-space coordinates. 'l' contiguous, 'd' strided by n."""
+    out = []
+    for size, b, s in zip(padded, cuboid, strategy):
+        n = size // b
+        c = np.arange(n)[:, None]
+        i = np.arange(b)[None, :]
+        if s == "l":
+            out.append(c * b + i)
+        elif s == "d":
+            out.append(i * n + c)
+        else:
+            raise NotImplementedError(f"unknown cuboid strategy {s!r}")
+    return out
+
+
+def _flatten_slots(ct, ch, cw, fn):
+    """Evaluate fn(t, h, w) on the (nT,nH,nW,bT,bH,bW) grid -> (num_cuboids, vol)."""
+    nT, bT = ct.shape
+    nH, bH = ch.shape
+    nW, bW = cw.shape
+    t = ct.reshape(nT, 1, 1, bT, 1, 1)
+    h = ch.reshape(1, nH, 1, 1, bH, 1)
+    w = cw.reshape(1, 1, nW, 1, 1, bW)
+    full = np.broadcast_to(fn(t, h, w), (nT, nH, nW, bT, bH, bW))
+    return full.reshape(nT * nH * nW, bT * bH * bW)
+
+
+def attention_tables(shape, cuboid, shift, strategy, padding_type):
+    """All index tables of one CuboidSelfAttentionLayer applied to a (T,H,W) token grid."""
+    if padding_type not in ("zeros", "ignore", "nearest"):
+        raise ValueError(f"padding_type={padding_type!r}")
+    T, H, W = (int(v) for v in shape)
+    cub, sh = clamp_cuboid((T, H, W), cuboid, shift, strategy)
+    pad = tuple((b - s % b) % b for s, b in zip((T, H, W), cub))
+    if padding_type == "nearest" and any(pad):
+        raise NotImplementedError("padding_type='nearest' with a non-divisible shape is not supported by the HIP path")
+    P = (T + pad[0], H + pad[1], W + pad[2])
+    ct, ch, cw = _slot_coords(P, cub, strategy)
+    # torch.roll(x, -shift): slot at padded coordinate p reads padded position (p + shift) mod P
+    st, s_h, sw = (ct + sh[0]) % P[0], (ch + sh[1]) % P[1], (cw + sh[2]) % P[2]
+    tok = _flatten_slots(st, s_h, sw, lambda t, h, w: np.where((t < T) & (h < H) & (w < W), (t * H + h) * W + w, -1))
+    nc, vol = tok.shape
+
+    # shifted-window region ids (cuboid_transformer.py:516-525): three python slices per axis, later ones win
+    def region(size, b, s):
+        r = np.zeros(size, dtype=np.int64)
+        r[slice(-b)] = 0
+        r[slice(-b, -s)] = 1
+        r[slice(-s, None)] = 2
+        return r
+    rt, rh, rw = region(P[0], cub[0], sh[0]), region(P[1], cub[1], sh[1]), region(P[2], cub[2], sh[2])
+    rid = _flatten_slots(ct, ch, cw, lambda t, h, w: (rt[t] * 3 + rh[h]) * 3 + rw[w])
+    mask = rid[:, :, None] == rid[:, None, :]
+    if padding_type == "ignore":
+        valid = tok >= 0
+        mask = mask & valid[:, :, None] & valid[:, None, :]
+    mask_t = None if mask.all() else torch.from_numpy(mask.astype(np.uint8)).contiguous()
+    return dict(cuboid=cub, shift=sh, pad=pad, nc=int(nc), vol=int(vol),
+                tok_index=torch.from_numpy(tok.astype(np.int32)).contiguous(), mask=mask_t)
+
+
+def relative_position_bias(table: torch.Tensor, rel_index: torch.Tensor, vol: int) -> torch.Tensor:
+    """(heads, vol, vol) fp32 bias: table[index[:vol, :vol]] (the slice reproduces quirk Q2 of SURVEY.md:
+    when the cuboid was clamped the index is sliced from the *unclamped* table).  cuboid_transformer.py:855-860."""
+    idx = rel_index[:vol, :vol].reshape(-1)
+    return table.detach().float()[idx].reshape(vol, vol, -1).permute(2, 0, 1).contiguous()

@@ -1,0 +1,353 @@
+"""GPU: every C-ABI kernel of libprediff_hip.so against a plain PyTorch fp32 statement of the same op
+(run on the bf16-rounded operands for the bf16 MFMA paths, on the fp32 operands for the split / fp32 paths)
+and against the oracle for the attention core.  Tolerances are written at each check.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from prediff_amd import _lib as L  # noqa: E402
+from prediff_amd.packing import pack_conv, pack_linear, split_bf16  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def padded_bf16(x2d, split=False):
+    """(rows, K) fp32 -> (rows, pad64(K)) bf16 hi[, lo]"""
+    rows, K = x2d.shape
+    Kp = L.pad64(K)
+    xp = torch.zeros(rows, Kp, device=x2d.device)
+    xp[:, :K] = x2d
+    return split_bf16(xp, split)
+
+
+# ------------------------------------------------------------------------------------------------ igemm: linear
+@pytest.mark.parametrize("M,N,K,tile", [(256, 128, 64, 1), (256, 128, 64, 2), (3328, 768, 256, 0), (1000, 200, 96, 1),
+                                        (1000, 200, 96, 2), (37, 5, 32, 2), (832, 2048, 512, 0), (128, 64, 1024, 2)])
+@pytest.mark.parametrize("split", [False, True])
+def test_igemm_linear(M, N, K, tile, split):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    # asymmetric data: transposes / row-col swaps cannot cancel
+    x = (torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5 + torch.arange(M)[:, None] * 1e-3).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.arange(N)[:, None] * 1e-3).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    a_hi, a_lo = padded_bf16(x, split)
+    w_hi, w_lo = pack_linear(w, split)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    outb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    L.igemm(a_hi, w_hi, A_lo=a_lo, W_lo=w_lo, M=M, N=N, Cin=a_hi.shape[1], bias=bias, residual=res, act="gelu",
+            out_f32=out, out_bf16=outb, tile=tile)
+    torch.cuda.synchronize()
+    if split:
+        ref = F.gelu(x @ w.t() + bias) + res
+        tol = 2e-5          # hi/lo split: fp32-class accuracy
+    else:
+        ref = F.gelu(bf(x) @ bf(w).t() + bias) + res
+        tol = 2e-6          # same bf16 operands, fp32 accumulate: only summation order differs
+    assert rel_l2(out, ref) < tol
+    assert rel_l2(outb.float(), ref) < 4e-3      # bf16 output rounding
+
+
+def test_igemm_rowvec_alpha_mul_period():
+    M, N, K = 512, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    rowvec = torch.randn(4, N, generator=g).to(DEV)         # 4 samples x 128 rows
+    mul = torch.randn(M, N, generator=g).to(DEV)
+    table = torch.randn(128, N, generator=g).to(DEV)        # periodic residual (positional table)
+    a_hi, _ = padded_bf16(x)
+    w_hi, _ = pack_linear(w, False)
+    out = torch.empty(M, N, device=DEV)
+    L.igemm(a_hi, w_hi, M=M, N=N, Cin=K, rowvec=rowvec, rows_per_sample=128, mul=mul, residual=table, res_period=128,
+            alpha=0.25, act="silu", out_f32=out)
+    ref = F.silu(0.25 * (bf(x) @ bf(w).t()) + rowvec.repeat_interleave(128, 0)) * mul + table.repeat(4, 1)
+    assert rel_l2(out, ref) < 2e-6
+
+
+def test_igemm_batched():
+    nb, M, N, K = 3, 256, 256, 128
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = torch.randn(nb, M, K, generator=g).to(DEV)
+    w = torch.randn(nb, N, K, generator=g).to(DEV)
+    a_hi, _ = split_bf16(x, False)
+    w_hi, _ = split_bf16(w, False)
+    out = torch.empty(nb, M, N, device=DEV)
+    L.igemm(a_hi, w_hi, M=M, N=N, Cin=K, nbatch=nb, a_batch_stride=M * K, w_batch_stride=N * K, out_batch_stride=M * N,
+            alpha=0.5, out_f32=out)
+    ref = 0.5 * torch.einsum("bmk,bnk->bmn", bf(x), bf(w))
+    assert rel_l2(out, ref) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ igemm: convolutions
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 5, 8, 8, 64, 64), (1, 13, 16, 16, 256, 256), (2, 3, 6, 6, 5, 32), (1, 13, 8, 8, 512, 512)])
+@pytest.mark.parametrize("split", [False, True])
+def test_igemm_conv3d(B, T, H, W, Cin, Cout, split):
+    g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
+    x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    emb = torch.randn(B, Cout, generator=g).to(DEV)
+    a_hi, a_lo = padded_bf16(x.reshape(-1, Cin), split)
+    w_hi, w_lo = pack_conv(w, split)
+    Cp = a_hi.shape[1]
+    M = B * T * H * W
+    out = torch.empty(M, Cout, device=DEV)
+    L.igemm(a_hi, w_hi, A_lo=a_lo, W_lo=w_lo, M=M, N=Cout, Cin=Cp, taps=27, w_tap_stride=Cout * Cp,
+            geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias, rowvec=emb, rows_per_sample=T * H * W, out_f32=out)
+    xs, ws = (x, w) if split else (bf(x), bf(w))
+    ref = F.conv3d(xs.permute(0, 4, 1, 2, 3), ws, bias, padding=1) + emb[:, :, None, None, None]
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(M, Cout)
+    assert rel_l2(out, ref) < (3e-5 if split else 3e-6)
+
+
+@pytest.mark.parametrize("mode", ["same", "up2", "down2"])
+def test_igemm_conv2d(mode):
+    N_, H, W, Cin, Cout = 3, 8, 8, 64, 96
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(N_, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    a_hi, _ = padded_bf16(x.reshape(-1, Cin))
+    w_hi, _ = pack_conv(w, False)
+    xc = bf(x).permute(0, 3, 1, 2)
+    if mode == "same":
+        geom = L.conv_geom(N_, (1, H, W), (1, 3, 3), pad=(0, 1, 1))
+        ref = F.conv2d(xc, bf(w), bias, padding=1)
+    elif mode == "up2":      # nearest x2 then conv pad 1 (cuboid_transformer.py:373-375 / taming/resnet.py:128-141)
+        geom = L.conv_geom(N_, (1, H, W), (1, 3, 3), pad=(0, 1, 1), up=(1, 2, 2))
+        ref = F.conv2d(F.interpolate(xc, scale_factor=2.0, mode="nearest"), bf(w), bias, padding=1)
+    else:                    # pad (0,1,0,1) then stride-2 conv, padding 0 (taming/resnet.py:183-188)
+        geom = L.conv_geom(N_, (1, H, W), (1, 3, 3), stride=(1, 2, 2), pad=(0, 0, 0), out_thw=(1, H // 2, W // 2))
+        ref = F.conv2d(F.pad(xc, (0, 1, 0, 1)), bf(w), bias, stride=2)
+    M = N_ * geom["Ho"] * geom["Wo"]
+    out = torch.empty(M, Cout, device=DEV)
+    L.igemm(a_hi, w_hi, M=M, N=Cout, Cin=64, taps=9, w_tap_stride=Cout * 64, geom=geom, bias=bias, out_f32=out)
+    assert rel_l2(out, ref.permute(0, 2, 3, 1).reshape(M, Cout)) < 3e-6
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rows,Cn", [(1000, 256), (333, 512), (64, 1024), (50, 64), (7, 32), (100, 2048)])
+def test_layernorm(rows, Cn):
+    g = torch.Generator(device="cpu").manual_seed(rows + Cn)
+    x = (torch.randn(rows, Cn, generator=g) * 3 + 1.5).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(Cn, generator=g)).to(DEV), torch.randn(Cn, generator=g).to(DEV)
+    ld = L.pad64(Cn)
+    out = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    lo = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.layernorm(x, gamma, beta, out, lo, rows, Cn, ld)
+    ref = F.layer_norm(x, (Cn,), gamma, beta, 1e-5)
+    assert rel_l2(out[:, :Cn].float() + lo[:, :Cn].float(), ref) < 2e-5       # hi+lo ~ fp32
+    assert rel_l2(out[:, :Cn].float(), ref) < 4e-3                            # bf16 rounding
+    assert float(out[:, Cn:].float().abs().max() if ld > Cn else 0) == 0
+
+
+@pytest.mark.parametrize("T,H,W,Cn", [(3, 8, 8, 64), (13, 16, 16, 256), (3, 7, 6, 16)])
+def test_patch_merge_layernorm(T, H, W, Cn):
+    B = 2
+    g = torch.Generator(device="cpu").manual_seed(T * H)
+    x = torch.randn(B, T, H, W, Cn, generator=g).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(4 * Cn, generator=g)).to(DEV), torch.randn(4 * Cn, generator=g).to(DEV)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    ld = L.pad64(4 * Cn)
+    out = torch.zeros(B * T * Ho * Wo, ld, dtype=torch.bfloat16, device=DEV)
+    lo = torch.zeros_like(out)
+    L.patch_merge_layernorm(x, gamma, beta, out, lo, B, T, H, W, Cn, (1, 2, 2), ld)
+    xp = F.pad(x, (0, 0, 0, Wo * 2 - W, 0, Ho * 2 - H))
+    xm = xp.reshape(B, T, 1, Ho, 2, Wo, 2, Cn).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(B * T * Ho * Wo, 4 * Cn)
+    ref = F.layer_norm(xm, (4 * Cn,), gamma, beta, 1e-5)
+    assert rel_l2(out[:, :4 * Cn].float() + lo[:, :4 * Cn].float(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,S,Cn,G", [(2, 3328, 256, 32), (2, 832, 512, 32), (2, 320, 5, 5), (3, 100, 65, 65), (2, 64, 64, 32),
+                                      (1, 16384, 128, 32), (2, 200, 32, 8)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_silu(B, S, Cn, G, silu):
+    g = torch.Generator(device="cpu").manual_seed(S + Cn)
+    x = (torch.randn(B, S, Cn, generator=g) * 2 + 0.7).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(Cn, generator=g)).to(DEV), torch.randn(Cn, generator=g).to(DEV)
+    ld = L.pad64(Cn)
+    part = torch.zeros(B * L.groupnorm_nchunk(S, Cn) * G * 2, dtype=torch.float64, device=DEV)
+    out = torch.full((B * S, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    lo = torch.full((B * S, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.groupnorm_silu(x, gamma, beta, part, out, lo, B, S, Cn, G, ld, 1e-6, silu=silu)
+    ref = F.group_norm(x.permute(0, 2, 1), G, gamma, beta, 1e-6)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(B * S, Cn)
+    assert rel_l2(out[:, :Cn].float() + lo[:, :Cn].float(), ref) < 2e-5
+    if ld > Cn:
+        assert float(out[:, Cn:].float().abs().max()) == 0
+
+
+def test_groupnorm_scale_shift():
+    B, S, Cn, G = 2, 128, 64, 32
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(B, S, Cn, generator=g).to(DEV)
+    gamma, beta = torch.randn(Cn, generator=g).to(DEV), torch.randn(Cn, generator=g).to(DEV)
+    ss = torch.randn(B, 2 * Cn, generator=g).to(DEV)
+    part = torch.zeros(B * L.groupnorm_nchunk(S, Cn) * G * 2, dtype=torch.float64, device=DEV)
+    out = torch.zeros(B * S, Cn, dtype=torch.bfloat16, device=DEV)
+    lo = torch.zeros_like(out)
+    L.groupnorm_silu(x, gamma, beta, part, out, lo, B, S, Cn, G, Cn, 1e-5, silu=True, ss_scale=ss, ss_shift=ss[:, Cn:], ld_ss=2 * Cn)
+    ref = F.group_norm(x.permute(0, 2, 1), G, gamma, beta, 1e-5) * (1 + ss[:, :Cn, None]) + ss[:, Cn:, None]
+    ref = F.silu(ref).permute(0, 2, 1).reshape(B * S, Cn)
+    assert rel_l2(out.float() + lo.float(), ref) < 2e-5
+
+
+def test_cast_rows_slice():
+    x = torch.randn(3, 13, 10, device=DEV)           # 3 samples x 13 rows x 10 ch
+    out = torch.full((3 * 6, 64), 5.0, dtype=torch.bfloat16, device=DEV)
+    lo = torch.zeros_like(out)
+    L.cast_rows(x, out, lo, 3, 13, 7, 6, 10, 10, 64)
+    ref = x[:, 7:].reshape(18, 10)
+    assert rel_l2(out[:, :10].float() + lo[:, :10].float(), ref) < 1e-5
+    assert float(out[:, 10:].float().abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ attention core
+def _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, B, qdtype, force_generic):
+    from oracle import unet as OU
+    from prediff_amd.cuboid_geometry import attention_tables
+    T, H, W = shape
+    g = torch.Generator(device="cpu").manual_seed(T * 100 + Cn)
+    ntok = T * H * W
+    qkv = torch.randn(B, ntok, 3 * Cn, generator=g)
+    table_rows = (2 * cuboid[0] - 1) * (2 * cuboid[1] - 1) * (2 * cuboid[2] - 1)
+    bias_table = torch.randn(table_rows, heads, generator=g) * 0.5
+    relidx = OU.relative_position_index(cuboid)
+    tabs = attention_tables(shape, cuboid, shift, strategy, padding_type)
+    vol, nc = tabs["vol"], tabs["nc"]
+    if qdtype == "bf16":
+        qkv = bf(qkv)
+    # ---- oracle statement of the core on the same q/k/v (cuboid_transformer.py:839-861,947-962) ----
+    cub, sh = tabs["cuboid"], tabs["shift"]
+    pad = tabs["pad"]
+    x = qkv.reshape(B, T, H, W, 3 * Cn)
+    x = F.pad(x, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))         # qkv of padded tokens is exactly zero (no qkv bias)
+    if any(s > 0 for s in sh):
+        x = torch.roll(x, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))
+    xr = OU.cuboid_reorder(x, cub, strategy)
+    hd = Cn // heads
+    q, k, v = xr.reshape(B, nc, vol, 3, heads, hd).permute(3, 0, 4, 1, 2, 5)
+    score = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    bias = bias_table[relidx[:vol, :vol].reshape(-1)].reshape(vol, vol, heads).permute(2, 0, 1)
+    score = score + bias.unsqueeze(1)
+    mask = OU.cuboid_attention_mask(shape, cub, sh, strategy, padding_type)
+    y = (OU.masked_softmax(score, mask) @ v).permute(0, 2, 3, 1, 4).reshape(B, nc, vol, Cn)
+    y = OU.cuboid_reorder_reverse(y, cub, strategy, (T + pad[0], H + pad[1], W + pad[2]))
+    if any(s > 0 for s in sh):
+        y = torch.roll(y, shifts=sh, dims=(1, 2, 3))
+    ref = y[:, :T, :H, :W].reshape(B, ntok, Cn)
+    # ---- HIP ----
+    tok = tabs["tok_index"].to(DEV)
+    m = tabs["mask"].to(DEV) if tabs["mask"] is not None else None
+    assert (m is None) == bool(mask.all())
+    bias_d = bias.contiguous().to(DEV)
+    kw = dict(tok_index=tok, bias=bias_d, mask=m, B=B, ntok=ntok, Cn=Cn, heads=heads, nc=nc, vol=vol, ld_qkv=3 * Cn,
+              ld_out=Cn, scale=hd ** -0.5, force_generic=force_generic)
+    if qdtype == "bf16":
+        out = torch.zeros(B, ntok, Cn, dtype=torch.bfloat16, device=DEV)
+        L.cuboid_attention(qkv_bf16=qkv.to(torch.bfloat16).to(DEV), out_bf16=out, **kw)
+        return out.float().cpu(), ref
+    out = torch.zeros(B, ntok, Cn, device=DEV)
+    L.cuboid_attention(qkv_f32=qkv.to(DEV), out_f32=out, **kw)
+    return out.cpu(), ref
+
+
+LLL, DDD = ("l", "l", "l"), ("d", "d", "d")
+AXIAL = [((13, 16, 16), (13, 1, 1), 256, 4), ((13, 16, 16), (1, 16, 1), 256, 4), ((13, 16, 16), (1, 1, 16), 256, 4),
+         ((13, 8, 8), (13, 1, 1), 512, 4), ((13, 8, 8), (1, 8, 1), 512, 4), ((13, 8, 8), (1, 1, 8), 512, 4),
+         ((5, 8, 8), (5, 1, 1), 64, 2)]
+
+
+@pytest.mark.parametrize("shape,cuboid,Cn,heads", AXIAL)
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_attention_axial_bf16(shape, cuboid, Cn, heads, force_generic):
+    out, ref = _attn_case(shape, cuboid, (0, 0, 0), LLL, "zeros", Cn, heads, 2, "bf16", force_generic)
+    # bf16 probabilities / bf16 output rounding (MFMA path); the generic path keeps fp32 probabilities
+    assert rel_l2(out, ref) < 6e-3
+
+
+GENERIC = [((5, 8, 8), (2, 4, 4), (0, 0, 0), LLL, "zeros"), ((5, 8, 8), (2, 4, 4), (1, 2, 2), LLL, "zeros"),
+           ((5, 8, 8), (2, 4, 4), (1, 2, 2), LLL, "ignore"), ((5, 7, 6), (2, 4, 4), (1, 2, 2), LLL, "ignore"),
+           ((5, 8, 8), (1, 4, 4), (0, 0, 0), DDD, "zeros"), ((3, 8, 8), (4, 16, 2), (2, 1, 1), LLL, "ignore"),
+           ((5, 8, 8), (4, 4, 4), (0, 0, 0), DDD, "ignore"), ((13, 16, 16), (13, 1, 1), (0, 0, 0), LLL, "zeros")]
+
+
+@pytest.mark.parametrize("shape,cuboid,shift,strategy,padding_type", GENERIC)
+def test_attention_generic_fp32(shape, cuboid, shift, strategy, padding_type):
+    out, ref = _attn_case(shape, cuboid, shift, strategy, padding_type, 64, 2, 2, "fp32", False)
+    assert rel_l2(out, ref) < 1e-5
+
+
+def test_softmax_rows():
+    x = torch.randn(300, 256, device=DEV) * 4
+    out = torch.zeros(300, 256, dtype=torch.bfloat16, device=DEV)
+    lo = torch.zeros_like(out)
+    L.softmax_rows(x, out, lo, 300, 256, 256, 256)
+    assert rel_l2(out.float() + lo.float(), torch.softmax(x, -1)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ glue
+def test_glue_kernels():
+    from oracle import unet as OU
+    B, Tin, Tout, HW, Cn = 2, 3, 2, 16, 4
+    x, cond = torch.randn(B, Tout, HW, Cn, device=DEV), torch.randn(B, Tin, HW, Cn, device=DEV)
+    out = torch.full((B, Tin + Tout, HW, 8), 9.0, device=DEV)
+    L.unet_build_input(x, cond, out, B, Tin, Tout, HW, Cn, 8)
+    ref = torch.cat([cond, x], 1)
+    assert torch.equal(out[..., :Cn], ref)
+    assert torch.equal(out[:, :Tin, :, Cn], torch.ones(B, Tin, HW, device=DEV)) and float(out[:, Tin:, :, Cn].abs().max()) == 0
+    assert float(out[..., Cn + 1:].abs().max()) == 0
+    t = torch.tensor([0, 1, 17, 500, 999], device=DEV)
+    emb = torch.empty(5, 256, device=DEV)
+    L.timestep_embedding(t, L.timestep_freqs(256, device=DEV), emb, 5, 256)
+    assert rel_l2(emb, OU.timestep_embedding(t.cpu(), 256)) < 2e-6      # cosf/sinf ulps only (args up to ~1e3 rad)
+    xs, Wm, bm = torch.randn(5, 256, device=DEV), torch.randn(1024, 256, device=DEV) / 16, torch.randn(1024, device=DEV)
+    o = torch.empty(5, 1024, device=DEV)
+    L.linear_small(xs, Wm, bm, o, 5, 256, 1024, act_in="silu", act_out="silu")
+    assert rel_l2(o, F.silu(F.linear(F.silu(xs), Wm, bm))) < 1e-5
+    a = torch.randn(2, 6, 5, device=DEV)
+    tab = torch.randn(6, 5, device=DEV)
+    r = a + tab
+    L.add_rowtable(a, tab, 2, 6, 5)
+    assert torch.allclose(a, r)
+    n = torch.randn(3, 7, 5, 5, device=DEV)
+    o1 = torch.empty(3, 25, 8, device=DEV)
+    L.nchw_to_nhwc(n, o1, 3, 7, 25, 8)
+    assert torch.equal(o1[..., :7], n.reshape(3, 7, 25).permute(0, 2, 1)) and float(o1[..., 7].abs().max()) == 0
+    o2 = torch.empty(3, 7, 25, device=DEV)
+    L.nhwc_to_nchw(o1, o2, 3, 7, 25, 8)
+    assert torch.equal(o2.reshape(3, 7, 5, 5), n)
+
+
+def test_diffusion_steps():
+    from oracle import diffusion as OD
+    buf = {k: torch.as_tensor(v) for k, v in OD.schedule_buffers(OD.beta_schedule("linear", 1000)).items()}
+    coef = torch.stack([buf[k] for k in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+                                         "posterior_mean_coef2", "posterior_log_variance_clipped")]).contiguous().to(DEV)
+    B, per = 4, 6 * 16 * 16 * 8
+    zt, eps, noise, shift = (torch.randn(B, per) for _ in range(4))
+    t = torch.tensor([999, 500, 1, 0])
+    out = torch.empty(B, per, device=DEV)
+    L.ddpm_step(zt.to(DEV), eps.to(DEV), noise.to(DEV), None, t.to(DEV), coef, 1000, out, B, per)
+    assert rel_l2(out, OD.ddpm_step(buf, zt, eps, t, noise)) < 2e-6
+    L.ddpm_step(zt.to(DEV), eps.to(DEV), noise.to(DEV), shift.to(DEV), t.to(DEV), coef, 1000, out, B, per)
+    assert rel_l2(out, OD.ddpm_step(buf, zt, eps, t, noise, mean_shift=shift)) < 2e-6
+    a_t, a_prev, sig = buf["alphas_cumprod"][t.clamp_min(21)], buf["alphas_cumprod"][t.clamp_min(21) - 20], torch.rand(B) * 0.1
+    c = torch.stack([a_t, a_prev, sig], 1).contiguous().to(DEV)
+    L.ddim_step(zt.to(DEV), eps.to(DEV), noise.to(DEV), c, out, B, per)
+    assert rel_l2(out, OD.ddim_step(zt, eps, a_t, a_prev, sig, noise)) < 2e-6
