@@ -27,6 +27,8 @@ enum pd_act { PD_ACT_NONE = 0, PD_ACT_GELU = 1, PD_ACT_SILU = 2, PD_ACT_LEAKY = 
 
 int pd_abi_version(void);
 const char* pd_last_error(void);
+int pd_sizeof_igemm_args(void);         /* binding self-check: sizeof the argument structs below */
+int pd_sizeof_cuboid_attn_args(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * pd_igemm: implicit-GEMM on the MFMA pipes (bf16 x bf16 -> fp32 accumulate).
@@ -58,6 +60,7 @@ typedef struct pd_igemm_args {
   int32_t lda, ldw;
   int32_t B, Ti, Hi, Wi, To, Ho, Wo;      /* conv geometry (input dims before up-sampling) */
   int32_t KT, KH, KW, st, sh, sw, pt, ph, pw, ut, uh, uw;
+  int32_t vT, vH, vW;      /* size of the (virtually up-sampled) input the taps are bounds-checked against; 0 = Ti*ut etc. */
   int32_t rows_per_sample, ld_rowvec, ld_res, res_period, ld_mul, act, ld_out, ld_outb, split;
   float alpha;
   int32_t tile;            /* 0 = auto, 1 = 128x128, 2 = 64x64 */

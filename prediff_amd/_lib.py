@@ -28,7 +28,7 @@ class IgemmArgs(C.Structure):
                  "w_tap_stride")] + \
                [(n, C.c_int32) for n in
                 ("nbatch", "M", "N", "Cin", "taps", "lda", "ldw", "B", "Ti", "Hi", "Wi", "To", "Ho", "Wo",
-                 "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw", "ut", "uh", "uw",
+                 "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw", "ut", "uh", "uw", "vT", "vH", "vW",
                  "rows_per_sample", "ld_rowvec", "ld_res", "res_period", "ld_mul", "act", "ld_out", "ld_outb", "split")] + \
                [("alpha", C.c_float), ("tile", C.c_int32), ("vec_epilogue", C.c_int32)]
 
@@ -45,6 +45,8 @@ _lib = None
 _PROTOS = {
     "pd_abi_version": (C.c_int, []),
     "pd_last_error": (C.c_char_p, []),
+    "pd_sizeof_igemm_args": (C.c_int, []),
+    "pd_sizeof_cuboid_attn_args": (C.c_int, []),
     "pd_igemm": (C.c_int, [C.POINTER(IgemmArgs), C.c_void_p]),
     "pd_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pd_patch_merge_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_void_p]),
@@ -80,6 +82,9 @@ def lib():
             f = getattr(l, name)      # AttributeError if a declared symbol is missing
             f.restype = res
             f.argtypes = args
+        if l.pd_sizeof_igemm_args() != C.sizeof(IgemmArgs) or l.pd_sizeof_cuboid_attn_args() != C.sizeof(CuboidAttnArgs):
+            raise PrediffHipError(f"{LIB_PATH} is stale: its argument structs do not match prediff_amd/_lib.py "
+                                  f"(rebuild with `make -C prediff_amd/csrc`)")
         _lib = l
     return _lib
 
@@ -150,13 +155,16 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
     _check(lib().pd_igemm(C.byref(a), stream_ptr()), "pd_igemm")
 
 
-def conv_geom(B, in_thw, kernel, stride=(1, 1, 1), pad=(1, 1, 1), up=(1, 1, 1), out_thw=None):
+def conv_geom(B, in_thw, kernel, stride=(1, 1, 1), pad=(1, 1, 1), up=(1, 1, 1), out_thw=None, virt_thw=None):
+    """virt_thw: size of the nearest-up-sampled input when it is not exactly in_thw*up (odd target sizes)."""
     Ti, Hi, Wi = in_thw
     KT, KH, KW = kernel
     if out_thw is None:
-        out_thw = tuple((s * u + 2 * p - k) // st + 1 for s, u, p, k, st in zip(in_thw, up, pad, kernel, stride))
+        v = virt_thw if virt_thw is not None else tuple(s * u for s, u in zip(in_thw, up))
+        out_thw = tuple((s + 2 * p - k) // st + 1 for s, p, k, st in zip(v, pad, kernel, stride))
     To, Ho, Wo = out_thw
-    return dict(B=B, Ti=Ti, Hi=Hi, Wi=Wi, To=To, Ho=Ho, Wo=Wo, KT=KT, KH=KH, KW=KW, st=stride[0], sh=stride[1],
+    vt, vh, vw = virt_thw if virt_thw is not None else (0, 0, 0)
+    return dict(vT=vt, vH=vh, vW=vw, B=B, Ti=Ti, Hi=Hi, Wi=Wi, To=To, Ho=Ho, Wo=Wo, KT=KT, KH=KH, KW=KW, st=stride[0], sh=stride[1],
                 sw=stride[2], pt=pad[0], ph=pad[1], pw=pad[2], ut=up[0], uh=up[1], uw=up[2])
 
 

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
   }
   const int kchunks = p.Cin >> 6;
   const int nk = p.taps * kchunks;
-  const int vT = p.Ti * p.ut, vH = p.Hi * p.uh, vW = p.Wi * p.uw;
+  const int vT = p.vT > 0 ? p.vT : p.Ti * p.ut, vH = p.vH > 0 ? p.vH : p.Hi * p.uh, vW = p.vW > 0 ? p.vW : p.Wi * p.uw;
   const int khw = p.KH * p.KW;
 
   uint32_t aoff[AI];   // element offset of (row, this tap, chunk) or 0xffffffff
