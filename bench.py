@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising-steps/sec of the PreDiff sampling hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one DDIM step (eta = 0) of the Earthformer-UNet denoiser for a batch of `--batch` independent latent
+trajectories per GPU at the SEVIR-LR v1 configuration (BASELINE.json configs[1]: latent 6x16x16x64 <- 6x128x128
+frames, context 7 frames, 136.8 M-parameter denoiser, bf16 MFMA operands / fp32 accumulate, no knowledge alignment):
+denoiser forward + fused step epilogue, replayed from one HIP graph.  Weights are seeded random (no checkpoints
+offline), inputs synthetic; everything is resident in HBM before the timed region.  value = trajectory-steps per
+second over the whole job = gpus * batch * steps / wall (max over ranks).  Ranks are independent ensemble shards
+(weak scaling, no data-path collective; the only exchange of the real sampler is the final all-gather of decoded
+frames, outside the step loop).
+
+Two extra objects on the JSON line:
+  roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM, igemm_kernel<128,128,false,2>): algorithmic FLOPs per
+                 launch / its average launch duration measured here with HIP events, against the dense bf16 MFMA peak.
+  cpu_baseline - the oracle (CPU restatement of the reference forward) timed on this box's host cores on a bounded
+                 sample of the same workload (kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF; 2495 TF measured)
+UNET_GFLOP_PER_STEP = 653.4        # one denoiser forward, one trajectory (2*MAC)
+CONV3D_GFLOP_PER_STEP = 376.9 + 14.9   # 32 TimeEmbedResBlock convs + first_proj
+CONV3D_LAUNCHES_PER_STEP = 34
+
+
+def v1_model(precision, device):
+    from _cases import V1_UNET_CFG
+    from _weights import seeded_state_dict
+    from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
+    from prediff_amd.latent_diffusion import LatentDiffusion
+    net = CuboidTransformerUNet(**V1_UNET_CFG, precision=precision)
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 1234))
+    ldm = LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(6, 128, 128, 1), timesteps=1000,
+                          beta_schedule="linear", use_ema=False, latent_shape=(6, 16, 16, 64), first_stage_model=None,
+                          cond_stage_model=None, scale_factor=1.0)
+    return ldm.to(device).eval()
+
+
+def conv3d_kernel_time(ldm, B, device, reps=3):
+    """Average duration (s) of the Conv3d implicit-GEMM launches of one denoiser forward, measured with HIP events on
+    the launch stream (eager mode: one event pair per launch)."""
+    from prediff_amd import _lib as L
+    net = ldm.torch_nn_module
+    z = torch.randn(ldm.get_batch_latent_shape(B), device=device)
+    zc = torch.randn((B, 7, 16, 16, 64), device=device)
+    t = torch.full((B,), 500, dtype=torch.long, device=device)
+    orig = L.igemm
+    pairs = []
+
+    def timed(*a, **k):
+        if k.get("taps", 1) == 27:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(*a, **k)
+            e1.record()
+            pairs.append((e0, e1))
+        else:
+            orig(*a, **k)
+    net(z, t, zc)
+    L.igemm = timed
+    try:
+        for _ in range(reps):
+            net(z, t, zc)
+    finally:
+        L.igemm = orig
+    torch.cuda.synchronize(device)
+    total_ms = sum(a.elapsed_time(b) for a, b in pairs)
+    return total_ms * 1e-3 / len(pairs), len(pairs) // reps
+
+
+def cpu_baseline(budget_s=15.0):
+    """Oracle forward (fp32, B=1) on the host cores: bounded sample of the same workload."""
+    from _cases import V1_UNET_CFG
+    from _templates import unet_template
+    from _weights import seeded_input, seeded_state_dict
+    from oracle import unet as OU
+    sd = seeded_state_dict(unet_template(V1_UNET_CFG, "v1_unet_schema.json"), 1234)
+    x, c = seeded_input("v1x", (1, 6, 16, 16, 64), 2), seeded_input("v1c", (1, 7, 16, 16, 64), 3)
+    t = torch.tensor([500])
+    with torch.no_grad():
+        OU.unet_forward(sd, V1_UNET_CFG, x, t, c)      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            OU.unet_forward(sd, V1_UNET_CFG, x, t, c)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 12:
+                break
+    return {"value": round(n / el, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} oracle denoiser forwards (fp32, B=1, v1 config, torch CPU {torch.get_num_threads()} threads) in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="latent trajectories (ensemble members) per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import numpy as np
+    from prediff_amd import _lib as L
+    from prediff_amd.schedule import make_ddim_sampling_parameters, make_ddim_timesteps
+    B = args.batch
+    ldm = v1_model(args.precision, device)
+    shape = ldm.get_batch_latent_shape(B)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    zc = torch.randn((B, 7, 16, 16, 64), generator=g).to(device)
+    z = torch.randn(shape, generator=g).to(device)
+
+    # DDIM-50 schedule of the reference helpers, cycled if steps > 50
+    steps = np.minimum(make_ddim_timesteps("uniform", 50, 1000), 999)
+    sig, a, a_prev = make_ddim_sampling_parameters(ldm._alphas_cumprod_f64.astype(np.float32).astype(np.float64), steps, 0.0)
+    order = list(reversed(range(len(steps))))
+    n_total = args.warmup + args.steps
+    t_all = torch.tensor([[int(steps[order[k % 50]])] * B for k in range(n_total)], dtype=torch.int64, device=device)
+    coef_all = torch.tensor([[[a[order[k % 50]], a_prev[order[k % 50]], sig[order[k % 50]]]] * B for k in range(n_total)],
+                            dtype=torch.float32, device=device)
+
+    if args.no_graph:
+        st = None
+        out = torch.empty_like(z)
+        noise0 = torch.zeros_like(z)
+    else:
+        st = ldm._graph_step("ddim", B, zc, device)
+        st["noise"].zero_()
+        st["z"].copy_(z)
+
+    def one_step(k):
+        nonlocal z
+        if st is not None:
+            st["t"].copy_(t_all[k])
+            st["coef"].copy_(coef_all[k])
+            st["graph"].replay()
+            st["z"].copy_(st["out"])
+        else:
+            eps = ldm.apply_model(z, t_all[k], zc)
+            L.ddim_step(z, eps, noise0, coef_all[k], out, B, z[0].numel())
+            z.copy_(out)
+
+    for k in range(args.warmup):
+        one_step(k)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(args.warmup, n_total):
+        one_step(k)
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    final = st["z"] if st is not None else z
+    assert bool(torch.isfinite(final).all()), "non-finite latents after the timed steps"
+
+    if rank == 0:
+        n_gpus = world
+        value = n_gpus * B * args.steps / elapsed
+        ker_s, launches = conv3d_kernel_time(ldm, B, device)
+        flops_per_launch = CONV3D_GFLOP_PER_STEP * 1e9 * B / CONV3D_LAUNCHES_PER_STEP
+        achieved = flops_per_launch / ker_s / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "conv3d_hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(f"B{B}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "denoising_steps_per_sec", "value": round(value, 2), "unit": "steps/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision if args.precision == "bf16" else "bf16x3",
+            "data": "synthetic (seeded random weights of the v1 architecture, N(0,1) latents/context)",
+            "config": {"workload": "SEVIR-LR 7->6 x128x128 (latent 13x16x16, C 256/512, depth [4,4], axial), DDIM-50 eta=0, "
+                                   "no knowledge alignment (BASELINE.json configs[1])",
+                       "trajectories_per_gpu": B, "global_trajectories": B * n_gpus, "sampler": "ddim50", "hip_graph": st is not None,
+                       "parallelism": f"ensemble-shard x{n_gpus}"},
+            "step_tflops": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12, 2),
+            "step_frac_of_bf16_peak": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<128,128,false,2> (Conv3d 3x3x3 implicit GEMM)",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches,
+                         "gflop_per_launch": round(flops_per_launch / 1e9, 3)},
+        }
+        if not args.no_cpu_baseline and n_gpus == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

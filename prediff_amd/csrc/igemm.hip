@@ -25,7 +25,8 @@ __device__ __attribute__((aligned(64))) uint32_t g_pd_zero_page[32];   // 128 B 
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                    (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
-template <int BM, int BN, bool SPLIT>
+// KIND only tags the instantiation (0 linear, 1 conv2d, 2 conv3d) so that profilers report the three uses separately.
+template <int BM, int BN, bool SPLIT, int KIND>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
   constexpr int BK = 64;
   constexpr int A_TILE = BM * BK * 2;   // bytes
@@ -248,12 +249,12 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
   }
 }
 
-template <int BM, int BN, bool SPLIT>
+template <int BM, int BN, bool SPLIT, int KIND>
 static int launch_igemm(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 64 * 2 * (SPLIT ? 2 : 1);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, SPLIT>,
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, SPLIT, KIND>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
@@ -263,7 +264,7 @@ static int launch_igemm(const pd_igemm_args& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, 1, a.nbatch > 0 ? a.nbatch : 1);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, SPLIT>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, SPLIT, KIND>), grid, dim3(256), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -294,6 +295,12 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.nbatch > 0 ? a.nbatch : 1);
     tile = t128 >= 192 ? 1 : 2;
   }
-  if (a.split) return tile == 1 ? launch_igemm<128, 128, true>(a, s) : launch_igemm<64, 64, true>(a, s);
-  return tile == 1 ? launch_igemm<128, 128, false>(a, s) : launch_igemm<64, 64, false>(a, s);
+  const int kind = a.taps == 1 ? 0 : (a.KT == 1 ? 1 : 2);
+#define PD_DISPATCH(KIND)                                                                                         \
+  if (a.split) return tile == 1 ? launch_igemm<128, 128, true, KIND>(a, s) : launch_igemm<64, 64, true, KIND>(a, s); \
+  return tile == 1 ? launch_igemm<128, 128, false, KIND>(a, s) : launch_igemm<64, 64, false, KIND>(a, s);
+  if (kind == 0) { PD_DISPATCH(0) }
+  if (kind == 1) { PD_DISPATCH(1) }
+  PD_DISPATCH(2)
+#undef PD_DISPATCH
 }

@@ -64,3 +64,24 @@ def test_cpu_forward_fails_loudly():
     net = CuboidTransformerUNet(**cfg)
     with pytest.raises(PrediffHipError):
         net(torch.zeros(1, *cfg["target_shape"]), torch.zeros(1, dtype=torch.long), torch.zeros(1, *cfg["input_shape"]))
+
+
+# ------------------------------------------------------------------------------------------------ VAE
+def test_vae_state_dict_schema():
+    from _cases import TINY_VAE_CFG, V1_VAE_CFG
+    from prediff_amd.autoencoder_kl import AutoencoderKL
+    vae = AutoencoderKL(**TINY_VAE_CFG)
+    ref = _schema("tiny_vae_schema.json")
+    sd = vae.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert list(v.shape) == ref[k], k
+    vae = AutoencoderKL(**V1_VAE_CFG)
+    ref = _schema("v1_vae_schema.json")
+    sd = vae.state_dict()
+    assert len(sd) == 248 and list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert [list(v.shape), "float32"] == ref[k], k
+    from prediff_amd._lib import PrediffHipError
+    with pytest.raises(PrediffHipError):
+        vae.encode(torch.zeros(1, 1, 128, 128))
