@@ -1,0 +1,335 @@
+"""Knowledge alignment (guided sampling) -- stays in PyTorch autograd by design (BASELINE.json north_star).
+
+Reference: diffusion/knowledge_alignment/sevir.py:7-104 (SEVIRAvgIntensityAlignment), models.py:19-528
+(NoisyCuboidTransformerEncoder, AttentionPool3d, QKVAttention), alignment_pl.py:423-446 (get_sample_align_fn).
+
+The guidance term of one denoising step is  guide_scale * grad_{z_t} || mean_tau U_phi(z_t, t)[b, tau] - avg_x_gt[b] ||_2
+(the L2 norm spans the whole batch, sevir.py:81-82).  U_phi is a small half-U-Net built from the same blocks as the
+denoiser; because its *gradient* is needed it runs as ordinary differentiable PyTorch ops (on the GPU through
+PyTorch-ROCm, or on CPU), on modules that keep the reference's constructor keywords and ``state_dict`` schema so the
+reference checkpoint ``pretrained_sevirlr_alignment_avg_x_cuboid_v1.pt`` loads strictly.  The cuboid decomposition
+reuses prediff_amd.cuboid_geometry (gather / scatter by token index instead of the reference's reshape-permute chain).
+"""
+import math
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .cuboid_geometry import attention_tables
+from .cuboid_transformer_unet import (CuboidSelfAttentionLayer, PatchMerging3D, PosEmbed, PositionwiseFFN,
+                                      StackCuboidSelfAttentionBlock, TimeEmbedLayer, TimeEmbedResBlock,
+                                      apply_initialization, round_to)
+from .patterns import CuboidSelfAttentionPatterns
+
+_ACT = {"leaky": lambda v: F.leaky_relu(v, 0.1), "gelu": F.gelu, "relu": F.relu, "silu": F.silu, "identity": lambda v: v}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# differentiable forwards of the parameter-holder modules (channels-last, (B, T, H, W, C))
+# ----------------------------------------------------------------------------------------------------------------------
+def timestep_embedding(t, dim, max_period=10000):
+    """models/utils.py:68-88"""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(t.device)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def resblock_forward(m: TimeEmbedResBlock, x, emb=None):
+    """models/time_embed.py:134-169 on channels-last input."""
+    xc = x.permute(0, 4, 1, 2, 3)
+    h = m.in_layers[2](F.silu(m.in_layers[0](xc)))
+    if m.use_embed:
+        e = m.emb_layers[1](F.silu(emb)).type(h.dtype)[:, :, None, None, None]
+        if m.use_scale_shift_norm:
+            scale, shift = torch.chunk(e, 2, dim=1)
+            h = m.out_layers[3](F.silu(m.out_layers[0](h) * (1 + scale) + shift))
+        else:
+            h = m.out_layers[3](F.silu(m.out_layers[0](h + e)))
+    else:
+        h = m.out_layers[3](F.silu(m.out_layers[0](h)))
+    return (m.skip_connection(xc) + h).permute(0, 2, 3, 4, 1)
+
+
+def attention_forward(at: CuboidSelfAttentionLayer, x, tables):
+    """cuboid_transformer.py:812-966 (no global vectors): returns the layer output (no residual)."""
+    B, T, H, W, C = x.shape
+    S = T * H * W
+    tok = tables["tok_index"].to(x.device).long()
+    nc, vol = tok.shape
+    h = at.norm(x).reshape(B, S, C)
+    h = torch.cat([h, h.new_zeros(B, 1, C)], dim=1)                  # row S = the zero padding token
+    gather = torch.where(tok >= 0, tok, torch.full_like(tok, S)).reshape(-1)
+    xr = h[:, gather].reshape(B, nc, vol, C)
+    hd = C // at.num_heads
+    qkv = at.qkv(xr).reshape(B, nc, vol, 3, at.num_heads, hd).permute(3, 0, 4, 1, 2, 5)
+    q, k, v = qkv[0] * at.scale, qkv[1], qkv[2]
+    score = q @ k.transpose(-2, -1)
+    if at.use_relative_pos:
+        idx = at.relative_position_index[:vol, :vol].reshape(-1)
+        bias = at.relative_position_bias_table[idx].reshape(vol, vol, -1).permute(2, 0, 1)
+        score = score + bias.unsqueeze(1)
+    if tables["mask"] is not None:
+        mask = tables["mask"].to(x.device).bool()
+        score = score.masked_fill(~mask, -1e4 if score.dtype == torch.float16 else -1e18)
+        att = torch.softmax(score, dim=-1) * mask
+    else:
+        att = torch.softmax(score, dim=-1)
+    y = (att @ v).permute(0, 2, 3, 1, 4).reshape(B, nc * vol, C)
+    if at.use_final_proj:
+        y = at.proj(y)
+    out = y.new_zeros(B, S + 1, C).index_copy(1, gather, y)          # padded slots land in the dummy row
+    return out[:, :S].reshape(B, T, H, W, C)
+
+
+def ffn_forward(ff: PositionwiseFFN, x):
+    """cuboid_transformer.py:182-208 (pre-norm)."""
+    h = ff.layer_norm(x)
+    act = _ACT[ff.activation_name]
+    h = act(ff.ffn_1_gate(h)) * ff.ffn_1(h) if ff.gated else act(ff.ffn_1(h))
+    return ff.ffn_2(h) + x
+
+
+def stack_forward(blk: StackCuboidSelfAttentionBlock, x, tables):
+    for a, at in enumerate(blk.attn_l):
+        x = x + attention_forward(at, x, tables[a])
+        if blk.use_inter_ffn:
+            x = ffn_forward(blk.ffn_l[a], x)
+    if not blk.use_inter_ffn:
+        x = ffn_forward(blk.ffn_l[0], x)
+    return x
+
+
+def patch_merge_forward(pm: PatchMerging3D, x):
+    """cuboid_transformer.py:261-296"""
+    B, T, H, W, C = x.shape
+    d = pm.downsample
+    pt, ph, pw = [(d[i] - s % d[i]) % d[i] for i, s in enumerate((T, H, W))]
+    if ph or pw:
+        if pm.padding_type == "nearest":
+            x = F.interpolate(x.permute(0, 4, 1, 2, 3), size=(T + pt, H + ph, W + pw)).permute(0, 2, 3, 4, 1)
+        else:
+            x = F.pad(x, (0, 0, 0, pw, 0, ph, 0, pt))
+        T, H, W = T + pt, H + ph, W + pw
+    x = x.reshape(B, T // d[0], d[0], H // d[1], d[1], W // d[2], d[2], C).permute(0, 1, 3, 5, 2, 4, 6, 7)
+    x = x.reshape(B, T // d[0], H // d[1], W // d[2], d[0] * d[1] * d[2] * C)
+    return pm.reduction(pm.norm(x))
+
+
+def pos_embed_forward(pe: PosEmbed, x):
+    _, T, H, W, C = x.shape
+    return x + pe.table(T, H, W).reshape(T, H, W, C).to(x.dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class QKVAttention(nn.Module):
+    """models.py:19-46"""
+
+    def __init__(self, n_heads):
+        super().__init__()
+        self.n_heads = n_heads
+
+    def forward(self, qkv):
+        bs, width, length = qkv.shape
+        assert width % (3 * self.n_heads) == 0
+        ch = width // (3 * self.n_heads)
+        q, k, v = qkv.chunk(3, dim=1)
+        scale = 1 / math.sqrt(math.sqrt(ch))
+        weight = torch.einsum("bct,bcs->bts", (q * scale).view(bs * self.n_heads, ch, length),
+                              (k * scale).view(bs * self.n_heads, ch, length))
+        weight = torch.softmax(weight.float(), dim=-1).type(weight.dtype)
+        a = torch.einsum("bts,bcs->bct", weight, v.reshape(bs * self.n_heads, ch, length))
+        return a.reshape(bs, -1, length)
+
+
+class AttentionPool3d(nn.Module):
+    """models.py:49-104"""
+
+    def __init__(self, data_dim: int, embed_dim: int, num_heads: int, output_dim: int = None, init_mode: str = "0"):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(embed_dim, data_dim + 1) / embed_dim ** 0.5)
+        self.qkv_proj = nn.Conv1d(embed_dim, 3 * embed_dim, 1)
+        self.c_proj = nn.Conv1d(embed_dim, output_dim or embed_dim, 1)
+        self.num_heads = num_heads
+        self.attention = QKVAttention(self.num_heads)
+        self.init_mode = init_mode
+
+    def forward(self, x):
+        b, c, *_ = x.shape
+        x = x.reshape(b, c, -1)
+        x = torch.cat([x.mean(dim=-1, keepdim=True), x], dim=-1)
+        x = x + self.positional_embedding[None, :, :].to(x.dtype)
+        x = self.c_proj(self.attention(self.qkv_proj(x)))
+        return x[:, :, 0]
+
+    def reset_parameters(self):
+        self.qkv_proj.reset_parameters()
+        self.c_proj.reset_parameters()
+
+
+class NoisyCuboidTransformerEncoder(nn.Module):
+    """Half U-Net U_phi(z_t, t) with a pooled read-out (models.py:107-528); pool="attention" as in every shipped config."""
+
+    def __init__(self, input_shape, out_channels=1, base_units=128, block_units=None, scale_alpha=1.0, depth=[4, 4, 4],
+                 downsample=2, downsample_type="patch_merge", block_attn_patterns=None,
+                 block_cuboid_size=[(4, 4, 4), (4, 4, 4)], block_cuboid_strategy=[("l", "l", "l"), ("d", "d", "d")],
+                 block_cuboid_shift_size=[(0, 0, 0), (0, 0, 0)], num_heads=4, attn_drop=0.0, proj_drop=0.0, ffn_drop=0.0,
+                 ffn_activation="gelu", gated_ffn=False, norm_layer="layer_norm", use_inter_ffn=True,
+                 hierarchical_pos_embed=False, pos_embed_type="t+h+w", padding_type="zeros", checkpoint_level=True,
+                 use_relative_pos=True, self_attn_use_final_proj=True, num_global_vectors=0, use_global_vector_ffn=True,
+                 use_global_self_attn=False, separate_global_qkv=False, global_dim_ratio=1, attn_linear_init_mode="0",
+                 ffn_linear_init_mode="0", ffn2_linear_init_mode="2", attn_proj_linear_init_mode="2", conv_init_mode="0",
+                 down_linear_init_mode="0", global_proj_linear_init_mode="2", norm_init_mode="0",
+                 time_embed_channels_mult=4, time_embed_use_scale_shift_norm=False, time_embed_dropout=0.0,
+                 pool: str = "attention", readout_seq: bool = True, out_len: int = None):
+        super().__init__()
+        if num_global_vectors:
+            raise NotImplementedError("global vectors are dead at every shipped config")
+        if pool != "attention" or downsample_type != "patch_merge" or norm_layer != "layer_norm":
+            raise NotImplementedError
+        self.input_shape, self.out_channels = input_shape, out_channels
+        self.num_blocks, self.depth, self.base_units = len(depth), list(depth), base_units
+        if not isinstance(downsample, (tuple, list)):
+            downsample = (1, downsample, downsample)
+        if block_units is None:
+            block_units = [round_to(base_units * int((max(downsample) ** scale_alpha) ** i), 4) for i in range(self.num_blocks)]
+        self.block_units = block_units
+        self.hierarchical_pos_embed = hierarchical_pos_embed
+        self.time_embed_channels = block_units[0] * time_embed_channels_mult
+        self.pool, self.readout_seq, self.out_len = pool, readout_seq, out_len
+        self.norm_init_mode = norm_init_mode
+        T_in, H_in, W_in, C_in = input_shape
+        self.first_proj = TimeEmbedResBlock(channels=C_in, emb_channels=None, dropout=proj_drop, out_channels=base_units,
+                                            use_embed=False, dims=3)
+        self.pos_embed = PosEmbed(embed_dim=base_units, typ=pos_embed_type, maxT=T_in, maxH=H_in, maxW=W_in)
+        self.time_embed = TimeEmbedLayer(base_channels=block_units[0], time_embed_channels=self.time_embed_channels)
+        if self.num_blocks > 1:
+            self.downsample_layers = nn.ModuleList([
+                PatchMerging3D(dim=block_units[i], downsample=downsample, padding_type=padding_type, out_dim=block_units[i + 1],
+                               linear_init_mode=down_linear_init_mode, norm_init_mode=norm_init_mode)
+                for i in range(self.num_blocks - 1)])
+            if hierarchical_pos_embed:
+                self.down_hierarchical_pos_embed_l = nn.ModuleList([
+                    PosEmbed(embed_dim=block_units[i], typ=pos_embed_type, maxT=self.mem_shapes[i][0],
+                             maxH=self.mem_shapes[i][1], maxW=self.mem_shapes[i][2]) for i in range(self.num_blocks - 1)])
+        if block_attn_patterns is not None:
+            if not isinstance(block_attn_patterns, (tuple, list)):
+                block_attn_patterns = [block_attn_patterns] * self.num_blocks
+            block_cuboid_size, block_cuboid_strategy, block_cuboid_shift_size = [], [], []
+            for idx, key in enumerate(block_attn_patterns):
+                cs, st, sh = CuboidSelfAttentionPatterns.get(key)(self.mem_shapes[idx])
+                block_cuboid_size.append(cs), block_cuboid_strategy.append(st), block_cuboid_shift_size.append(sh)
+        else:
+            rep = lambda v: [v] * self.num_blocks if not isinstance(v[0][0], (list, tuple)) else v
+            block_cuboid_size, block_cuboid_strategy, block_cuboid_shift_size = rep(block_cuboid_size), rep(block_cuboid_strategy), rep(block_cuboid_shift_size)
+        self.block_cuboid_size, self.block_cuboid_strategy, self.block_cuboid_shift_size = block_cuboid_size, block_cuboid_strategy, block_cuboid_shift_size
+        down_self, down_te = [], []
+        for i in range(self.num_blocks):
+            down_te.append(TimeEmbedResBlock(channels=self.mem_shapes[i][-1], emb_channels=self.time_embed_channels,
+                                             dropout=time_embed_dropout, out_channels=self.mem_shapes[i][-1], use_embed=True,
+                                             use_scale_shift_norm=time_embed_use_scale_shift_norm, dims=3))
+            down_self.append(nn.ModuleList([
+                StackCuboidSelfAttentionBlock(
+                    dim=self.mem_shapes[i][-1], num_heads=num_heads, block_cuboid_size=block_cuboid_size[i],
+                    block_strategy=block_cuboid_strategy[i], block_shift_size=block_cuboid_shift_size[i],
+                    activation=ffn_activation, gated_ffn=gated_ffn, use_inter_ffn=use_inter_ffn, padding_type=padding_type,
+                    use_relative_pos=use_relative_pos, use_final_proj=self_attn_use_final_proj,
+                    attn_linear_init_mode=attn_linear_init_mode, ffn_linear_init_mode=ffn_linear_init_mode,
+                    ffn2_linear_init_mode=ffn2_linear_init_mode, attn_proj_linear_init_mode=attn_proj_linear_init_mode,
+                    norm_init_mode=norm_init_mode) for _ in range(depth[i])]))
+        self.down_self_blocks = nn.ModuleList(down_self)
+        self.down_time_embed_blocks = nn.ModuleList(down_te)
+        out_shape = self.mem_shapes[-1]
+        cc = out_shape[-1]
+        data_dim = int(np.prod(out_shape[1:-1])) if readout_seq else int(np.prod(out_shape[:-1]))
+        self.out = nn.Sequential(nn.GroupNorm(min(cc, 32), cc), nn.SiLU(), AttentionPool3d(data_dim, cc, num_heads, out_channels, init_mode="0"))
+        apply_initialization(self.out[0], norm_mode=norm_init_mode)
+        self.out[2].reset_parameters()
+        self._tables = [[attention_tables(self.mem_shapes[i][:3], cs, sh, st, padding_type)
+                         for cs, sh, st in zip(block_cuboid_size[i], block_cuboid_shift_size[i], block_cuboid_strategy[i])]
+                        for i in range(self.num_blocks)]
+
+    @property
+    def mem_shapes(self):
+        inner = tuple(self.input_shape)[:3] + (self.base_units,)
+        if self.num_blocks == 1:
+            return [inner]
+        shapes, cur = [inner], inner
+        for layer in self.downsample_layers:
+            cur = layer.get_out_shape(cur)
+            shapes.append(cur)
+        return shapes
+
+    def forward(self, x, t, verbose=False, **kwargs):
+        """x (B,T,H,W,C), t (B,) -> (B, out_len, out_channels); extra kwargs (zc, y, avg_x_gt, ...) are ignored exactly as
+        the reference does (models.py:459)."""
+        B, seq_len = x.shape[0], x.shape[1]
+        x = resblock_forward(self.first_proj, x)
+        x = pos_embed_forward(self.pos_embed, x)
+        t_emb = self.time_embed.layer(timestep_embedding(t, self.block_units[0]))
+        for i in range(self.num_blocks):
+            if i > 0:
+                x = patch_merge_forward(self.downsample_layers[i - 1], x)
+                if self.hierarchical_pos_embed:
+                    x = pos_embed_forward(self.down_hierarchical_pos_embed_l[i - 1], x)
+            for d in range(self.depth[i]):
+                x = resblock_forward(self.down_time_embed_blocks[i], x, t_emb)
+                x = stack_forward(self.down_self_blocks[i][d], x, self._tables[i])
+        if self.readout_seq:
+            if self.out_len is not None:
+                seq_len = self.out_len
+                x = x[:, -self.out_len:, ...]
+            Bx, T, H, W, C = x.shape
+            out = x.permute(0, 1, 4, 2, 3).reshape(Bx * T, C, H * W)          # "(b t) c (h w)"
+            return self.out(out).reshape(B, seq_len, -1)
+        Bx, T, H, W, C = x.shape
+        return self.out(x.permute(0, 4, 1, 2, 3).reshape(Bx, C, T * H * W))
+
+
+def get_sample_align_fn(sample_align_model):
+    """grad of the (scalar-summed) alignment objective w.r.t. the noisy latent (alignment_pl.py:423-446)."""
+    def sample_align_fn(x, *args, **kwargs):
+        with torch.enable_grad():
+            x_in = x.detach().requires_grad_(True)
+            logits = sample_align_model(x_in, *args, **kwargs)
+            return torch.autograd.grad(logits.sum(), x_in, allow_unused=True)[0]
+    return sample_align_fn
+
+
+class SEVIRAvgIntensityAlignment:
+    """sevir.py:7-104"""
+
+    def __init__(self, alignment_type: str = "avg_x", guide_scale: float = 1.0, model_type: str = "cuboid",
+                 model_args: Dict[str, Any] = None, model_ckpt_path: str = None):
+        assert alignment_type in ["avg_x"], f"alignment_type {alignment_type} is not supported"
+        self.alignment_type, self.guide_scale = alignment_type, guide_scale
+        if model_type != "cuboid":
+            raise NotImplementedError(f"model_type={model_type} is not implemented")
+        self.model = NoisyCuboidTransformerEncoder(**(model_args or {}))
+        if model_ckpt_path is not None:
+            self.model.load_state_dict(torch.load(model_ckpt_path, map_location="cpu"))
+        self.model.eval()
+        self.model.requires_grad_(False)
+
+    @classmethod
+    def model_objective(cls, x, y=None, **kwargs):
+        return torch.mean(x, dim=[2, 3, 4], keepdim=False).unsqueeze(-1)
+
+    def alignment_fn(self, zt, t, y=None, zc=None, **kwargs):
+        pred = self.model(zt, t, zc=zc, y=y, **kwargs).mean(dim=1)           # b t 1 -> b 1
+        return torch.linalg.vector_norm(pred - kwargs.get("avg_x_gt"), ord=2)
+
+    def get_mean_shift(self, zt, t, y=None, zc=None, **kwargs):
+        return self.guide_scale * get_sample_align_fn(self.alignment_fn)(zt, t, y=y, zc=zc, **kwargs)
+
+
+def get_alignment_kwargs_avg_x(context_seq=None, target_seq=None):
+    """scripts/prediff/sevirlr/train_sevirlr_prediff.py:48-67: avg_x_gt = 2 * mean(target) per sample."""
+    B = target_seq.shape[0]
+    return {"avg_x_gt": 2.0 * target_seq.reshape(B, -1).mean(dim=1, keepdim=True)}

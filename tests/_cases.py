@@ -103,3 +103,20 @@ V1_UNET_CFG = dict(input_shape=[7, 16, 16, 64], target_shape=[6, 16, 16, 64], ba
 V1_VAE_CFG = dict(in_channels=1, out_channels=1, down_block_types=["DownEncoderBlock2D"] * 4,
                   up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=[128, 256, 512, 512],
                   layers_per_block=2, act_fn="silu", latent_channels=64, norm_num_groups=32)
+
+
+def _align(**over):
+    cfg = dict(input_shape=[2, 8, 8, 4], out_channels=1, base_units=32, scale_alpha=1.0, depth=[1, 1], downsample=2,
+               downsample_type="patch_merge", block_attn_patterns="axial", num_heads=2, attn_drop=0.0, proj_drop=0.0,
+               ffn_drop=0.0, ffn_activation="gelu", gated_ffn=False, norm_layer="layer_norm", use_inter_ffn=True,
+               hierarchical_pos_embed=False, pos_embed_type="t+h+w", padding_type="zeros", checkpoint_level=0,
+               use_relative_pos=True, self_attn_use_final_proj=True, num_global_vectors=0, time_embed_channels_mult=4,
+               time_embed_use_scale_shift_norm=False, time_embed_dropout=0.0, pool="attention", readout_seq=True, out_len=2)
+    cfg.update(over)
+    return cfg
+
+
+TINY_ALIGN_ARGS = _align()
+# prediff_sevirlr_v1.yaml:104-155 (model.align.model_args)
+V1_ALIGN_ARGS = _align(input_shape=[6, 16, 16, 64], base_units=128, num_heads=4, attn_drop=0.1, proj_drop=0.1, ffn_drop=0.1,
+                       out_len=6)

@@ -281,8 +281,51 @@ def gen_diffusion():
     save("sample3", decoded=dec, latent=lat_out, tape=torch.stack(tape), zc=ldm.cond_stage_forward({"y": y}))
 
 
+def gen_alignment():
+    """SEVIRAvgIntensityAlignment: U_phi forward, guidance gradient, aligned p_sample and aligned sample()."""
+    from _cases import TINY_ALIGN_ARGS, V1_ALIGN_ARGS
+    al = R.SEVIRAvgIntensityAlignment(alignment_type="avg_x", guide_scale=50.0, model_type="cuboid", model_args=dict(TINY_ALIGN_ARGS))
+    reseed(al.model, 700)
+    with open(os.path.join(HERE, "tiny_align_schema.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in al.model.state_dict().items()}, f)
+    B = 2
+    lat = (B,) + tuple(TINY_ALIGN_ARGS["input_shape"])
+    zt = seeded_input("azt", lat, 9)
+    t = torch.tensor([999, 3])
+    avg = torch.tensor([[0.31], [0.07]])
+    arrs = {"u": al.model(zt, t), "shift": al.get_mean_shift(zt, t, y=None, zc=None, avg_x_gt=avg), "avg_x_gt": avg}
+    ldm, cfg = build_tiny_ldm()
+    ldm.set_alignment(al.get_mean_shift)
+    zc = seeded_input("dzc", (B,) + tuple(cfg["input_shape"]), 5)
+    noise = seeded_input("an", lat, 10)
+    for tt in (500, 0):
+        tv = torch.full((B,), tt, dtype=torch.long)
+        torch.manual_seed(5)
+        arrs[f"psample_aligned_{tt}"] = ldm.p_sample(zt=zt, zc=zc, t=tv, y=None, use_alignment=True, alignment_kwargs={"avg_x_gt": avg})
+        torch.manual_seed(5)
+        arrs[f"psample_noise_{tt}"] = torch.randn(lat)
+    y = seeded_input("dy", (B, cfg["input_shape"][0], 32, 32, 1), 8, kind="uniform")
+    torch.manual_seed(321)
+    arrs["sample_aligned_latent"] = ldm.sample(cond={"y": y}, batch_size=B, timesteps=3, use_alignment=True,
+                                               alignment_kwargs={"avg_x_gt": avg}, return_decoded=False)
+    torch.manual_seed(321)
+    arrs["tape"] = torch.stack([torch.randn(lat) for _ in range(4)])
+    save("alignment", **arrs)
+    # v1-size alignment network: schema + forward (8.94 M params)
+    net = R.SEVIRAvgIntensityAlignment(model_args=dict(V1_ALIGN_ARGS)).model
+    with open(os.path.join(HERE, "v1_align_schema.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in net.state_dict().items()}, f)
+    reseed(net, 701)
+    z = seeded_input("v1az", (2, 6, 16, 16, 64), 11)
+    save("v1_alignment", u=net(z, torch.tensor([400, 20])))
+
+
 def main():
-    which = sys.argv[1:] or ["index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion"]
+    which = sys.argv[1:] or ["index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion", "alignment"]
+    if "alignment" in which:
+        torch.set_grad_enabled(True)
+        gen_alignment()
+        torch.set_grad_enabled(False)
     if "index" in which:
         gen_reorder_and_masks()
     if "attn" in which:

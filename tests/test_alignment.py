@@ -1,0 +1,104 @@
+"""Knowledge alignment (PyTorch autograd by design): parity of prediff_amd.alignment with the reference on CPU, and of the
+aligned sampling step on the GPU engine."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _templates as TP
+from _cases import TINY_ALIGN_ARGS, TINY_UNET_CFGS, V1_ALIGN_ARGS
+from _weights import seeded_input, seeded_state_dict
+from prediff_amd.alignment import NoisyCuboidTransformerEncoder, SEVIRAvgIntensityAlignment, get_alignment_kwargs_avg_x
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _tiny_alignment():
+    al = SEVIRAvgIntensityAlignment(alignment_type="avg_x", guide_scale=50.0, model_type="cuboid", model_args=dict(TINY_ALIGN_ARGS))
+    ref = json.load(open(os.path.join(GOLDEN, "tiny_align_schema.json")))
+    sd = al.model.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert list(v.shape) == ref[k], k
+    al.model.load_state_dict(seeded_state_dict(sd, 700), strict=True)
+    return al
+
+
+def test_alignment_network_and_gradient_cpu(golden):
+    g = golden("alignment")
+    al = _tiny_alignment()
+    B = 2
+    zt = seeded_input("azt", (B,) + tuple(TINY_ALIGN_ARGS["input_shape"]), 9)
+    t = torch.tensor([999, 3])
+    avg = torch.as_tensor(g["avg_x_gt"])
+    with torch.no_grad():
+        u = al.model(zt, t, zc="ignored", y="ignored")          # extra kwargs are swallowed
+    assert rel_l2(u, g["u"]) < 1e-5
+    with torch.no_grad():                                        # the hook is called under no_grad and re-enables grad itself
+        shift = al.get_mean_shift(zt, t, y=None, zc=None, avg_x_gt=avg)
+    assert rel_l2(shift, g["shift"]) < 1e-4
+    # the L2 norm couples the batch (sevir.py:81-82): a sample's guidance changes when its batch-mates change
+    alone = al.get_mean_shift(zt[:1], t[:1], avg_x_gt=avg[:1])
+    assert rel_l2(alone, shift[:1]) > 1e-3
+
+
+def test_v1_alignment_network_cpu(golden):
+    net = NoisyCuboidTransformerEncoder(**V1_ALIGN_ARGS)
+    ref = json.load(open(os.path.join(GOLDEN, "v1_align_schema.json")))
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref.keys()) and all(list(v.shape) == ref[k] for k, v in sd.items())
+    assert abs(sum(p.numel() for p in net.parameters()) / 8.94e6 - 1) < 1e-2
+    net.load_state_dict(seeded_state_dict(sd, 701))
+    z = seeded_input("v1az", (2, 6, 16, 16, 64), 11)
+    with torch.no_grad():
+        assert rel_l2(net(z, torch.tensor([400, 20])), golden("v1_alignment")["u"]) < 1e-5
+
+
+def test_alignment_kwargs():
+    tgt = torch.rand(3, 6, 8, 8, 1)
+    kw = get_alignment_kwargs_avg_x(target_seq=tgt)
+    assert kw["avg_x_gt"].shape == (3, 1) and torch.allclose(kw["avg_x_gt"][:, 0], 2 * tgt.reshape(3, -1).mean(1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32"])
+def test_aligned_sampling_on_gpu(golden, precision):
+    """p_sample / sample with use_alignment=True: HIP denoiser + PyTorch-autograd guidance + fused aligned-mean epilogue,
+    against the reference's aligned outputs."""
+    from prediff_amd.autoencoder_kl import AutoencoderKL
+    from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
+    from prediff_amd.latent_diffusion import LatentDiffusion
+    from _cases import TINY_VAE_CFG
+    g = golden("alignment")
+    cfg = TINY_UNET_CFGS["axial"]
+    net = CuboidTransformerUNet(**cfg, precision=precision)
+    net.load_state_dict(seeded_state_dict(TP.unet_template(cfg, "tiny_unet_schema.json", "axial"), 600))
+    vae = AutoencoderKL(**TINY_VAE_CFG, precision=precision)
+    vae.load_state_dict(seeded_state_dict(TP.from_schema("tiny_vae_schema.json"), 601))
+    ldm = LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(2, 32, 32, 1), timesteps=1000, use_ema=False,
+                          latent_shape=tuple(cfg["target_shape"]), first_stage_model=vae, cond_stage_model="__is_first_stage__").cuda()
+    al = _tiny_alignment()
+    al.model.cuda()
+    ldm.set_alignment(al.get_mean_shift)
+    B = 2
+    zt = seeded_input("azt", (B,) + tuple(cfg["target_shape"]), 9).cuda()
+    zc = seeded_input("dzc", (B,) + tuple(cfg["input_shape"]), 5).cuda()
+    avg = torch.as_tensor(g["avg_x_gt"]).cuda()
+    for tt in (500, 0):
+        t = torch.full((B,), tt, dtype=torch.long, device="cuda")
+        out = ldm.p_sample(zt=zt, zc=zc, t=t, y=None, use_alignment=True, alignment_kwargs={"avg_x_gt": avg},
+                           noise=torch.as_tensor(g[f"psample_noise_{tt}"]).cuda())
+        assert rel_l2(out, g[f"psample_aligned_{tt}"]) < 1e-4, tt
+    y = seeded_input("dy", (B, cfg["input_shape"][0], 32, 32, 1), 8, kind="uniform").cuda()
+    lat = ldm.sample(cond={"y": y}, batch_size=B, timesteps=3, use_alignment=True, alignment_kwargs={"avg_x_gt": avg},
+                     return_decoded=False, noise_tape=torch.as_tensor(g["tape"]))
+    e = rel_l2(lat, g["sample_aligned_latent"])
+    print(f"[aligned sample3] latent rel-L2 vs reference {e:.3e}")
+    assert e < 1e-3
