@@ -65,6 +65,9 @@ typedef struct pd_igemm_args {
   float alpha;
   int32_t tile;            /* 0 = auto, 1 = 128x128, 2 = 64x64 */
   int32_t vec_epilogue;    /* set by the library */
+  uint32_t a_bytes, w_bytes; /* set by the library: extent of one A / W batch (buffer-descriptor bounds) */
+  int32_t debug_flags;     /* profiling ablations only: 1 skip main loop, 2 skip stores, 4 skip activation (0 in production) */
+  int32_t reserved0;
 } pd_igemm_args;
 int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
 

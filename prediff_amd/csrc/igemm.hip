@@ -17,24 +17,42 @@
 //     XCD's L2 across the N tiles and across the overlapping filter taps).
 //   * SPLIT: x = hi + lo bf16 decomposition of both operands, 3 MFMAs per fragment pair (drops lo*lo): fp32-class
 //     accuracy (~2^-16 relative per product) at 1/3 of the bf16 MFMA rate instead of 1/16 for the f32 MFMA.
+#include <type_traits>
 #include "common.h"
 
 __device__ __attribute__((aligned(64))) uint32_t g_pd_zero_page[32];   // 128 B of zeros (never written)
 
-#define GLDS16(gptr, ldsptr)                                                                   \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
-                                   (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+#ifndef PD_BIG_TILE_DEFAULT
+#define PD_BIG_TILE_DEFAULT 1
+#endif
 
-// KIND only tags the instantiation (0 linear, 1 conv2d, 2 conv3d) so that profilers report the three uses separately.
-template <int BM, int BN, bool SPLIT, int KIND>
+// 16 B/lane DMA HBM/L2 -> LDS through a buffer descriptor: per-lane byte offset in a VGPR, wave-uniform byte offset in an
+// SGPR, hardware bounds check (offset >= num_records reads as zero: out-of-image taps and M/N tails cost no address math).
+#define BLDS16(rsrc, ldsptr, voff, soff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
+#define PD_OOB 0xffffff00u
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// KIND: 0 linear (no spatial decode), 1 conv2d, 2 conv3d -- also tags the instantiation so profilers report the uses separately.
+// BK in {32, 64}; NS = LDS ring depth (NS-1 K-steps of operand traffic in flight while one is being consumed).
+template <int BM, int BN, int BK, int NS, bool SPLIT, int KIND>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
-  constexpr int BK = 64;
-  constexpr int A_TILE = BM * BK * 2;   // bytes
-  constexpr int B_TILE = BN * BK * 2;
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
+  constexpr int ROWB = BK * 2;                    // bytes per tile row
+  constexpr int CPR = ROWB / 16;                  // 16 B chunks per row (4 or 8)
+  constexpr int RPI = 256 / CPR;                  // tile rows covered by one 256-thread DMA instruction (64 or 32)
+  constexpr int A_TILE = BM * ROWB;
+  constexpr int B_TILE = BN * ROWB;
   constexpr int NP = SPLIT ? 2 : 1;
   constexpr int STAGE = (A_TILE + B_TILE) * NP;
-  constexpr int AI = BM / 32, BI = BN / 32;       // 16 B DMA instructions per thread per tile
+  constexpr int AI = BM / RPI, BI = BN / RPI;     // DMA instructions per thread per tile
+  constexpr int LPS = (AI + BI) * NP;             // DMA instructions per thread per stage
   constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave
+  constexpr int KSUB = BK / 16;                   // MFMA k-substeps per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -54,75 +72,79 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
   const int n0 = (t % tiles_n) * BN;
   const int bz = blockIdx.z;
 
-  const pd_bf16* __restrict__ Ag = p.A + (int64_t)bz * p.a_batch_stride;
-  const pd_bf16* __restrict__ Wg = p.W + (int64_t)bz * p.w_batch_stride;
-  const pd_bf16* __restrict__ Alo = SPLIT ? p.A_lo + (int64_t)bz * p.a_batch_stride : nullptr;
-  const pd_bf16* __restrict__ Wlo = SPLIT ? p.W_lo + (int64_t)bz * p.w_batch_stride : nullptr;
-  const pd_bf16* zero = (const pd_bf16*)g_pd_zero_page;
+  // buffer descriptors (wave-uniform: kernel arguments + blockIdx only)
+  const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)bz * p.a_batch_stride), 0, p.a_bytes, 0x00020000);
+  const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)bz * p.w_batch_stride), 0, p.w_bytes, 0x00020000);
+  const auto rAlo = __builtin_amdgcn_make_buffer_rsrc((void*)((SPLIT ? p.A_lo : p.A) + (int64_t)bz * p.a_batch_stride), 0, p.a_bytes, 0x00020000);
+  const auto rWlo = __builtin_amdgcn_make_buffer_rsrc((void*)((SPLIT ? p.W_lo : p.W) + (int64_t)bz * p.w_batch_stride), 0, p.w_bytes, 0x00020000);
 
   // ---- staging descriptors (fixed per thread) ----
-  const int srow = tid >> 3;                      // row inside a 32-row slab
-  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);   // logical 16 B k-chunk fetched by this lane (source-side swizzle)
-  const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
+  // lane -> (row inside the RPI-row slab, 16 B position); the k-chunk it FETCHES is position ^ swizzle(row) so that the
+  // lane-linear DMA image is the bank-conflict-free one the ds_read_b128 below expects.
+  const int srow = tid / CPR;
+  const int spos = tid % CPR;
+  const int schunk = (CPR == 8) ? (spos ^ ((srow >> 1) & 7)) : (spos ^ ((srow >> 2) & 3));
   int vt0[AI], vh0[AI], vw0[AI];
   uint32_t abase[AI];
-  bool mok[AI];
+  uint32_t aoff[AI];   // BYTE offset of (row, current tap, chunk) or PD_OOB
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int m = m0 + i * 32 + srow;
-    mok[i] = m < p.M;
-    const int mm = mok[i] ? m : 0;
-    const int b = mm / thw_o, r1 = mm - b * thw_o;
-    const int ot = r1 / hw_o, r2 = r1 - ot * hw_o;
-    const int oh = r2 / p.Wo, ow = r2 - oh * p.Wo;
-    vt0[i] = ot * p.st - p.pt;
-    vh0[i] = oh * p.sh - p.ph;
-    vw0[i] = ow * p.sw - p.pw;
-    abase[i] = (uint32_t)b * (uint32_t)(p.Ti * p.Hi * p.Wi);
+    const int m = m0 + i * RPI + srow;
+    if (KIND == 0) {
+      aoff[i] = m < p.M ? ((uint32_t)m * (uint32_t)p.lda + schunk * 8) * 2u : PD_OOB;
+    } else {
+      const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
+      const bool ok = m < p.M;
+      const int mm = ok ? m : 0;
+      const int b = mm / thw_o, r1 = mm - b * thw_o;
+      const int ot = r1 / hw_o, r2 = r1 - ot * hw_o;
+      const int oh = r2 / p.Wo, ow = r2 - oh * p.Wo;
+      vt0[i] = ok ? ot * p.st - p.pt : -(1 << 20);      // invalid rows fail every bounds check
+      vh0[i] = oh * p.sh - p.ph;
+      vw0[i] = ow * p.sw - p.pw;
+      abase[i] = (uint32_t)b * (uint32_t)(p.Ti * p.Hi * p.Wi);
+    }
   }
   uint32_t woff[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int n = n0 + i * 32 + srow;
-    woff[i] = n < p.N ? (uint32_t)n * (uint32_t)p.ldw + schunk * 8 : 0xffffffffu;
+    const int n = n0 + i * RPI + srow;
+    woff[i] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldw + schunk * 8) * 2u : PD_OOB;
   }
-  const int kchunks = p.Cin >> 6;
-  const int nk = p.taps * kchunks;
+  const int kchunks = p.Cin / BK;
+  const int nk = (p.debug_flags & 1) ? 0 : p.taps * kchunks;
   const int vT = p.vT > 0 ? p.vT : p.Ti * p.ut, vH = p.vH > 0 ? p.vH : p.Hi * p.uh, vW = p.vW > 0 ? p.vW : p.Wi * p.uw;
   const int khw = p.KH * p.KW;
 
-  uint32_t aoff[AI];   // element offset of (row, this tap, chunk) or 0xffffffff
   auto set_tap = [&](int tap) {
     const int kt = tap / khw, r = tap - kt * khw;
     const int kh = r / p.KW, kw = r - kh * p.KW;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int vt = vt0[i] + kt, vh = vh0[i] + kh, vw = vw0[i] + kw;
-      const bool ok = mok[i] && (unsigned)vt < (unsigned)vT && (unsigned)vh < (unsigned)vH && (unsigned)vw < (unsigned)vW;
+      const bool ok = (unsigned)vt < (unsigned)vT && (unsigned)vh < (unsigned)vH && (unsigned)vw < (unsigned)vW;
       const int it = p.ut == 2 ? vt >> 1 : vt, ih = p.uh == 2 ? vh >> 1 : vh, iw = p.uw == 2 ? vw >> 1 : vw;
-      aoff[i] = ok ? (abase[i] + (uint32_t)((it * p.Hi + ih) * p.Wi + iw)) * (uint32_t)p.lda + schunk * 8 : 0xffffffffu;
+      aoff[i] = ok ? ((abase[i] + (uint32_t)((it * p.Hi + ih) * p.Wi + iw)) * (uint32_t)p.lda + schunk * 8) * 2u : PD_OOB;
     }
   };
 
   auto issue = [&](int stage, int ks) {
     const int tap = ks / kchunks, kc = ks - tap * kchunks;
-    if (kc == 0) set_tap(tap);
+    if (KIND != 0 && kc == 0) set_tap(tap);
     char* sbase = smem + stage * STAGE;
-    const uint32_t kofs = kc * 64;
-    const int64_t wtap = (int64_t)tap * p.w_tap_stride + kofs;
+    const int ka = kc * (BK * 2);                                             // wave-uniform byte offsets
+    const int kw = (int)(((int64_t)tap * p.w_tap_stride + kc * BK) * 2);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const bool ok = aoff[i] != 0xffffffffu;
       char* dst = sbase + (i * 256 + wave * 64) * 16;
-      GLDS16(ok ? Ag + aoff[i] + kofs : zero, dst);
-      if (SPLIT) GLDS16(ok ? Alo + aoff[i] + kofs : zero, dst + A_TILE);
+      BLDS16(rA, dst, aoff[i], ka);
+      if (SPLIT) BLDS16(rAlo, dst + A_TILE, aoff[i], ka);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const bool ok = woff[i] != 0xffffffffu;
       char* dst = sbase + A_TILE * NP + (i * 256 + wave * 64) * 16;
-      GLDS16(ok ? Wg + wtap + woff[i] : zero, dst);
-      if (SPLIT) GLDS16(ok ? Wlo + wtap + woff[i] : zero, dst + B_TILE);
+      BLDS16(rW, dst, woff[i], kw);
+      if (SPLIT) BLDS16(rWlo, dst + B_TILE, woff[i], kw);
     }
   };
 
@@ -137,29 +159,39 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
 
   const int wr = wave >> 1, wc = wave & 1;
   const int lrow = lane & 31, lhalf = lane >> 5;
-  const int swz = (lrow >> 1) & 7;
-  const int a_row_b = (wr * (BM / 2) + lrow) * 128;   // byte offset of this lane's row in the A tile
-  const int b_row_b = (wc * (BN / 2) + lrow) * 128;
+  const int swz = (CPR == 8) ? ((lrow >> 1) & 7) : ((lrow >> 2) & 3);
+  const int a_row_b = (wr * (BM / 2) + lrow) * ROWB;   // byte offset of this lane's row in the A tile
+  const int b_row_b = (wc * (BN / 2) + lrow) * ROWB;
 
-  issue(0, 0);
+  // ---- software pipeline: stages ks+1 .. ks+NS-1 are in flight while stage ks is consumed ----
+  constexpr int D = NS - 1;
+#pragma unroll
+  for (int s0 = 0; s0 < D; ++s0)
+    if (s0 < nk) issue(s0, s0);
+  int stage = 0;
   for (int ks = 0; ks < nk; ++ks) {
-    __syncthreads();   // stage ks&1 has landed (vmcnt(0) precedes the barrier); stage (ks+1)&1 is free again
-    if (ks + 1 < nk) issue((ks + 1) & 1, ks + 1);
-    const char* sA = smem + (ks & 1) * STAGE;
+    // this wave's share of stage ks has landed once at most min(D-1, nk-ks-1) younger stages remain outstanding
+    const int younger = min(D - 1, nk - ks - 1);
+    if (D >= 3 && younger == 2) wait_vmcnt<2 * LPS>();
+    else if (D >= 2 && younger == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone finished reading the stage refilled below
+    if (ks + D < nk) issue((stage + D) % NS, ks + D);
+    const char* sA = smem + stage * STAGE;
     const char* sB = sA + A_TILE * NP;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KSUB; ++kk) {
       const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
       bf16x8 a[TM], b[TN], al[TM], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        a[i] = *(const bf16x8*)(sA + a_row_b + i * 32 * 128 + pos);
-        if (SPLIT) al[i] = *(const bf16x8*)(sA + A_TILE + a_row_b + i * 32 * 128 + pos);
+        a[i] = *(const bf16x8*)(sA + a_row_b + i * 32 * ROWB + pos);
+        if (SPLIT) al[i] = *(const bf16x8*)(sA + A_TILE + a_row_b + i * 32 * ROWB + pos);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        b[j] = *(const bf16x8*)(sB + b_row_b + j * 32 * 128 + pos);
-        if (SPLIT) bl[j] = *(const bf16x8*)(sB + B_TILE + b_row_b + j * 32 * 128 + pos);
+        b[j] = *(const bf16x8*)(sB + b_row_b + j * 32 * ROWB + pos);
+        if (SPLIT) bl[j] = *(const bf16x8*)(sB + B_TILE + b_row_b + j * 32 * ROWB + pos);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -172,6 +204,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+    stage = stage + 1 == NS ? 0 : stage + 1;
   }
 
   // ---- epilogue: accumulators -> per-wave LDS slab (row major) -> coalesced 16 B row segments ----
@@ -191,70 +224,110 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
   pd_bf16* outb = p.out_bf16 ? p.out_bf16 + (int64_t)bz * p.outb_batch_stride : nullptr;
   pd_bf16* outbl = p.out_bf16_lo ? p.out_bf16_lo + (int64_t)bz * p.outb_batch_stride : nullptr;
   const float* res = p.residual ? p.residual + (int64_t)bz * p.res_batch_stride : nullptr;
-  constexpr int LPR = WN / 4;                      // lanes per row
-  constexpr int RPP = 64 / LPR;                    // rows per pass
-  const int c4 = (lane % LPR) * 4;
-  const int n = n0 + wc * WN + c4;
-  const bool vec = p.vec_epilogue && (n + 3 < p.N);
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) {
+  // CW columns per lane: 8 when only bf16 is stored (16 B stores: the 8 B/lane form is store-issue bound), else 4.
+  auto run_epilogue = [&](auto cw_tag) {
+    constexpr int CW = decltype(cw_tag)::value;
+    constexpr int LPR = WN / CW;                     // lanes per row
+    constexpr int RPP = 64 / LPR;                    // rows per pass
+    const int c0 = (lane % LPR) * CW;
+    const int n = n0 + wc * WN + c0;
+    const bool vec = p.vec_epilogue && (n + CW - 1 < p.N);
+    float bias_v[CW];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) if (n + e < p.N) bias4[e] = p.bias[n + e];
-  }
+    for (int e = 0; e < CW; ++e) bias_v[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
 #pragma unroll 1
-  for (int pass = 0; pass < WM / RPP; ++pass) {
-    const int row = pass * RPP + lane / LPR;
-    const int m = m0 + wr * WM + row;
-    if (m >= p.M || n >= p.N) continue;
-    const float4 a4 = *(const float4*)(sC + row * WN + c4);
-    float v[4] = {a4.x, a4.y, a4.z, a4.w};
-    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_sample) * p.ld_rowvec + n : nullptr;
-    const float* mu = p.mul ? p.mul + (int64_t)m * p.ld_mul + n : nullptr;
-    const float* rs = res ? res + (int64_t)(p.res_period ? m % p.res_period : m) * p.ld_res + n : nullptr;
-    if (vec) {
-      float4 t;
+    for (int pass = 0; pass < WM / RPP; ++pass) {
+      const int row = pass * RPP + lane / LPR;
+      const int m = m0 + wr * WM + row;
+      if (m >= p.M || n >= p.N || (p.debug_flags & 2)) continue;
+      float v[CW];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + bias4[e];
-      if (rv) { t = *(const float4*)rv; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
-      if (mu) { t = *(const float4*)mu; v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w; }
-      if (rs) { t = *(const float4*)rs; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-      if (outf) *(float4*)(outf + (int64_t)m * p.ld_out + n) = make_float4(v[0], v[1], v[2], v[3]);
-      if (outb) {
-        uint16_t hi[4], lo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f2bf_split(v[e], hi[e], lo[e]);
-        *(uint2*)(outb + (int64_t)m * p.ld_outb + n) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
-        if (outbl)
-          *(uint2*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+      for (int q = 0; q < CW / 4; ++q) {
+        const float4 a4 = *(const float4*)(sC + row * WN + c0 + 4 * q);
+        v[4 * q] = a4.x; v[4 * q + 1] = a4.y; v[4 * q + 2] = a4.z; v[4 * q + 3] = a4.w;
       }
-    } else {
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.N) break;
-        float x = v[e] * p.alpha + bias4[e];
-        if (rv) x += rv[e];
-        x = act_apply(x, p.act);
-        if (mu) x *= mu[e];
-        if (rs) x += rs[e];
-        if (outf) outf[(int64_t)m * p.ld_out + n + e] = x;
+      const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_sample) * p.ld_rowvec + n : nullptr;
+      const float* mu = p.mul ? p.mul + (int64_t)m * p.ld_mul + n : nullptr;
+      const float* rs = res ? res + (int64_t)(p.res_period ? m % p.res_period : m) * p.ld_res + n : nullptr;
+      const int act = (p.debug_flags & 4) ? 0 : p.act;
+      if (vec) {
+#pragma unroll
+        for (int e = 0; e < CW; ++e) v[e] = v[e] * p.alpha + bias_v[e];
+        if (rv) {
+#pragma unroll
+          for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(rv + 4 * q); v[4 * q] += t4.x; v[4 * q + 1] += t4.y; v[4 * q + 2] += t4.z; v[4 * q + 3] += t4.w; }
+        }
+#pragma unroll
+        for (int e = 0; e < CW; ++e) v[e] = act_apply(v[e], act);
+        if (mu) {
+#pragma unroll
+          for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(mu + 4 * q); v[4 * q] *= t4.x; v[4 * q + 1] *= t4.y; v[4 * q + 2] *= t4.z; v[4 * q + 3] *= t4.w; }
+        }
+        if (rs) {
+#pragma unroll
+          for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(rs + 4 * q); v[4 * q] += t4.x; v[4 * q + 1] += t4.y; v[4 * q + 2] += t4.z; v[4 * q + 3] += t4.w; }
+        }
+        if (outf) {
+#pragma unroll
+          for (int q = 0; q < CW / 4; ++q)
+            *(float4*)(outf + (int64_t)m * p.ld_out + n + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
         if (outb) {
-          uint16_t hi, lo;
-          f2bf_split(x, hi, lo);
-          outb[(int64_t)m * p.ld_outb + n + e] = hi;
-          if (outbl) outbl[(int64_t)m * p.ld_outb + n + e] = lo;
+          uint32_t hi[CW / 2], lo[CW / 2];
+#pragma unroll
+          for (int e = 0; e < CW / 2; ++e) {
+            if (outbl) {
+              uint16_t h0, l0, h1, l1;
+              f2bf_split(v[2 * e], h0, l0);
+              f2bf_split(v[2 * e + 1], h1, l1);
+              hi[e] = h0 | ((uint32_t)h1 << 16);
+              lo[e] = l0 | ((uint32_t)l1 << 16);
+            } else {
+              hi[e] = f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+            }
+          }
+          if (CW == 8) {
+            *(uint4*)(outb + (int64_t)m * p.ld_outb + n) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            if (outbl) *(uint4*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+          } else {
+            *(uint2*)(outb + (int64_t)m * p.ld_outb + n) = make_uint2(hi[0], hi[1]);
+            if (outbl) *(uint2*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint2(lo[0], lo[1]);
+          }
+        }
+      } else {
+        for (int e = 0; e < CW; ++e) {
+          if (n + e >= p.N) break;
+          float x = v[e] * p.alpha + bias_v[e];
+          if (rv) x += rv[e];
+          x = act_apply(x, act);
+          if (mu) x *= mu[e];
+          if (rs) x += rs[e];
+          if (outf) outf[(int64_t)m * p.ld_out + n + e] = x;
+          if (outb) {
+            uint16_t h, l;
+            f2bf_split(x, h, l);
+            outb[(int64_t)m * p.ld_outb + n + e] = h;
+            if (outbl) outbl[(int64_t)m * p.ld_outb + n + e] = l;
+          }
         }
       }
     }
-  }
+  };
+  if (p.vec_epilogue == 2)
+    run_epilogue(std::integral_constant<int, 8>{});
+  else
+    run_epilogue(std::integral_constant<int, 4>{});
+#endif
 }
 
-template <int BM, int BN, bool SPLIT, int KIND>
+template <int BM, int BN, int BK, int NS, bool SPLIT, int KIND>
 static int launch_igemm(const pd_igemm_args& a, hipStream_t s) {
-  constexpr int lds = 2 * (BM + BN) * 64 * 2 * (SPLIT ? 2 : 1);
+  constexpr int stage = (BM + BN) * BK * 2 * (SPLIT ? 2 : 1);
+  constexpr int epi = 4 * (BM / 2) * (BN / 2) * 4;
+  constexpr int lds = NS * stage > epi ? NS * stage : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, SPLIT, KIND>,
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, NS, SPLIT, KIND>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
@@ -264,10 +337,25 @@ static int launch_igemm(const pd_igemm_args& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, 1, a.nbatch > 0 ? a.nbatch : 1);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, SPLIT, KIND>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, NS, SPLIT, KIND>), grid, dim3(256), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
+
+// Tile / pipeline configurations (a.tile): 1 = 128x128, BK 64, 2-stage (2 workgroups/CU);  2 = 64x64, BK 64, 2-stage;
+// 3 = 128x128, BK 32, 4-stage ring (2 workgroups/CU, 3 K-steps in flight);  4 = 128x128, BK 64, 3-stage (1 workgroup/CU).
+template <bool SPLIT, int KIND>
+static int dispatch_igemm(const pd_igemm_args& a, int tile, hipStream_t s) {
+  switch (tile) {
+    case 1: return launch_igemm<128, 128, 64, 2, SPLIT, KIND>(a, s);
+    case 2: return launch_igemm<64, 64, 64, 2, SPLIT, KIND>(a, s);
+    case 3: return launch_igemm<128, 128, 32, 4, SPLIT, KIND>(a, s);
+    case 4: return launch_igemm<128, 128, 64, 3, SPLIT, KIND>(a, s);
+    default: pd_set_error("pd_igemm: unknown tile config %d", tile); return PD_ERR_ARG;
+  }
+}
+
+extern "C" int pd_igemm_default_tile = 0;   // bench / tuning override of the auto choice (0 = built-in heuristic)
 
 extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(pa != nullptr, "pd_igemm: null args");
@@ -279,8 +367,13 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(a.taps == a.KT * a.KH * a.KW, "pd_igemm: taps != KT*KH*KW");
   PD_CHECK_ARG((int64_t)a.B * a.To * a.Ho * a.Wo == a.M, "pd_igemm: M != B*To*Ho*Wo");
   PD_CHECK_ARG((a.ut == 1 || a.ut == 2) && (a.uh == 1 || a.uh == 2) && (a.uw == 1 || a.uw == 2), "pd_igemm: bad upsample");
-  PD_CHECK_ARG((int64_t)a.B * a.Ti * a.Hi * a.Wi * (int64_t)a.lda < (1ll << 32) - 64, "pd_igemm: A too large for 32-bit offsets");
-  PD_CHECK_ARG((int64_t)a.N * a.ldw < (1ll << 32) - 64, "pd_igemm: W tap too large for 32-bit offsets");
+  {
+    const int64_t abytes = (int64_t)a.B * a.Ti * a.Hi * a.Wi * (int64_t)a.lda * 2;
+    const int64_t wbytes = ((int64_t)(a.taps - 1) * a.w_tap_stride + (int64_t)a.N * a.ldw) * 2;
+    PD_CHECK_ARG(abytes < 0xfffffe00ll && wbytes < 0xfffffe00ll, "pd_igemm: operand larger than a 4 GiB buffer descriptor");
+    a.a_bytes = (uint32_t)abytes;
+    a.w_bytes = (uint32_t)wbytes;
+  }
   PD_CHECK_ARG(!a.split || (a.A_lo && a.W_lo), "pd_igemm: split needs A_lo and W_lo");
   PD_CHECK_ARG(!a.rowvec || a.rows_per_sample > 0, "pd_igemm: rowvec needs rows_per_sample");
   PD_CHECK_ARG(a.out_f32 || a.out_bf16, "pd_igemm: no output");
@@ -290,17 +383,26 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
                    (!a.mul || (a.ld_mul & 3) == 0) && (((uintptr_t)a.out_f32 | (uintptr_t)a.residual | (uintptr_t)a.rowvec |
                    (uintptr_t)a.mul) & 15) == 0 && (((uintptr_t)a.out_bf16 | (uintptr_t)a.out_bf16_lo) & 7) == 0 &&
                    ((a.out_batch_stride | a.outb_batch_stride | a.res_batch_stride) & 3) == 0;
-  int tile = a.tile;
+  if (a.vec_epilogue && !a.out_f32 && a.out_bf16 && (a.N & 7) == 0 && (a.ld_outb & 7) == 0 && (a.outb_batch_stride & 7) == 0 &&
+      (((uintptr_t)a.out_bf16 | (uintptr_t)a.out_bf16_lo) & 15) == 0)
+    a.vec_epilogue = 2;   // 16 B bf16 stores
+  int tile = a.tile ? a.tile : pd_igemm_default_tile;
+  const int kind = a.taps == 1 ? 0 : (a.KT == 1 ? 1 : 2);
+  if (kind == 0) {
+    PD_CHECK_ARG(a.B == 1 && a.To == 1 && a.Ho == 1 && a.Wo == a.M && a.Ti == 1 && a.Hi == 1 && a.Wi == a.M,
+                 "pd_igemm: taps == 1 expects the identity geometry (B=To=Ho=1, Wo=Wi=M)");
+  }
   if (tile == 0) {
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.nbatch > 0 ? a.nbatch : 1);
-    tile = t128 >= 192 ? 1 : 2;
+    tile = t128 >= 192 ? (a.split ? 1 : PD_BIG_TILE_DEFAULT) : 2;
   }
-  const int kind = a.taps == 1 ? 0 : (a.KT == 1 ? 1 : 2);
-#define PD_DISPATCH(KIND)                                                                                         \
-  if (a.split) return tile == 1 ? launch_igemm<128, 128, true, KIND>(a, s) : launch_igemm<64, 64, true, KIND>(a, s); \
-  return tile == 1 ? launch_igemm<128, 128, false, KIND>(a, s) : launch_igemm<64, 64, false, KIND>(a, s);
-  if (kind == 0) { PD_DISPATCH(0) }
-  if (kind == 1) { PD_DISPATCH(1) }
-  PD_DISPATCH(2)
-#undef PD_DISPATCH
+  if (a.split && tile == 4) tile = 1;   // 3 x 64 KB stages do not fit
+  if (a.split) {
+    if (kind == 0) return dispatch_igemm<true, 0>(a, tile, s);
+    if (kind == 1) return dispatch_igemm<true, 1>(a, tile, s);
+    return dispatch_igemm<true, 2>(a, tile, s);
+  }
+  if (kind == 0) return dispatch_igemm<false, 0>(a, tile, s);
+  if (kind == 1) return dispatch_igemm<false, 1>(a, tile, s);
+  return dispatch_igemm<false, 2>(a, tile, s);
 }

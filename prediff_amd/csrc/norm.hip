@@ -229,6 +229,98 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   }
 }
 
+// ---- fast path: C % 4 == 0, (C/4) divides 256, channels-per-group % 4 == 0, ld_out == C.  A thread owns one float4
+// column (4 channels of ONE group) and walks rows; loads are 16 B/lane, stores 8 B/lane (bf16 x4). ----
+__global__ void __launch_bounds__(256) gn_stats_vec_kernel(const float* __restrict__ x, double* __restrict__ partials, int S, int C, int G) {
+  __shared__ float sred[256 * 2];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int CV = C >> 2, RP = 256 / CV;                 // float4 columns, rows per pass
+  const int tid = threadIdx.x, cv = tid % CV, rr = tid / CV;
+  const int r0 = chunk * GN_ROWS, r1 = min(S, r0 + GN_ROWS);
+  const float4* xb = (const float4*)(x + ((int64_t)b * S + r0) * C) + cv;
+  float s = 0.f, q = 0.f;
+#pragma unroll 4
+  for (int r = rr; r < r1 - r0; r += RP) {
+    const float4 v = xb[(int64_t)r * CV];
+    s += (v.x + v.y) + (v.z + v.w);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  sred[tid * 2] = s;
+  sred[tid * 2 + 1] = q;
+  __syncthreads();
+  if (tid < G) {
+    const int cvg = (C / G) >> 2;                       // float4 columns per group
+    double ss = 0, qq = 0;
+    for (int r = 0; r < RP; ++r)
+      for (int k = 0; k < cvg; ++k) {
+        const int t = r * CV + tid * cvg + k;
+        ss += sred[t * 2];
+        qq += sred[t * 2 + 1];
+      }
+    double* out = partials + ((int64_t)b * nchunk + chunk) * G * 2;
+    out[tid * 2] = ss;
+    out[tid * 2 + 1] = qq;
+  }
+}
+
+__global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ ss_scale,
+                                                           const float* __restrict__ ss_shift, int ld_ss,
+                                                           const double* __restrict__ partials, pd_bf16* __restrict__ out,
+                                                           pd_bf16* __restrict__ out_lo, int S, int C, int G, float eps, int silu,
+                                                           int nchunk) {
+  __shared__ float smr[2 * 256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cpg = C / G;
+  const int tid = threadIdx.x;
+  if (tid < G) {
+    double ss = 0, qq = 0;
+    const double* pp = partials + (int64_t)b * nchunk * G * 2 + tid * 2;
+    for (int k = 0; k < nchunk; ++k) { ss += pp[(int64_t)k * G * 2]; qq += pp[(int64_t)k * G * 2 + 1]; }
+    const double cnt = (double)S * cpg, mean = ss / cnt;
+    double var = qq / cnt - mean * mean;
+    if (var < 0) var = 0;
+    smr[tid * 2] = (float)mean;
+    smr[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int CV = C >> 2, RP = 256 / CV;
+  const int cv = tid % CV, rr = tid / CV, c = cv * 4, g = c / cpg;
+  const float mean = smr[g * 2], rstd = smr[g * 2 + 1];
+  float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+  // fold: y = x * a + d  with a = rstd*gamma, d = beta - mean*rstd*gamma  [then (1+scale)*y + shift]
+  float a[4] = {rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w};
+  float d[4] = {be.x - mean * a[0], be.y - mean * a[1], be.z - mean * a[2], be.w - mean * a[3]};
+  if (ss_scale) {
+    const float4 sc = *(const float4*)(ss_scale + (int64_t)b * ld_ss + c), sh = *(const float4*)(ss_shift + (int64_t)b * ld_ss + c);
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] *= (1.f + scv[k]); d[k] = d[k] * (1.f + scv[k]) + shv[k]; }
+  }
+  const int r0 = chunk * GN_ROWS, r1 = min(S, r0 + GN_ROWS);
+  const float4* xb = (const float4*)(x + ((int64_t)b * S + r0) * C) + cv;
+  uint2* ob = (uint2*)(out + ((int64_t)b * S + r0) * C) + cv;
+  uint2* obl = out_lo ? (uint2*)(out_lo + ((int64_t)b * S + r0) * C) + cv : nullptr;
+#pragma unroll 4
+  for (int r = rr; r < r1 - r0; r += RP) {
+    const float4 v = xb[(int64_t)r * CV];
+    float y[4] = {v.x * a[0] + d[0], v.y * a[1] + d[1], v.z * a[2] + d[2], v.w * a[3] + d[3]};
+    if (silu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.f + __expf(-y[k]));
+    }
+    if (obl) {
+      uint16_t hi[4], lo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) f2bf_split(y[k], hi[k], lo[k]);
+      ob[(int64_t)r * CV] = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+      obl[(int64_t)r * CV] = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+    } else {
+      ob[(int64_t)r * CV] = make_uint2(f2bf(y[0]) | ((uint32_t)f2bf(y[1]) << 16), f2bf(y[2]) | ((uint32_t)f2bf(y[3]) << 16));
+    }
+  }
+}
+
 extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, const float* ss_scale,
                                  const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo, int B, int S,
                                  int C, int G, int ld_out, float eps, int silu, pd_stream_t stream) {
@@ -238,6 +330,18 @@ extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float
   PD_CHECK_ARG(G <= 4096, "pd_groupnorm_silu: too many groups");
   const int nchunk = pd_groupnorm_nchunk(S, C);
   hipStream_t s = (hipStream_t)stream;
+  const int CV = C / 4, cpg = C / G;
+  const bool vec = (C % 4 == 0) && CV <= 256 && (256 % CV == 0) && (cpg % 4 == 0) && ld_out == C && G <= 256 &&
+                   (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && (((uintptr_t)out | (uintptr_t)out_lo) & 7) == 0 &&
+                   (!ss_scale || ((ld_ss % 4 == 0) && (((uintptr_t)ss_scale | (uintptr_t)ss_shift) & 15) == 0));
+  if (vec) {
+    hipLaunchKernelGGL(gn_stats_vec_kernel, dim3(nchunk, B), dim3(256), 0, s, x, partials, S, C, G);
+    PD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_vec_kernel, dim3(nchunk, B), dim3(256), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, partials, out,
+                       out_lo, S, C, G, eps, silu, nchunk);
+    PD_CHECK_LAUNCH();
+    return PD_OK;
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), (512 + 2 * G) * sizeof(double), s, x, partials, S, C, G);
   PD_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), 2 * G * sizeof(float), s, x, gamma, beta, ss_scale, ss_shift,

@@ -36,7 +36,9 @@ def padded_bf16(x2d, split=False):
 
 # ------------------------------------------------------------------------------------------------ igemm: linear
 @pytest.mark.parametrize("M,N,K,tile", [(256, 128, 64, 1), (256, 128, 64, 2), (3328, 768, 256, 0), (1000, 200, 96, 1),
-                                        (1000, 200, 96, 2), (37, 5, 32, 2), (832, 2048, 512, 0), (128, 64, 1024, 2)])
+                                        (1000, 200, 96, 2), (37, 5, 32, 2), (832, 2048, 512, 0), (128, 64, 1024, 2),
+                                        (3328, 768, 256, 3), (3328, 768, 256, 4), (1000, 200, 96, 3), (1000, 200, 96, 4), (300, 130, 64, 3),
+                                        (300, 130, 64, 4), (512, 256, 2048, 3), (512, 256, 2048, 4)])
 @pytest.mark.parametrize("split", [False, True])
 def test_igemm_linear(M, N, K, tile, split):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
@@ -96,7 +98,8 @@ def test_igemm_batched():
 # ------------------------------------------------------------------------------------------------ igemm: convolutions
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 5, 8, 8, 64, 64), (1, 13, 16, 16, 256, 256), (2, 3, 6, 6, 5, 32), (1, 13, 8, 8, 512, 512)])
 @pytest.mark.parametrize("split", [False, True])
-def test_igemm_conv3d(B, T, H, W, Cin, Cout, split):
+@pytest.mark.parametrize("tile", [0, 3, 4])
+def test_igemm_conv3d(B, T, H, W, Cin, Cout, split, tile):
     g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
     x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
     w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).to(DEV)
@@ -108,7 +111,7 @@ def test_igemm_conv3d(B, T, H, W, Cin, Cout, split):
     M = B * T * H * W
     out = torch.empty(M, Cout, device=DEV)
     L.igemm(a_hi, w_hi, A_lo=a_lo, W_lo=w_lo, M=M, N=Cout, Cin=Cp, taps=27, w_tap_stride=Cout * Cp,
-            geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias, rowvec=emb, rows_per_sample=T * H * W, out_f32=out)
+            geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias, rowvec=emb, rows_per_sample=T * H * W, out_f32=out, tile=tile)
     xs, ws = (x, w) if split else (bf(x), bf(w))
     ref = F.conv3d(xs.permute(0, 4, 1, 2, 3), ws, bias, padding=1) + emb[:, :, None, None, None]
     ref = ref.permute(0, 2, 3, 4, 1).reshape(M, Cout)
@@ -192,8 +195,9 @@ def test_groupnorm_silu(B, S, Cn, G, silu):
         assert float(out[:, Cn:].float().abs().max()) == 0
 
 
-def test_groupnorm_scale_shift():
-    B, S, Cn, G = 2, 128, 64, 32
+@pytest.mark.parametrize("Cn", [64, 128])          # 64: generic kernels, 128: vectorised fast path
+def test_groupnorm_scale_shift(Cn):
+    B, S, G = 2, 128, 32
     g = torch.Generator(device="cpu").manual_seed(3)
     x = torch.randn(B, S, Cn, generator=g).to(DEV)
     gamma, beta = torch.randn(Cn, generator=g).to(DEV), torch.randn(Cn, generator=g).to(DEV)
