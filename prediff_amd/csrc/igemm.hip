@@ -224,59 +224,68 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
   pd_bf16* outb = p.out_bf16 ? p.out_bf16 + (int64_t)bz * p.outb_batch_stride : nullptr;
   pd_bf16* outbl = p.out_bf16_lo ? p.out_bf16_lo + (int64_t)bz * p.outb_batch_stride : nullptr;
   const float* res = p.residual ? p.residual + (int64_t)bz * p.res_batch_stride : nullptr;
-  // CW columns per lane: 8 when only bf16 is stored (16 B stores: the 8 B/lane form is store-issue bound), else 4.
-  auto run_epilogue = [&](auto cw_tag) {
+  // The row loop is instantiated per (columns-per-lane, activation, operand presence) so that the hot call sites get
+  // straight-line code; tag value 2 = "decide at run time" (generic instantiation).
+  //   CW columns per lane: 8 when only bf16 is stored (16 B stores: the 8 B/lane form is store-issue bound), else 4.
+  auto run_epilogue = [&](auto cw_tag, auto act_tag, auto rv_tag, auto mu_tag, auto rs_tag, auto of_tag, auto ob_tag, auto ol_tag) {
     constexpr int CW = decltype(cw_tag)::value;
+    constexpr int ACT = decltype(act_tag)::value;          // -1 = run time
+    auto on = [](auto tag, bool rt) { constexpr int T = decltype(tag)::value; return T == 2 ? rt : (T == 1); };
     constexpr int LPR = WN / CW;                     // lanes per row
     constexpr int RPP = 64 / LPR;                    // rows per pass
     const int c0 = (lane % LPR) * CW;
     const int n = n0 + wc * WN + c0;
     const bool vec = p.vec_epilogue && (n + CW - 1 < p.N);
+    const bool has_rv = on(rv_tag, p.rowvec != nullptr), has_mu = on(mu_tag, p.mul != nullptr), has_rs = on(rs_tag, res != nullptr);
+    const bool has_of = on(of_tag, outf != nullptr), has_ob = on(ob_tag, outb != nullptr), has_ol = on(ol_tag, outbl != nullptr);
+    const int act = ACT >= 0 ? ACT : ((p.debug_flags & 4) ? 0 : p.act);
     float bias_v[CW];
 #pragma unroll
     for (int e = 0; e < CW; ++e) bias_v[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+    if (n >= p.N || (p.debug_flags & 2)) return;
 #pragma unroll 1
     for (int pass = 0; pass < WM / RPP; ++pass) {
       const int row = pass * RPP + lane / LPR;
       const int m = m0 + wr * WM + row;
-      if (m >= p.M || n >= p.N || (p.debug_flags & 2)) continue;
+      if (m >= p.M) continue;
       float v[CW];
 #pragma unroll
       for (int q = 0; q < CW / 4; ++q) {
         const float4 a4 = *(const float4*)(sC + row * WN + c0 + 4 * q);
         v[4 * q] = a4.x; v[4 * q + 1] = a4.y; v[4 * q + 2] = a4.z; v[4 * q + 3] = a4.w;
       }
-      const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_sample) * p.ld_rowvec + n : nullptr;
-      const float* mu = p.mul ? p.mul + (int64_t)m * p.ld_mul + n : nullptr;
-      const float* rs = res ? res + (int64_t)(p.res_period ? m % p.res_period : m) * p.ld_res + n : nullptr;
-      const int act = (p.debug_flags & 4) ? 0 : p.act;
+      const float* rv = has_rv ? p.rowvec + (int64_t)(m / p.rows_per_sample) * p.ld_rowvec + n : nullptr;
+      const float* mu = has_mu ? p.mul + (int64_t)m * p.ld_mul + n : nullptr;
+      const float* rs = has_rs ? res + (int64_t)(p.res_period ? m % p.res_period : m) * p.ld_res + n : nullptr;
       if (vec) {
 #pragma unroll
         for (int e = 0; e < CW; ++e) v[e] = v[e] * p.alpha + bias_v[e];
-        if (rv) {
+        if (has_rv) {
 #pragma unroll
           for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(rv + 4 * q); v[4 * q] += t4.x; v[4 * q + 1] += t4.y; v[4 * q + 2] += t4.z; v[4 * q + 3] += t4.w; }
         }
+        if (act != 0) {
 #pragma unroll
-        for (int e = 0; e < CW; ++e) v[e] = act_apply(v[e], act);
-        if (mu) {
+          for (int e = 0; e < CW; ++e) v[e] = act_apply(v[e], act);
+        }
+        if (has_mu) {
 #pragma unroll
           for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(mu + 4 * q); v[4 * q] *= t4.x; v[4 * q + 1] *= t4.y; v[4 * q + 2] *= t4.z; v[4 * q + 3] *= t4.w; }
         }
-        if (rs) {
+        if (has_rs) {
 #pragma unroll
           for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(rs + 4 * q); v[4 * q] += t4.x; v[4 * q + 1] += t4.y; v[4 * q + 2] += t4.z; v[4 * q + 3] += t4.w; }
         }
-        if (outf) {
+        if (has_of) {
 #pragma unroll
           for (int q = 0; q < CW / 4; ++q)
             *(float4*)(outf + (int64_t)m * p.ld_out + n + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         }
-        if (outb) {
+        if (has_ob) {
           uint32_t hi[CW / 2], lo[CW / 2];
 #pragma unroll
           for (int e = 0; e < CW / 2; ++e) {
-            if (outbl) {
+            if (has_ol) {
               uint16_t h0, l0, h1, l1;
               f2bf_split(v[2 * e], h0, l0);
               f2bf_split(v[2 * e + 1], h1, l1);
@@ -286,12 +295,12 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
               hi[e] = f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
             }
           }
-          if (CW == 8) {
+          if constexpr (CW == 8) {
             *(uint4*)(outb + (int64_t)m * p.ld_outb + n) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            if (outbl) *(uint4*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            if (has_ol) *(uint4*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
           } else {
             *(uint2*)(outb + (int64_t)m * p.ld_outb + n) = make_uint2(hi[0], hi[1]);
-            if (outbl) *(uint2*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint2(lo[0], lo[1]);
+            if (has_ol) *(uint2*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint2(lo[0], lo[1]);
           }
         }
       } else {
@@ -302,21 +311,43 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
           x = act_apply(x, act);
           if (mu) x *= mu[e];
           if (rs) x += rs[e];
-          if (outf) outf[(int64_t)m * p.ld_out + n + e] = x;
-          if (outb) {
+          if (has_of) outf[(int64_t)m * p.ld_out + n + e] = x;
+          if (has_ob) {
             uint16_t h, l;
             f2bf_split(x, h, l);
             outb[(int64_t)m * p.ld_outb + n + e] = h;
-            if (outbl) outbl[(int64_t)m * p.ld_outb + n + e] = l;
+            if (has_ol) outbl[(int64_t)m * p.ld_outb + n + e] = l;
           }
         }
       }
     }
   };
-  if (p.vec_epilogue == 2)
-    run_epilogue(std::integral_constant<int, 8>{});
-  else
-    run_epilogue(std::integral_constant<int, 4>{});
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
+  using F_ = std::integral_constant<int, 0>;
+  using T_ = std::integral_constant<int, 1>;
+  using R_ = std::integral_constant<int, 2>;
+  using AN = std::integral_constant<int, 0>;
+  using AG = std::integral_constant<int, PD_ACT_GELU>;
+  using AR = std::integral_constant<int, -1>;
+  {
+    const bool rvp = p.rowvec != nullptr, mup = p.mul != nullptr, rsp = res != nullptr, ofp = outf != nullptr, obp = outb != nullptr,
+               olp = outbl != nullptr;
+    const int actv = (p.debug_flags & 4) ? 0 : p.act;
+    if (p.vec_epilogue == 2 && !rvp && !mup && !rsp && !ofp && obp && !olp && (actv == 0 || actv == PD_ACT_GELU)) {
+      // bf16-only producers: QKV (no activation), FFN-1 (GELU)
+      if (actv == 0) run_epilogue(I8{}, AN{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{});
+      else run_epilogue(I8{}, AG{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{});
+    } else if (p.vec_epilogue && ofp && !obp && !mup && actv == 0 && (rsp != rvp)) {
+      // fp32 residual-stream writers: proj / FFN-2 / conv-2 (+residual), conv-1 (+timestep embedding)
+      if (rsp) run_epilogue(I4{}, AN{}, F_{}, F_{}, T_{}, T_{}, F_{}, F_{});
+      else run_epilogue(I4{}, AN{}, T_{}, F_{}, F_{}, T_{}, F_{}, F_{});
+    } else if (p.vec_epilogue == 2) {
+      run_epilogue(I8{}, AR{}, R_{}, R_{}, R_{}, R_{}, R_{}, R_{});
+    } else {
+      run_epilogue(I4{}, AR{}, R_{}, R_{}, R_{}, R_{}, R_{}, R_{});
+    }
+  }
 #endif
 }
 
@@ -387,11 +418,10 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
       (((uintptr_t)a.out_bf16 | (uintptr_t)a.out_bf16_lo) & 15) == 0)
     a.vec_epilogue = 2;   // 16 B bf16 stores
   int tile = a.tile ? a.tile : pd_igemm_default_tile;
-  const int kind = a.taps == 1 ? 0 : (a.KT == 1 ? 1 : 2);
-  if (kind == 0) {
-    PD_CHECK_ARG(a.B == 1 && a.To == 1 && a.Ho == 1 && a.Wo == a.M && a.Ti == 1 && a.Hi == 1 && a.Wi == a.M,
-                 "pd_igemm: taps == 1 expects the identity geometry (B=To=Ho=1, Wo=Wi=M)");
-  }
+  // a 1-tap, stride-1, unpadded, un-upsampled "convolution" is a plain row-wise linear layer: row m reads A row m
+  const bool pointwise = a.taps == 1 && a.st == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.ph == 0 && a.pw == 0 && a.ut == 1 &&
+                         a.uh == 1 && a.uw == 1 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && a.vT <= 0 && a.vH <= 0 && a.vW <= 0;
+  const int kind = pointwise ? 0 : ((a.KT == 1 && a.Ti == 1 && a.To == 1) ? 1 : 2);
   if (tile == 0) {
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.nbatch > 0 ? a.nbatch : 1);
     tile = t128 >= 192 ? (a.split ? 1 : PD_BIG_TILE_DEFAULT) : 2;
