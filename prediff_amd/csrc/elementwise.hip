@@ -65,25 +65,32 @@ extern "C" int pd_timestep_embedding(const int64_t* t, const float* freqs, float
   return PD_OK;
 }
 
-// ---- small dense layer (M <= 64 rows): one wave per output column, fp32 ----
+// ---- small dense layer (M <= 64 rows): one wave per (row, output column), fp32, float4 loads ----
 __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ out, int M, int K, int N,
                                                            int act_in, int act_out) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int m = blockIdx.y;
   if (n >= N) return;
   const float* w = W + (int64_t)n * K;
-  for (int m = 0; m < M; ++m) {
-    float a = 0.f;
-    for (int k = lane; k < K; k += 64) a += act_apply(x[(int64_t)m * K + k], act_in) * w[k];
-    a = wave_sum(a);
-    if (lane == 0) out[(int64_t)m * N + n] = act_apply(a + (bias ? bias[n] : 0.f), act_out);
+  const float* xr = x + (int64_t)m * K;
+  float a = 0.f;
+  if ((K & 3) == 0) {
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 xv = *(const float4*)(xr + k), wv = *(const float4*)(w + k);
+      a += act_apply(xv.x, act_in) * wv.x + act_apply(xv.y, act_in) * wv.y + act_apply(xv.z, act_in) * wv.z + act_apply(xv.w, act_in) * wv.w;
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) a += act_apply(xr[k], act_in) * w[k];
   }
+  a = wave_sum(a);
+  if (lane == 0) out[(int64_t)m * N + n] = act_apply(a + (bias ? bias[n] : 0.f), act_out);
 }
 extern "C" int pd_linear_small(const float* x, const float* W, const float* b, float* out, int M, int K, int N, int act_in, int act_out,
                                pd_stream_t stream) {
-  PD_CHECK_ARG(x && W && out && M > 0 && M <= 64 && K > 0 && N > 0, "pd_linear_small: bad args (M=%d)", M);
-  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, out, M, K, N, act_in, act_out);
+  PD_CHECK_ARG(x && W && out && M > 0 && M <= 65535 && K > 0 && N > 0, "pd_linear_small: bad args (M=%d)", M);
+  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4, M), dim3(256), 0, (hipStream_t)stream, x, W, b, out, M, K, N, act_in, act_out);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }

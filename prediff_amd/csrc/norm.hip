@@ -8,7 +8,9 @@
 // -------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 16;   // up to 64*4*16 = 4096 channels per row
 
-template <bool GATHER>
+// NV = float4 vectors per lane per row (ceil(C/256)), R = rows handled concurrently by one wave (independent load /
+// reduce chains keep R x NV 16 B loads in flight per lane: the kernel is pure HBM streaming).
+template <bool GATHER, int NV, int R>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, pd_bf16* __restrict__ out,
                                                         pd_bf16* __restrict__ out_lo, int64_t rows, int C, int ld_out,
@@ -16,73 +18,106 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
                                                         // patch-merge gather geometry (GATHER only)
                                                         int T, int H, int W, int Cs, int dt, int dh, int dw) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int nv = (C + 255) >> 8;   // float4 vectors per lane
-  float4 v[LN_MAXV];
-  // source row decode for the patch-merge gather: row = ((b*To + to)*Ho + ho)*Wo + wo
-  int64_t gb = 0;
-  int to = 0, ho = 0, wo = 0;
-  if (GATHER) {
-    const int To = (T + dt - 1) / dt, Ho = (H + dh - 1) / dh, Wo = (W + dw - 1) / dw;
-    int64_t r = row;
-    wo = (int)(r % Wo); r /= Wo;
-    ho = (int)(r % Ho); r /= Ho;
-    to = (int)(r % To); gb = r / To;
-  }
-  float s = 0.f;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  float4 v[R][NV];
+  float s[R];
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    if (j >= nv) break;
-    const int c = j * 256 + lane * 4;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < C) {
-      if (GATHER) {
-        // element e = ((it*dh + ih)*dw + iw)*Cs + cs   (cuboid_transformer.py:286-292)
-        const int sub = c / Cs, cs = c - sub * Cs;
-        const int iw = sub % dw, ih = (sub / dw) % dh, it = sub / (dw * dh);
-        const int tt = to * dt + it, hh = ho * dh + ih, ww = wo * dw + iw;
-        if (tt < T && hh < H && ww < W)
-          t = *(const float4*)(x + ((((gb * T + tt) * H + hh) * W + ww) * (int64_t)Cs + cs));
-      } else {
-        t = *(const float4*)(x + row * (int64_t)C + c);
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + r;
+    s[r] = 0.f;
+    // source row decode for the patch-merge gather: row = ((b*To + to)*Ho + ho)*Wo + wo
+    int64_t gb = 0;
+    int to = 0, ho = 0, wo = 0;
+    if (GATHER) {
+      const int To = (T + dt - 1) / dt, Ho = (H + dh - 1) / dh, Wo = (W + dw - 1) / dw;
+      int64_t q = row;
+      wo = (int)(q % Wo); q /= Wo;
+      ho = (int)(q % Ho); q /= Ho;
+      to = (int)(q % To); gb = q / To;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = j * 256 + lane * 4;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C && row < rows) {
+        if (GATHER) {
+          // element e = ((it*dh + ih)*dw + iw)*Cs + cs   (cuboid_transformer.py:286-292)
+          const int sub = c / Cs, cs = c - sub * Cs;
+          const int iw = sub % dw, ih = (sub / dw) % dh, it = sub / (dw * dh);
+          const int tt = to * dt + it, hh = ho * dh + ih, ww = wo * dw + iw;
+          if (tt < T && hh < H && ww < W)
+            t = *(const float4*)(x + ((((gb * T + tt) * H + hh) * W + ww) * (int64_t)Cs + cs));
+        } else {
+          t = *(const float4*)(x + row * (int64_t)C + c);
+        }
+      }
+      v[r][j] = t;
+      s[r] += (t.x + t.y) + (t.z + t.w);
+    }
+  }
+  float mean[R], rstd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) / (float)C;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = j * 256 + lane * 4;
+      if (c < C) {
+        const float a = v[r][j].x - mean[r], b = v[r][j].y - mean[r], cc = v[r][j].z - mean[r], d = v[r][j].w - mean[r];
+        q += (a * a + b * b) + (cc * cc + d * d);
       }
     }
-    v[j] = t;
-    s += t.x + t.y + t.z + t.w;
+    s[r] = q;
   }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    if (j >= nv) break;
-    const int c = j * 256 + lane * 4;
-    if (c < C) {
-      const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
-      q += a * a + b * b + cc * cc + d * d;
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(wave_sum(s[r]) / (float)C + eps);
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    if (j >= nv) break;
+  for (int j = 0; j < NV; ++j) {
     const int c = j * 256 + lane * 4;
     if (c >= ld_out) continue;
-    float y[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < C) {
-      const float4 g = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
-      y[0] = (v[j].x - mean) * rstd * g.x + be.x;
-      y[1] = (v[j].y - mean) * rstd * g.y + be.y;
-      y[2] = (v[j].z - mean) * rstd * g.z + be.z;
-      y[3] = (v[j].w - mean) * rstd * g.w + be.w;
-    }
-    uint16_t hi[4], lo[4];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), be = g;
+    if (c < C) { g = *(const float4*)(gamma + c); be = *(const float4*)(beta + c); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) f2bf_split(y[k], hi[k], lo[k]);
-    *(uint2*)(out + row * (int64_t)ld_out + c) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
-    if (out_lo)
-      *(uint2*)(out_lo + row * (int64_t)ld_out + c) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = row0 + r;
+      if (row >= rows) continue;
+      float y[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+        y[0] = (v[r][j].x - mean[r]) * rstd[r] * g.x + be.x;
+        y[1] = (v[r][j].y - mean[r]) * rstd[r] * g.y + be.y;
+        y[2] = (v[r][j].z - mean[r]) * rstd[r] * g.z + be.z;
+        y[3] = (v[r][j].w - mean[r]) * rstd[r] * g.w + be.w;
+      }
+      if (out_lo) {
+        uint16_t hi[4], lo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f2bf_split(y[k], hi[k], lo[k]);
+        *(uint2*)(out + row * (int64_t)ld_out + c) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+        *(uint2*)(out_lo + row * (int64_t)ld_out + c) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+      } else {
+        *(uint2*)(out + row * (int64_t)ld_out + c) =
+            make_uint2(f2bf(y[0]) | ((uint32_t)f2bf(y[1]) << 16), f2bf(y[2]) | ((uint32_t)f2bf(y[3]) << 16));
+      }
+    }
   }
+}
+
+template <bool GATHER>
+static void launch_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo, int64_t rows, int C,
+                             int ld_out, float eps, int T, int H, int W, int Cs, int dt, int dh, int dw, hipStream_t s) {
+  const int nv = (C + 255) / 256;
+#define PD_LN(NV, R)                                                                                                              \
+  hipLaunchKernelGGL((layernorm_kernel<GATHER, NV, R>), dim3((unsigned)((rows + 4 * (R) - 1) / (4 * (R)))), dim3(256), 0, s, x, gamma, \
+                     beta, out, out_lo, rows, C, ld_out, eps, T, H, W, Cs, dt, dh, dw)
+  if (nv <= 1) PD_LN(1, 4);
+  else if (nv <= 2) PD_LN(2, 2);
+  else if (nv <= 4) PD_LN(4, 1);
+  else if (nv <= 8) PD_LN(8, 1);
+  else PD_LN(16, 1);
+#undef PD_LN
 }
 
 extern "C" int pd_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
@@ -92,8 +127,7 @@ extern "C" int pd_layernorm(const float* x, const float* gamma, const float* bet
   PD_CHECK_ARG(ld_out >= C && (ld_out & 3) == 0 && ld_out <= ((C + 255) / 256) * 256,
                "pd_layernorm: ld_out=%d must be >= C, multiple of 4 and within the last 256-column block", ld_out);
   if (rows <= 0) return PD_OK;
-  hipLaunchKernelGGL((layernorm_kernel<false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                     out, out_lo, rows, C, ld_out, eps, 0, 0, 0, 0, 1, 1, 1);
+  launch_layernorm<false>(x, gamma, beta, out, out_lo, rows, C, ld_out, eps, 0, 0, 0, 0, 1, 1, 1, (hipStream_t)stream);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -106,8 +140,7 @@ extern "C" int pd_patch_merge_layernorm(const float* x, const float* gamma, cons
   PD_CHECK_ARG((C & 3) == 0 && Cm <= 256 * LN_MAXV, "pd_patch_merge_layernorm: C=%d (merged %d) unsupported", C, Cm);
   PD_CHECK_ARG(ld_out >= Cm && (ld_out & 3) == 0 && ld_out <= ((Cm + 255) / 256) * 256, "pd_patch_merge_layernorm: bad ld_out=%d", ld_out);
   const int64_t rows = (int64_t)B * ((T + dt - 1) / dt) * ((H + dh - 1) / dh) * ((W + dw - 1) / dw);
-  hipLaunchKernelGGL((layernorm_kernel<true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                     out, out_lo, rows, Cm, ld_out, eps, T, H, W, C, dt, dh, dw);
+  launch_layernorm<true>(x, gamma, beta, out, out_lo, rows, Cm, ld_out, eps, T, H, W, C, dt, dh, dw, (hipStream_t)stream);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
