@@ -15,7 +15,7 @@ second over the whole job = gpus * batch * steps / wall (max over ranks).  Ranks
 frames, outside the step loop).
 
 Two extra objects on the JSON line:
-  roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM, igemm_kernel<128,128,false,2>): algorithmic FLOPs per
+  roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM, igemm_kernel<128,128,64,2,false,2,...>): algorithmic FLOPs per
                  launch / its average launch duration measured here with HIP events, against the dense bf16 MFMA peak.
   cpu_baseline - the oracle (CPU restatement of the reference forward) timed on this box's host cores on a bounded
                  sample of the same workload (kind "port").
@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="latent trajectories (ensemble members) per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="latent trajectories (ensemble members) per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,7 +211,7 @@ def main():
                        "parallelism": f"ensemble-shard x{n_gpus}"},
             "step_tflops": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12, 2),
             "step_frac_of_bf16_peak": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<128,128,false,2> (Conv3d 3x3x3 implicit GEMM)",
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<128,128,64,2,false,2,2,1> (Conv3d 3x3x3 implicit GEMM)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches,

@@ -39,8 +39,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // KIND: 0 linear (no spatial decode), 1 conv2d, 2 conv3d -- also tags the instantiation so profilers report the uses separately.
 // BK in {32, 64}; NS = LDS ring depth (NS-1 K-steps of operand traffic in flight while one is being consumed).
-template <int BM, int BN, int BK, int NS, bool SPLIT, int KIND>
-__global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
+template <int BM, int BN, int BK, int NS, bool SPLIT, int KIND, int OCC = 2, int ESLAB = 1>
+__global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
   constexpr int ROWB = BK * 2;                    // bytes per tile row
   constexpr int CPR = ROWB / 16;                  // 16 B chunks per row (4 or 8)
@@ -207,19 +207,11 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
 
-  // ---- epilogue: accumulators -> per-wave LDS slab (row major) -> coalesced 16 B row segments ----
+  // ---- epilogue: accumulators -> per-wave LDS slab (row major, ESLAB column slabs in turn) -> coalesced 16 B row segments ----
   constexpr int WM = BM / 2, WN = BN / 2;
-  __syncthreads();                                 // every wave is done reading the operand stages
-  float* sC = (float*)smem + wave * (WM * WN);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + j * 32 + lrow] = acc[i][j][r];
-  __syncthreads();
-
+  constexpr int WNS = WN / ESLAB;                  // columns staged at a time
+  constexpr int TNS = TN / ESLAB;
+  float* sC = (float*)smem + wave * (WM * WNS);
   float* outf = p.out_f32 ? p.out_f32 + (int64_t)bz * p.out_batch_stride : nullptr;
   pd_bf16* outb = p.out_bf16 ? p.out_bf16 + (int64_t)bz * p.outb_batch_stride : nullptr;
   pd_bf16* outbl = p.out_bf16_lo ? p.out_bf16_lo + (int64_t)bz * p.outb_batch_stride : nullptr;
@@ -227,14 +219,15 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
   // The row loop is instantiated per (columns-per-lane, activation, operand presence) so that the hot call sites get
   // straight-line code; tag value 2 = "decide at run time" (generic instantiation).
   //   CW columns per lane: 8 when only bf16 is stored (16 B stores: the 8 B/lane form is store-issue bound), else 4.
+  int slab = 0;
   auto run_epilogue = [&](auto cw_tag, auto act_tag, auto rv_tag, auto mu_tag, auto rs_tag, auto of_tag, auto ob_tag, auto ol_tag) {
     constexpr int CW = decltype(cw_tag)::value;
     constexpr int ACT = decltype(act_tag)::value;          // -1 = run time
     auto on = [](auto tag, bool rt) { constexpr int T = decltype(tag)::value; return T == 2 ? rt : (T == 1); };
-    constexpr int LPR = WN / CW;                     // lanes per row
+    constexpr int LPR = WNS / CW;                    // lanes per row
     constexpr int RPP = 64 / LPR;                    // rows per pass
     const int c0 = (lane % LPR) * CW;
-    const int n = n0 + wc * WN + c0;
+    const int n = n0 + wc * WN + slab * WNS + c0;
     const bool vec = p.vec_epilogue && (n + CW - 1 < p.N);
     const bool has_rv = on(rv_tag, p.rowvec != nullptr), has_mu = on(mu_tag, p.mul != nullptr), has_rs = on(rs_tag, res != nullptr);
     const bool has_of = on(of_tag, outf != nullptr), has_ob = on(ob_tag, outb != nullptr), has_ol = on(ol_tag, outbl != nullptr);
@@ -251,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
       float v[CW];
 #pragma unroll
       for (int q = 0; q < CW / 4; ++q) {
-        const float4 a4 = *(const float4*)(sC + row * WN + c0 + 4 * q);
+        const float4 a4 = *(const float4*)(sC + row * WNS + c0 + 4 * q);
         v[4 * q] = a4.x; v[4 * q + 1] = a4.y; v[4 * q + 2] = a4.z; v[4 * q + 3] = a4.w;
       }
       const float* rv = has_rv ? p.rowvec + (int64_t)(m / p.rows_per_sample) * p.ld_rowvec + n : nullptr;
@@ -330,35 +323,48 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const pd_igemm_args p) {
   using AN = std::integral_constant<int, 0>;
   using AG = std::integral_constant<int, PD_ACT_GELU>;
   using AR = std::integral_constant<int, -1>;
+#pragma unroll
+  for (int js = 0; js < ESLAB; ++js) {
+    __syncthreads();                               // operand stages (js == 0) / previous slab (js > 0) are no longer read
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TNS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * WNS + j * 32 + lrow] = acc[i][js * TNS + j][r];
+    __syncthreads();
+    slab = js;
   {
-    const bool rvp = p.rowvec != nullptr, mup = p.mul != nullptr, rsp = res != nullptr, ofp = outf != nullptr, obp = outb != nullptr,
-               olp = outbl != nullptr;
-    const int actv = (p.debug_flags & 4) ? 0 : p.act;
-    if (p.vec_epilogue == 2 && !rvp && !mup && !rsp && !ofp && obp && !olp && (actv == 0 || actv == PD_ACT_GELU)) {
-      // bf16-only producers: QKV (no activation), FFN-1 (GELU)
-      if (actv == 0) run_epilogue(I8{}, AN{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{});
-      else run_epilogue(I8{}, AG{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{});
-    } else if (p.vec_epilogue && ofp && !obp && !mup && actv == 0 && (rsp != rvp)) {
-      // fp32 residual-stream writers: proj / FFN-2 / conv-2 (+residual), conv-1 (+timestep embedding)
-      if (rsp) run_epilogue(I4{}, AN{}, F_{}, F_{}, T_{}, T_{}, F_{}, F_{});
-      else run_epilogue(I4{}, AN{}, T_{}, F_{}, F_{}, T_{}, F_{}, F_{});
-    } else if (p.vec_epilogue == 2) {
-      run_epilogue(I8{}, AR{}, R_{}, R_{}, R_{}, R_{}, R_{}, R_{});
-    } else {
-      run_epilogue(I4{}, AR{}, R_{}, R_{}, R_{}, R_{}, R_{}, R_{});
+      const bool rvp = p.rowvec != nullptr, mup = p.mul != nullptr, rsp = res != nullptr, ofp = outf != nullptr, obp = outb != nullptr,
+                 olp = outbl != nullptr;
+      const int actv = (p.debug_flags & 4) ? 0 : p.act;
+      if (p.vec_epilogue == 2 && !rvp && !mup && !rsp && !ofp && obp && !olp && (actv == 0 || actv == PD_ACT_GELU)) {
+        // bf16-only producers: QKV (no activation), FFN-1 (GELU)
+        if (actv == 0) run_epilogue(I8{}, AN{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{});
+        else run_epilogue(I8{}, AG{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{});
+      } else if (p.vec_epilogue && ofp && !obp && !mup && actv == 0 && (rsp != rvp)) {
+        // fp32 residual-stream writers: proj / FFN-2 / conv-2 (+residual), conv-1 (+timestep embedding)
+        if (rsp) run_epilogue(I4{}, AN{}, F_{}, F_{}, T_{}, T_{}, F_{}, F_{});
+        else run_epilogue(I4{}, AN{}, T_{}, F_{}, F_{}, T_{}, F_{}, F_{});
+      } else if (p.vec_epilogue == 2) {
+        run_epilogue(I8{}, AR{}, R_{}, R_{}, R_{}, R_{}, R_{}, R_{});
+      } else {
+        run_epilogue(I4{}, AR{}, R_{}, R_{}, R_{}, R_{}, R_{}, R_{});
+      }
     }
   }
 #endif
 }
 
-template <int BM, int BN, int BK, int NS, bool SPLIT, int KIND>
+template <int BM, int BN, int BK, int NS, bool SPLIT, int KIND, int OCC = 2, int ESLAB = 1>
 static int launch_igemm(const pd_igemm_args& a, hipStream_t s) {
   constexpr int stage = (BM + BN) * BK * 2 * (SPLIT ? 2 : 1);
-  constexpr int epi = 4 * (BM / 2) * (BN / 2) * 4;
-  constexpr int lds = NS * stage > epi ? NS * stage : epi;
+  constexpr int epi = 4 * (BM / 2) * (BN / 2) * 4 / ESLAB;
+  constexpr int lds = NS * stage > epi ? NS * stage : epi;   // the accumulator slab of the epilogue re-uses the operand ring
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, NS, SPLIT, KIND>,
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, NS, SPLIT, KIND, OCC, ESLAB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
@@ -368,7 +374,7 @@ static int launch_igemm(const pd_igemm_args& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, 1, a.nbatch > 0 ? a.nbatch : 1);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, NS, SPLIT, KIND>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, NS, SPLIT, KIND, OCC, ESLAB>), grid, dim3(256), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -382,6 +388,8 @@ static int dispatch_igemm(const pd_igemm_args& a, int tile, hipStream_t s) {
     case 2: return launch_igemm<64, 64, 64, 2, SPLIT, KIND>(a, s);
     case 3: return launch_igemm<128, 128, 32, 4, SPLIT, KIND>(a, s);
     case 4: return launch_igemm<128, 128, 64, 3, SPLIT, KIND>(a, s);
+    case 5: return launch_igemm<128, 128, 32, 2, SPLIT, KIND, (SPLIT ? 2 : 4), 2>(a, s);   // 32 KB LDS, <=128 VGPR: 4 workgroups/CU
+    case 6: return launch_igemm<128, 128, 32, 3, SPLIT, KIND, (SPLIT ? 2 : 3), 2>(a, s);   // 48 KB LDS: 3 workgroups/CU
     default: pd_set_error("pd_igemm: unknown tile config %d", tile); return PD_ERR_ARG;
   }
 }
@@ -424,7 +432,9 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   const int kind = pointwise ? 0 : ((a.KT == 1 && a.Ti == 1 && a.To == 1) ? 1 : 2);
   if (tile == 0) {
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.nbatch > 0 ? a.nbatch : 1);
-    tile = t128 >= 192 ? (a.split ? 1 : PD_BIG_TILE_DEFAULT) : 2;
+    // measured on MI355X (scripts/bench_igemm.py): with <= 4 K-steps the 4-workgroups/CU variant (BK 32, 32 KB LDS) hides the
+    // prologue/epilogue of its neighbours best; longer K prefers the BK 64 two-stage tile.
+    tile = t128 >= 192 ? ((!a.split && (int64_t)a.taps * a.Cin <= 256) ? 5 : PD_BIG_TILE_DEFAULT) : 2;
   }
   if (a.split && tile == 4) tile = 1;   // 3 x 64 KB stages do not fit
   if (a.split) {

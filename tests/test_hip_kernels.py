@@ -38,7 +38,8 @@ def padded_bf16(x2d, split=False):
 @pytest.mark.parametrize("M,N,K,tile", [(256, 128, 64, 1), (256, 128, 64, 2), (3328, 768, 256, 0), (1000, 200, 96, 1),
                                         (1000, 200, 96, 2), (37, 5, 32, 2), (832, 2048, 512, 0), (128, 64, 1024, 2),
                                         (3328, 768, 256, 3), (3328, 768, 256, 4), (1000, 200, 96, 3), (1000, 200, 96, 4), (300, 130, 64, 3),
-                                        (300, 130, 64, 4), (512, 256, 2048, 3), (512, 256, 2048, 4)])
+                                        (300, 130, 64, 4), (512, 256, 2048, 3), (512, 256, 2048, 4),
+                                        (3328, 768, 256, 5), (1000, 200, 96, 5), (300, 130, 64, 6), (512, 256, 2048, 6), (3328, 768, 256, 6)])
 @pytest.mark.parametrize("split", [False, True])
 def test_igemm_linear(M, N, K, tile, split):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
@@ -98,7 +99,7 @@ def test_igemm_batched():
 # ------------------------------------------------------------------------------------------------ igemm: convolutions
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 5, 8, 8, 64, 64), (1, 13, 16, 16, 256, 256), (2, 3, 6, 6, 5, 32), (1, 13, 8, 8, 512, 512)])
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("tile", [0, 3, 4])
+@pytest.mark.parametrize("tile", [0, 3, 4, 5, 6])
 def test_igemm_conv3d(B, T, H, W, Cin, Cout, split, tile):
     g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
     x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
