@@ -92,17 +92,26 @@ def cpu_baseline(budget_s=15.0):
     sd = seeded_state_dict(unet_template(V1_UNET_CFG, "v1_unet_schema.json"), 1234)
     x, c = seeded_input("v1x", (1, 6, 16, 16, 64), 2), seeded_input("v1c", (1, 7, 16, 16, 64), 3)
     t = torch.tensor([500])
+    # many-core hosts oversubscribe on these small convolutions: time the full core count and a 32-thread run, report the better
+    ncpu = torch.get_num_threads()
+    best = None
     with torch.no_grad():
-        OU.unet_forward(sd, V1_UNET_CFG, x, t, c)      # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            OU.unet_forward(sd, V1_UNET_CFG, x, t, c)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 12:
-                break
-    return {"value": round(n / el, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} oracle denoiser forwards (fp32, B=1, v1 config, torch CPU {torch.get_num_threads()} threads) in {el:.1f} s"}
+        for nthr in sorted({ncpu, min(ncpu, 32)}, reverse=True):
+            torch.set_num_threads(nthr)
+            OU.unet_forward(sd, V1_UNET_CFG, x, t, c)      # warm-up
+            n, t0 = 0, time.perf_counter()
+            while True:
+                OU.unet_forward(sd, V1_UNET_CFG, x, t, c)
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget_s / 2 or n >= 12:
+                    break
+            if best is None or n / el > best[0]:
+                best = (n / el, nthr, n, el)
+        torch.set_num_threads(ncpu)
+    v, nthr, n, el = best
+    return {"value": round(v, 4), "unit": "steps/s", "cores": nthr, "kind": "port",
+            "sample": f"{n} oracle denoiser forwards (fp32, B=1, v1 config, torch CPU, {nthr} of {ncpu} threads) in {el:.1f} s"}
 
 
 def main():
