@@ -159,6 +159,12 @@ int pd_ddim_step(const float* zt, const float* eps, const float* noise, const fl
 int pd_nchw_to_nhwc(const float* x, float* out, int N, int C, int HW, int ld_out, pd_stream_t stream);
 int pd_nhwc_to_nchw(const float* x, float* out, int N, int C, int HW, int ld_in, pd_stream_t stream);
 
+/* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
+ * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]
+ * (int64, keep_seq) or counts[thr][3].  Tensors are (outer, T, inner) fp32 in [0,1]; divisor = fp32(1/255). */
+int pd_sevir_skill_counts(const float* pred, const float* target, const float* thresholds, int nthr, float divisor,
+                          long long* counts, int64_t outer, int T, int64_t inner, int keep_seq, pd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ _PROTOS = {
     "pd_ddim_step": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_void_p]),
     "pd_nchw_to_nhwc": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "pd_nhwc_to_nchw": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
@@ -255,3 +256,8 @@ def nchw_to_nhwc(x, out, N, Cn, HW, ld_out):
 
 def nhwc_to_nchw(x, out, N, Cn, HW, ld_in):
     _check(lib().pd_nhwc_to_nchw(ptr(x), ptr(out), N, Cn, HW, ld_in, stream_ptr()), "pd_nhwc_to_nchw")
+
+
+def sevir_skill_counts(pred, target, thresholds, divisor, counts, outer, T, inner, keep_seq):
+    _check(lib().pd_sevir_skill_counts(ptr(pred), ptr(target), ptr(thresholds), thresholds.numel(), divisor, ptr(counts), outer, T,
+                                       inner, 1 if keep_seq else 0, stream_ptr()), "pd_sevir_skill_counts")

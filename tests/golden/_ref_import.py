@@ -82,6 +82,25 @@ def install_stubs():
     dm.autoencoder_kl = dma
     diffusers.models = dm
 
+    # torchmetrics.Metric / h5py: only needed to import datasets/sevir/evaluation.py (SEVIRSkillScore)
+    tm = _mod("torchmetrics")
+
+    class Metric(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self._defaults = {}
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            self._defaults[name] = default.clone()
+            setattr(self, name, default.clone())
+
+        def reset(self):
+            for k, v in self._defaults.items():
+                setattr(self, k, v.clone())
+
+    tm.Metric = Metric
+    _mod("h5py")
+
     tv = _mod("torchvision")
     tvm = _mod("torchvision.models")
 
@@ -122,4 +141,6 @@ def import_reference():
     ns.dutils = dutils
     ns.DiagonalGaussianDistribution = DiagonalGaussianDistribution
     ns.SEVIRAvgIntensityAlignment = SEVIRAvgIntensityAlignment
+    from prediff.datasets.sevir.evaluation import SEVIRSkillScore
+    ns.SEVIRSkillScore = SEVIRSkillScore
     return ns

@@ -22,6 +22,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 from _ref_import import import_reference  # noqa: E402
 from _weights import seeded_state_dict, seeded_input  # noqa: E402
+from _inputs import skill_inputs  # noqa: E402
 from _cases import (ATTN_CASES, MASK_CASES, REORDER_CASES, TINY_UNET_CFGS, TINY_VAE_CFG, V1_UNET_CFG,  # noqa: E402
                     V1_VAE_CFG, RESBLOCK3D_CASES)
 
@@ -320,8 +321,27 @@ def gen_alignment():
     save("v1_alignment", u=net(z, torch.tensor([400, 20])))
 
 
+def gen_skill():
+    """SEVIRSkillScore (datasets/sevir/evaluation.py:88-285): accumulated counts after two updates + compute() for modes 0/1/2."""
+    pred, target = skill_inputs()
+    arrs = {}
+    for mode in ("0", "1", "2"):
+        m = R.SEVIRSkillScore(layout="NTHWC", mode=mode, seq_len=6, preprocess_type="sevir",
+                              threshold_list=(16, 74, 133, 160, 181, 219), metrics_list=("csi", "pod", "sucr", "bias"))
+        m.update(pred, target)
+        m.update(pred.flip(0), target)          # second, different batch
+        arrs[f"hits_{mode}"], arrs[f"misses_{mode}"], arrs[f"fas_{mode}"] = m.hits, m.misses, m.fas
+        res = m.compute()
+        for thr in (16, 74, 133, 160, 181, 219, "avg"):
+            for met in ("csi", "pod", "sucr", "bias"):
+                arrs[f"score_{mode}_{thr}_{met}"] = np.asarray(res[thr][met], dtype=np.float64)
+    save("skill_score", **arrs)
+
+
 def main():
-    which = sys.argv[1:] or ["index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion", "alignment"]
+    which = sys.argv[1:] or ["skill", "index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion", "alignment"]
+    if "skill" in which:
+        gen_skill()
     if "alignment" in which:
         torch.set_grad_enabled(True)
         gen_alignment()

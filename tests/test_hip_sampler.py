@@ -145,3 +145,30 @@ def test_ensemble_members_are_batch_split_invariant():
     assert a.shape == (4,) + tuple(cfg["target_shape"])
     assert rel_l2(b, a) < 1e-6 and rel_l2(c, d) < 1e-6
     assert rel_l2(a[0], a[1]) > 1e-2            # members differ
+
+
+def test_config_front_end_end_to_end():
+    """YAML -> build_prediff -> evaluate_context (the sampling part of the reference test_step) on a reduced-size config."""
+    import os
+    from prediff_amd import config as CFG
+    from prediff_amd.sevir_skill import SEVIRSkillScore
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = CFG.load_config(os.path.join(root, "configs", "prediff_sevirlr_v1.yaml"))
+    # shrink: 32x32 frames, 2-level VAE, small denoiser / alignment net (same code paths, seconds instead of minutes)
+    cfg["layout"].update(img_height=32, img_width=32)
+    cfg["model"]["vae"].update(block_out_channels=[32, 64, 64], down_block_types=["DownEncoderBlock2D"] * 3,
+                               up_block_types=["UpDecoderBlock2D"] * 3, layers_per_block=1, latent_channels=4, norm_num_groups=8)
+    cfg["model"]["latent_model"].update(input_shape=[7, 8, 8, 4], target_shape=[6, 8, 8, 4], base_units=64, depth=[1, 1], num_heads=2)
+    cfg["model"]["diffusion"].update(data_shape=[6, 32, 32, 1], latent_shape=[6, 8, 8, 4])
+    cfg["model"]["align"]["model_args"].update(input_shape=[6, 8, 8, 4], base_units=32, num_heads=2)
+    ldm, align = CFG.build_prediff(cfg, precision="bf16")
+    for mod, seed in ((ldm.torch_nn_module, 1), (ldm.first_stage_model, 2), (align.model, 3)):
+        mod.load_state_dict(seeded_state_dict(mod.state_dict(), seed))
+    seq = seeded_input("seq", (2, 13, 32, 32, 1), 4, kind="uniform").cuda()
+    score, ascore = (SEVIRSkillScore(layout="NTHWC", mode="0") for _ in range(2))
+    out = CFG.evaluate_context(ldm, seq, cfg, score=score, aligned_score=ascore, timesteps=3)
+    assert out["pred"][0].shape == (2, 6, 32, 32, 1) and out["aligned_pred"][0].shape == (2, 6, 32, 32, 1)
+    assert bool(torch.isfinite(out["pred"][0]).all()) and bool(torch.isfinite(out["aligned_pred"][0]).all())
+    assert not torch.equal(out["pred"][0], out["aligned_pred"][0])
+    res = score.compute()
+    assert set(res.keys()) == {16, 74, 133, 160, 181, 219, "avg"} and 0.0 <= res["avg"]["csi"] <= 1.0
