@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-ffn", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,6 +143,7 @@ def main():
     from prediff_amd.schedule import make_ddim_sampling_parameters, make_ddim_timesteps
     B = args.batch
     ldm = v1_model(args.precision, device)
+    ldm.torch_nn_module.fuse_ffn = not args.no_fused_ffn
     shape = ldm.get_batch_latent_shape(B)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     zc = torch.randn((B, 7, 16, 16, 64), generator=g).to(device)

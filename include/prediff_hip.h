@@ -159,6 +159,13 @@ int pd_ddim_step(const float* zt, const float* eps, const float* noise, const fl
 int pd_nchw_to_nhwc(const float* x, float* out, int N, int C, int HW, int ld_out, pd_stream_t stream);
 int pd_nhwc_to_nchw(const float* x, float* out, int N, int C, int HW, int ld_in, pd_stream_t stream);
 
+/* PositionwiseFFN.forward, pre-norm (cuboid_transformer.py:182-208) fused into one launch: out = x + W2 act(W1 LN(x) + b1) + b2.
+ * x/out fp32 (M, C) (may alias), W1 bf16 (Hd, C), W2 bf16 (C, Hd) as packed for pd_igemm.  The hidden activations stay in LDS.
+ * Supported when pd_ffn_fused_supported(C, Hd) (C in {64,128,256}, Hd % 64 == 0); otherwise use pd_layernorm + 2 x pd_igemm. */
+int pd_ffn_fused_supported(int C, int Hd);
+int pd_ffn_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* W1, const float* b1,
+                 const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, pd_stream_t stream);
+
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
  * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]
  * (int64, keep_seq) or counts[thr][3].  Tensors are (outer, T, inner) fp32 in [0,1]; divisor = fp32(1/255). */

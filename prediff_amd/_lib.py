@@ -65,6 +65,8 @@ _PROTOS = {
     "pd_ddim_step": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_void_p]),
     "pd_nchw_to_nhwc": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "pd_nhwc_to_nchw": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
+    "pd_ffn_fused_supported": (C.c_int, [C.c_int, C.c_int]),
+    "pd_ffn_fused": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -261,3 +263,12 @@ def nhwc_to_nchw(x, out, N, Cn, HW, ld_in):
 def sevir_skill_counts(pred, target, thresholds, divisor, counts, outer, T, inner, keep_seq):
     _check(lib().pd_sevir_skill_counts(ptr(pred), ptr(target), ptr(thresholds), thresholds.numel(), divisor, ptr(counts), outer, T,
                                        inner, 1 if keep_seq else 0, stream_ptr()), "pd_sevir_skill_counts")
+
+
+def ffn_fused_supported(Cn, Hd):
+    return bool(lib().pd_ffn_fused_supported(Cn, Hd))
+
+
+def ffn_fused(x, out, gamma, beta, W1, b1, W2, b2, M, Cn, Hd, act="gelu", eps=1e-5):
+    _check(lib().pd_ffn_fused(ptr(x), ptr(out), ptr(gamma), ptr(beta), ptr(W1), ptr(b1), ptr(W2), ptr(b2), M, Cn, Hd, ACT[act], eps,
+                              stream_ptr()), "pd_ffn_fused")

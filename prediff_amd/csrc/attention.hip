@@ -88,8 +88,8 @@ __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_a
     o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o, 0, 0, 0);
     // lane: query q, d = d0 + 4g + r
     if (orow) {
-      const uint32_t lo = f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-      const uint32_t hi = f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+      const uint32_t lo = pack_bf16x2(o[0], o[1]);
+      const uint32_t hi = pack_bf16x2(o[2], o[3]);
       *(uint2*)(orow + d0) = make_uint2(lo, hi);
     }
   }

@@ -36,6 +36,12 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// two fp32 -> packed bf16x2 (lo | hi << 16), round to nearest even, ONE instruction (gfx950 v_cvt_pk_bf16_f32; no builtin)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // hi/lo bf16 decomposition: x ~= hi + lo with ~16 mantissa bits.

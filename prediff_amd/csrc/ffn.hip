@@ -1,0 +1,300 @@
+// pd_ffn_fused: out = x + W2 * act(W1 * LayerNorm(x) + b1) + b2 in ONE kernel (PositionwiseFFN.forward, pre-norm,
+// reference cuboid_transformer.py:182-208).
+//
+// Why: at the SEVIR-LR level-0 shapes (C = 256, hidden 1024, K only 256) the un-fused chain LN -> GEMM -> GEMM is HBM bound: the
+// bf16 hidden tensor (tokens x 1024) is written and read back (2 x 218 MB at 32 trajectories), plus the LN output.  Here the
+// hidden activations never leave the CU: algorithmic HBM traffic drops to one fp32 read + one fp32 write of x, and the kernel
+// is MFMA bound again.
+//
+// One workgroup = 512 threads (8 waves) owns BM = 128 token rows:
+//   phase 0   LayerNorm of the 128 rows (one wave per 16 rows, fp32, two-pass) -> bf16 A tile in LDS, K-slab swizzled exactly
+//             like the igemm operand tiles (conflict-free ds_read_b128).
+//   chunk j   (64 hidden units at a time, Hd/64 chunks)
+//       GEMM-1  H_j^T[64 x 128] = W1_j[64 x C] * A^T           one 32x32 MFMA tile per wave, K = C
+//               +b1, activation, bf16: the transposed product leaves 4 consecutive hidden units per lane -> 8 B LDS writes
+//               straight into the A-operand layout GEMM-2 reads.
+//       GEMM-2  acc[128 x C] += H_j[128 x 64] * W2_j[C x 64]^T  wave tile 32 x C/2, K = 64
+//     W1_j and W2_j stream through two single LDS buffers by buffer-descriptor DMA (16 B/lane): W2_j is in flight during
+//     GEMM-1 of chunk j, W1_{j+1} during GEMM-2 of chunk j; two barriers and 16+16 MFMAs per wave per chunk (C = 256).
+//   epilogue  acc + b2 + x -> out (fp32), staged through LDS for 16 B row segments.
+// LDS: A 128*C*2 + H 16 KB + W1 64*C*2 + W2 C*128  = 144 KB at C = 256 (one workgroup per CU, two waves per SIMD).
+#include "common.h"
+
+#define BLDS16(rsrc, ldsptr, voff, soff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
+
+struct pd_ffn_args_k {
+  const float* x;
+  float* out;
+  const float* gamma;
+  const float* beta;
+  const pd_bf16* W1;     // [Hd][C]
+  const float* b1;
+  const pd_bf16* W2;     // [C][Hd]
+  const float* b2;
+  int M, Hd, act;
+  float eps;
+  uint32_t w1_bytes, w2_bytes;
+  int dbg;   // profiling ablations: 1 no weight DMA after chunk 0, 2 no GEMM-1, 4 no activation + H store, 8 no GEMM-2
+};
+
+template <int C, int ACT>
+__global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, HC = 64;
+  constexpr int KS = C / 64;                       // 64-wide K slabs of the A tile / W1 chunk
+  constexpr int A_BYTES = BM * C * 2;
+  constexpr int H_BYTES = BM * HC * 2;
+  constexpr int W1_BYTES = HC * C * 2;
+  constexpr int W2_BYTES = C * HC * 2;
+  constexpr int TN2 = (C / 2) / 32;                // 32x32 tiles per wave in GEMM-2 (wave tile 32 x C/2)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sH = sA + A_BYTES;
+  char* sW1 = sH + H_BYTES;
+  char* sW2 = sW1 + W1_BYTES;
+  float* sB1 = (float*)(sW2 + W2_BYTES);            // whole b1 (Hd floats): an ordinary global load inside the chunk loop would make
+                                                    // hipcc drain the weight DMA queue (vmcnt(0)) every chunk
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * BM;
+  const int NJ = p.Hd / HC;
+
+  const auto rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, 0, p.w1_bytes, 0x00020000);
+  const auto rW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2, 0, p.w2_bytes, 0x00020000);
+
+  // DMA lane mapping: one 512-thread instruction fills one [64 rows][64 k] slab (8 KB), lane-linear, source-side swizzle
+  const int drow = tid >> 3, dpos = tid & 7;
+  const int dchunk = dpos ^ ((drow >> 1) & 7);
+  const uint32_t w1_voff = ((uint32_t)drow * C + dchunk * 8) * 2u;                 // + (j*64*C + s*64)*2 in the SGPR offset
+  uint32_t w2_voff[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) w2_voff[i] = ((uint32_t)(i * 64 + drow) * (uint32_t)p.Hd + dchunk * 8) * 2u;   // + j*64*2
+
+  // weight buffers: set 0 = {sW1, sW2}; set 1 = the A-tile region (A_BYTES == W1_BYTES + W2_BYTES), free once every wave
+  // holds its A fragments in registers
+  auto w1buf = [&](int b) { return b ? sA : sW1; };
+  auto w2buf = [&](int b) { return b ? sA + W1_BYTES : sW2; };
+  auto issue_w = [&](int j, int b) {
+    char* d1 = w1buf(b);
+    char* d2 = w2buf(b);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) BLDS16(rW1, d1 + s * 8192 + wave * 1024, w1_voff, (j * HC * C + s * 64) * 2);
+#pragma unroll
+    for (int i = 0; i < KS; ++i) BLDS16(rW2, d2 + i * 8192 + wave * 1024, w2_voff[i], j * HC * 2);
+  };
+
+  for (int i = tid; i < p.Hd; i += 512) sB1[i] = p.b1[i];
+  issue_w(0, 0);
+
+  // ---- phase 0: LayerNorm -> bf16 A tile (KS slabs of [128][64], chunk swizzle (row>>1)&7) ----
+  {
+    constexpr int LPRW = C / 4;                    // lanes holding one row (float4 each)
+    const bool act_lane = lane < LPRW;
+    float4 g4 = make_float4(0, 0, 0, 0), b4 = g4;
+    if (act_lane) { g4 = *(const float4*)(p.gamma + lane * 4); b4 = *(const float4*)(p.beta + lane * 4); }
+    float4 xv[16];                                 // all 16 rows of this wave in flight at once (latency, not bandwidth, bound)
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int m = m0 + wave * 16 + rr;
+      xv[rr] = make_float4(0, 0, 0, 0);
+      if (act_lane && m < p.M) xv[rr] = *(const float4*)(p.x + (int64_t)m * C + lane * 4);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = wave * 16 + rr;
+      const int m = m0 + row;
+      const float4 v = xv[rr];
+      const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)C;
+      float q = 0.f;
+      if (act_lane) { const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean; q = (a * a + b * b) + (c * c + d * d); }
+      const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
+      if (act_lane) {
+        float y0 = (v.x - mean) * rstd * g4.x + b4.x, y1 = (v.y - mean) * rstd * g4.y + b4.y;
+        float y2 = (v.z - mean) * rstd * g4.z + b4.z, y3 = (v.w - mean) * rstd * g4.w + b4.w;
+        if (m >= p.M) y0 = y1 = y2 = y3 = 0.f;
+        const int k = lane * 4, slab = k >> 6, chunk = (k & 63) >> 3;
+        const int off = slab * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + ((lane & 1) << 3);
+        *(uint2*)(sA + off) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+      }
+    }
+  }
+
+  // ---- wave roles ----
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int swz = (lrow >> 1) & 7;
+  // GEMM-1 (transposed): wave -> hidden tile tn (of 2) x row tile tq (of 4)
+  const int tn = wave & 1, tq = wave >> 1;
+  const int g1_a_row = (tn * 32 + lrow) * 128;     // W1 chunk row (hidden unit) inside a slab
+  const int g1_b_row = (tq * 32 + lrow) * 128;     // A tile row (token) inside a slab
+  // GEMM-2: wave -> row tile wm (of 4) x column half wn (of 2)
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g2_a_row = (wm * 32 + lrow) * 128;     // H row
+  const int g2_b_row = (wn * (C / 2) + lrow) * 128;   // W2 chunk row (output channel)
+
+  const uint32_t h_lds = (uint32_t)(uintptr_t)sH;       // LDS byte address of the H tile (low half of the flat address)
+  const uint32_t b1_lds = (uint32_t)(uintptr_t)sB1;
+  f32x16 acc2[TN2];
+#pragma unroll
+  for (int t = 0; t < TN2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+
+  // ---- this wave's GEMM-1 B operand (its 32 token rows, all of K) lives in registers for the whole kernel ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                        // A tile written by all waves; chunk-0 weights landed
+  bf16x8 areg[KS * 4];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) areg[s * 4 + kk] = *(const bf16x8*)(sA + s * (BM * 128) + g1_b_row + (((kk * 2 + lhalf) ^ swz) * 16));
+  __syncthreads();                                        // A-tile region is now free: it becomes weight-buffer set 1
+
+  for (int j = 0; j < NJ; ++j) {
+    const int cur = j & 1;
+    if (j + 1 < NJ && !(p.dbg & 1)) issue_w(j + 1, cur ^ 1);              // a whole chunk of MFMA work ahead of its first use
+    const char* cW1 = w1buf(cur);
+    const char* cW2 = w2buf(cur);
+    // ---- GEMM-1: H_j^T = W1_j * A^T ----
+    f32x16 acc1, acc1b;                                  // two accumulators: no back-to-back dependent MFMA chain
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
+    if (!(p.dbg & 2))
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
+        const bf16x8 a = *(const bf16x8*)(cW1 + s * 8192 + g1_a_row + pos);
+        if (kk & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, areg[s * 4 + kk], acc1b, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, areg[s * 4 + kk], acc1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
+    // lane: token row tq*32 + lrow, hidden units tn*32 + 8g + 4*lhalf + (0..3) for g = 0..3
+    if (!(p.dbg & 4)) {
+      const int hrow = tq * 32 + lrow;
+      const int hswz = (hrow >> 1) & 7;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = tn * 32 + 8 * g + 4 * lhalf;          // hidden unit inside the chunk (multiple of 4)
+        f32x4 bb;   // opaque LDS read (+ its wait) for the same reason as the H store below
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bb) : "v"(b1_lds + (uint32_t)((j * HC + nl) * 4)) : "memory");
+        const float h0 = act_apply(acc1[4 * g] + bb[0], ACT), h1 = act_apply(acc1[4 * g + 1] + bb[1], ACT);
+        const float h2 = act_apply(acc1[4 * g + 2] + bb[2], ACT), h3 = act_apply(acc1[4 * g + 3] + bb[3], ACT);
+        const int off = hrow * 128 + (((nl >> 3) ^ hswz) << 4) + ((nl & 7) << 1);
+        // Written with an opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell
+        // that H and the DMA destinations are disjoint LDS regions), which would serialise the prefetch every chunk.
+        const uint64_t pk = (uint64_t)(pack_bf16x2(h0, h1)) | ((uint64_t)(pack_bf16x2(h2, h3)) << 32);
+        asm volatile("ds_write_b64 %0, %1" ::"v"(h_lds + (uint32_t)off), "v"(pk) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // H_j visible to every wave (the weight DMA stays in flight)
+    // ---- GEMM-2: acc2 += H_j * W2_j^T ----
+    if (!(p.dbg & 8))
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
+      const bf16x8 a = *(const bf16x8*)(sH + g2_a_row + pos);
+#pragma unroll
+      for (int t = 0; t < TN2; ++t) {
+        const bf16x8 b = *(const bf16x8*)(cW2 + g2_b_row + t * 32 * 128 + pos);
+        acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[t], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk j+1 weights (issued before GEMM-1 of this chunk) landed
+    __builtin_amdgcn_s_barrier();                         // everyone is done with H_j and weight set `cur`
+  }
+
+  // ---- epilogue: acc2 -> per-wave LDS slab [32][C/2] fp32 -> + b2 + x -> out ----
+  constexpr int WN = C / 2;
+  __syncthreads();
+  float* sC = (float*)smem + wave * (32 * WN);
+#pragma unroll
+  for (int t = 0; t < TN2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + t * 32 + lrow] = acc2[t][r];
+  __syncthreads();
+  constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 32 at C = 256
+  constexpr int RPP = 64 / LPR;
+  const int c0 = (lane % LPR) * 4;
+  const int n = wn * WN + c0;
+  const float4 bias = *(const float4*)(p.b2 + n);
+  constexpr int NPASS = 32 / RPP;
+#pragma unroll
+  for (int p0 = 0; p0 < NPASS; p0 += 4) {          // 4 residual loads in flight per lane
+    float4 xr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + wm * 32 + (p0 + u) * RPP + lane / LPR;
+      xr[u] = make_float4(0, 0, 0, 0);
+      if (p0 + u < NPASS && m < p.M) xr[u] = *(const float4*)(p.x + (int64_t)m * C + n);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = (p0 + u) * RPP + lane / LPR;
+      const int m = m0 + wm * 32 + row;
+      if (p0 + u >= NPASS || m >= p.M) continue;
+      const float4 a4 = *(const float4*)(sC + row * WN + c0);
+      *(float4*)(p.out + (int64_t)m * C + n) =
+          make_float4(a4.x + bias.x + xr[u].x, a4.y + bias.y + xr[u].y, a4.z + bias.z + xr[u].z, a4.w + bias.w + xr[u].w);
+    }
+  }
+#endif
+}
+
+template <int C, int ACT>
+static int launch_ffn(const pd_ffn_args_k& a, hipStream_t s) {
+  const int lds = 128 * C * 2 + 128 * 64 * 2 + 64 * C * 2 + C * 64 * 2 + a.Hd * 4;
+  constexpr int epi = 8 * 32 * (C / 2) * 4;
+  const int bytes = lds > epi ? lds : epi;
+  static int attr_set = 0;
+  if (attr_set < bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<C, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      pd_set_error("pd_ffn_fused: hipFuncSetAttribute(%d) failed: %s", bytes, hipGetErrorString(e));
+      return PD_ERR_LAUNCH;
+    }
+    attr_set = bytes;
+  }
+  hipLaunchKernelGGL((ffn_fused_kernel<C, ACT>), dim3((a.M + 127) / 128), dim3(512), bytes, s, a);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+extern "C" int pd_ffn_debug_flags = 0;   // profiling ablations only (scripts/bench_ffn.py)
+
+extern "C" int pd_ffn_fused_supported(int C, int Hd) {
+  return (C == 64 || C == 128 || C == 256) && Hd > 0 && Hd % 64 == 0 && Hd <= 3072;   // LDS: 144 KB tiles + 4*Hd bytes of bias
+}
+
+extern "C" int pd_ffn_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* W1, const float* b1,
+                            const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, pd_stream_t stream) {
+  PD_CHECK_ARG(x && out && gamma && beta && W1 && b1 && W2 && b2, "pd_ffn_fused: null pointer");
+  PD_CHECK_ARG(pd_ffn_fused_supported(C, Hd), "pd_ffn_fused: unsupported units=%d hidden=%d (units in {64,128,256}, hidden %% 64 == 0)", C, Hd);
+  PD_CHECK_ARG(M > 0 && M < (1ll << 31), "pd_ffn_fused: bad M");
+  pd_ffn_args_k a;
+  a.x = x; a.out = out; a.gamma = gamma; a.beta = beta; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
+  a.M = (int)M; a.Hd = Hd; a.act = act; a.eps = eps;
+  a.w1_bytes = (uint32_t)((int64_t)Hd * C * 2);
+  a.w2_bytes = (uint32_t)((int64_t)C * Hd * 2);
+  a.dbg = pd_ffn_debug_flags;
+  hipStream_t s = (hipStream_t)stream;
+#define PD_FFN(ACT)                                  \
+  if (C == 256) return launch_ffn<256, ACT>(a, s);   \
+  if (C == 128) return launch_ffn<128, ACT>(a, s);   \
+  return launch_ffn<64, ACT>(a, s);
+  switch (act) {
+    case PD_ACT_GELU: PD_FFN(PD_ACT_GELU)
+    case PD_ACT_LEAKY: PD_FFN(PD_ACT_LEAKY)
+    case PD_ACT_RELU: PD_FFN(PD_ACT_RELU)
+    case PD_ACT_SILU: PD_FFN(PD_ACT_SILU)
+    case PD_ACT_NONE: PD_FFN(PD_ACT_NONE)
+    default: pd_set_error("pd_ffn_fused: unknown activation %d", act); return PD_ERR_ARG;
+  }
+#undef PD_FFN
+}

@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
               hi[e] = h0 | ((uint32_t)h1 << 16);
               lo[e] = l0 | ((uint32_t)l1 << 16);
             } else {
-              hi[e] = f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+              hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
             }
           }
           if constexpr (CW == 8) {

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         *(uint2*)(out_lo + row * (int64_t)ld_out + c) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
       } else {
         *(uint2*)(out + row * (int64_t)ld_out + c) =
-            make_uint2(f2bf(y[0]) | ((uint32_t)f2bf(y[1]) << 16), f2bf(y[2]) | ((uint32_t)f2bf(y[3]) << 16));
+            make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
       }
     }
   }
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restri
       ob[(int64_t)r * CV] = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
       obl[(int64_t)r * CV] = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
     } else {
-      ob[(int64_t)r * CV] = make_uint2(f2bf(y[0]) | ((uint32_t)f2bf(y[1]) << 16), f2bf(y[2]) | ((uint32_t)f2bf(y[3]) << 16));
+      ob[(int64_t)r * CV] = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
     }
   }
 }

@@ -330,6 +330,7 @@ class CuboidTransformerUNet(nn.Module):
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' (throughput) or 'fp32' (hi/lo split, fp32-class accuracy)")
         self.precision = precision
+        self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)
         self.depth = list(depth)
@@ -665,6 +666,11 @@ class CuboidTransformerUNet(nn.Module):
         ld = pad64(C)
         Hd = ff.ffn_1.out_features
         ldh = pad64(Hd)
+        if self.precision == "bf16" and self.fuse_ffn and not ff.gated and L.ffn_fused_supported(C, Hd):
+            # one launch, hidden activations never leave the CU (csrc/ffn.hip)
+            L.ffn_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".fc1.w"][0], P[name + ".fc1.b"], P[name + ".fc2.w"][0],
+                        P[name + ".fc2.b"], B * S, C, Hd, act=ff.activation_name)
+            return
         a, alo = self._bf("ln.a", B * S, ld, dev)
         L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld)
         h, hlo = self._bf("ffn.h", B * S, ldh, dev)

@@ -1,0 +1,23 @@
+import math, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from prediff_amd import _lib as L
+from prediff_amd.packing import pack_linear
+import ctypes
+dbg = ctypes.c_int.in_dll(L.lib(), "pd_ffn_debug_flags")
+dbg.value = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+for B in (16,):
+    M, C, Hd = B * 3328, 256, 1024
+    x = torch.randn(M, C, device="cuda")
+    g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    w1, _ = pack_linear(torch.randn(Hd, C, device="cuda") / 16, False)
+    w2, _ = pack_linear(torch.randn(C, Hd, device="cuda") / 32, False)
+    b1, b2 = torch.zeros(Hd, device="cuda"), torch.zeros(C, device="cuda")
+    out = torch.empty_like(x)
+    for _ in range(3): L.ffn_fused(x, out, g, b, w1, b1, w2, b2, M, C, Hd)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): L.ffn_fused(x, out, g, b, w1, b1, w2, b2, M, C, Hd)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print(f"[dbg {dbg.value}] ffn_fused L0 B={B}: {us:.1f} us  {4.0 * M * C * Hd / us / 1e6:.1f} TFLOP/s")

@@ -356,3 +356,30 @@ def test_diffusion_steps():
     c = torch.stack([a_t, a_prev, sig], 1).contiguous().to(DEV)
     L.ddim_step(zt.to(DEV), eps.to(DEV), noise.to(DEV), c, out, B, per)
     assert rel_l2(out, OD.ddim_step(zt, eps, a_t, a_prev, sig, noise)) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ fused FFN
+@pytest.mark.parametrize("M,Cn,act", [(256, 64, "gelu"), (1000, 128, "leaky"), (3328, 256, "gelu"), (130, 256, "gelu"), (53248, 256, "gelu")])
+def test_ffn_fused(M, Cn, act):
+    g = torch.Generator(device="cpu").manual_seed(M + Cn)
+    Hd = 4 * Cn
+    x = (torch.randn(M, Cn, generator=g) * 2 + 0.3 + torch.arange(M)[:, None] * 1e-4).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(Cn, generator=g)).to(DEV), (0.1 * torch.randn(Cn, generator=g)).to(DEV)
+    w1 = (torch.randn(Hd, Cn, generator=g) / math.sqrt(Cn)).to(DEV)
+    w2 = (torch.randn(Cn, Hd, generator=g) / math.sqrt(Hd)).to(DEV)
+    b1, b2 = torch.randn(Hd, generator=g).to(DEV) * 0.1, torch.randn(Cn, generator=g).to(DEV) * 0.1
+    w1p, _ = pack_linear(w1, False)
+    w2p, _ = pack_linear(w2, False)
+    assert L.ffn_fused_supported(Cn, Hd) and not L.ffn_fused_supported(512, 2048)
+    out = torch.empty_like(x)
+    L.ffn_fused(x, out, gamma, beta, w1p, b1, w2p, b2, M, Cn, Hd, act=act)
+    actf = F.gelu if act == "gelu" else (lambda v: F.leaky_relu(v, 0.1))
+    # same roundings as the kernel: bf16 LN output, bf16 weights, bf16 hidden, fp32 accumulation
+    h = bf(actf(bf(F.layer_norm(x, (Cn,), gamma, beta, 1e-5)) @ bf(w1).t() + b1))
+    ref = x + h @ bf(w2).t() + b2
+    assert rel_l2(out, ref) < 2e-4          # differs only by bf16 rounding boundaries of LN / hidden values and summation order
+    full = x + actf(F.layer_norm(x, (Cn,), gamma, beta, 1e-5) @ w1.t() + b1) @ w2.t() + b2
+    assert rel_l2(out, full) < 6e-3         # vs the un-rounded fp32 statement (bf16 engine tolerance)
+    xin = x.clone()
+    L.ffn_fused(xin, xin, gamma, beta, w1p, b1, w2p, b2, M, Cn, Hd, act=act)      # in place
+    assert torch.equal(xin, out)
