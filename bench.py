@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-ffn", action="store_true")
+    ap.add_argument("--no-tile256", action="store_true", help="A/B: keep pd_igemm on the 128x128 kernel for the long-K launches")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,6 +143,9 @@ def main():
     from prediff_amd import _lib as L
     from prediff_amd.schedule import make_ddim_sampling_parameters, make_ddim_timesteps
     B = args.batch
+    if args.no_tile256:
+        import ctypes
+        ctypes.c_int.in_dll(L.lib(), "pd_igemm_disable_256").value = 1
     ldm = v1_model(args.precision, device)
     ldm.torch_nn_module.fuse_ffn = not args.no_fused_ffn
     shape = ldm.get_batch_latent_shape(B)

@@ -19,6 +19,7 @@
 //     accuracy (~2^-16 relative per product) at 1/3 of the bf16 MFMA rate instead of 1/16 for the f32 MFMA.
 #include <type_traits>
 #include "common.h"
+#include "igemm_epilogue.h"
 
 __device__ __attribute__((aligned(64))) uint32_t g_pd_zero_page[32];   // 128 B of zeros (never written)
 
@@ -212,117 +213,6 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
   constexpr int WNS = WN / ESLAB;                  // columns staged at a time
   constexpr int TNS = TN / ESLAB;
   float* sC = (float*)smem + wave * (WM * WNS);
-  float* outf = p.out_f32 ? p.out_f32 + (int64_t)bz * p.out_batch_stride : nullptr;
-  pd_bf16* outb = p.out_bf16 ? p.out_bf16 + (int64_t)bz * p.outb_batch_stride : nullptr;
-  pd_bf16* outbl = p.out_bf16_lo ? p.out_bf16_lo + (int64_t)bz * p.outb_batch_stride : nullptr;
-  const float* res = p.residual ? p.residual + (int64_t)bz * p.res_batch_stride : nullptr;
-  // The row loop is instantiated per (columns-per-lane, activation, operand presence) so that the hot call sites get
-  // straight-line code; tag value 2 = "decide at run time" (generic instantiation).
-  //   CW columns per lane: 8 when only bf16 is stored (16 B stores: the 8 B/lane form is store-issue bound), else 4.
-  int slab = 0;
-  auto run_epilogue = [&](auto cw_tag, auto act_tag, auto rv_tag, auto mu_tag, auto rs_tag, auto of_tag, auto ob_tag, auto ol_tag) {
-    constexpr int CW = decltype(cw_tag)::value;
-    constexpr int ACT = decltype(act_tag)::value;          // -1 = run time
-    auto on = [](auto tag, bool rt) { constexpr int T = decltype(tag)::value; return T == 2 ? rt : (T == 1); };
-    constexpr int LPR = WNS / CW;                    // lanes per row
-    constexpr int RPP = 64 / LPR;                    // rows per pass
-    const int c0 = (lane % LPR) * CW;
-    const int n = n0 + wc * WN + slab * WNS + c0;
-    const bool vec = p.vec_epilogue && (n + CW - 1 < p.N);
-    const bool has_rv = on(rv_tag, p.rowvec != nullptr), has_mu = on(mu_tag, p.mul != nullptr), has_rs = on(rs_tag, res != nullptr);
-    const bool has_of = on(of_tag, outf != nullptr), has_ob = on(ob_tag, outb != nullptr), has_ol = on(ol_tag, outbl != nullptr);
-    const int act = ACT >= 0 ? ACT : ((p.debug_flags & 4) ? 0 : p.act);
-    float bias_v[CW];
-#pragma unroll
-    for (int e = 0; e < CW; ++e) bias_v[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
-    if (n >= p.N || (p.debug_flags & 2)) return;
-#pragma unroll 1
-    for (int pass = 0; pass < WM / RPP; ++pass) {
-      const int row = pass * RPP + lane / LPR;
-      const int m = m0 + wr * WM + row;
-      if (m >= p.M) continue;
-      float v[CW];
-#pragma unroll
-      for (int q = 0; q < CW / 4; ++q) {
-        const float4 a4 = *(const float4*)(sC + row * WNS + c0 + 4 * q);
-        v[4 * q] = a4.x; v[4 * q + 1] = a4.y; v[4 * q + 2] = a4.z; v[4 * q + 3] = a4.w;
-      }
-      const float* rv = has_rv ? p.rowvec + (int64_t)(m / p.rows_per_sample) * p.ld_rowvec + n : nullptr;
-      const float* mu = has_mu ? p.mul + (int64_t)m * p.ld_mul + n : nullptr;
-      const float* rs = has_rs ? res + (int64_t)(p.res_period ? m % p.res_period : m) * p.ld_res + n : nullptr;
-      if (vec) {
-#pragma unroll
-        for (int e = 0; e < CW; ++e) v[e] = v[e] * p.alpha + bias_v[e];
-        if (has_rv) {
-#pragma unroll
-          for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(rv + 4 * q); v[4 * q] += t4.x; v[4 * q + 1] += t4.y; v[4 * q + 2] += t4.z; v[4 * q + 3] += t4.w; }
-        }
-        if (act != 0) {
-#pragma unroll
-          for (int e = 0; e < CW; ++e) v[e] = act_apply(v[e], act);
-        }
-        if (has_mu) {
-#pragma unroll
-          for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(mu + 4 * q); v[4 * q] *= t4.x; v[4 * q + 1] *= t4.y; v[4 * q + 2] *= t4.z; v[4 * q + 3] *= t4.w; }
-        }
-        if (has_rs) {
-#pragma unroll
-          for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(rs + 4 * q); v[4 * q] += t4.x; v[4 * q + 1] += t4.y; v[4 * q + 2] += t4.z; v[4 * q + 3] += t4.w; }
-        }
-        if (has_of) {
-#pragma unroll
-          for (int q = 0; q < CW / 4; ++q)
-            *(float4*)(outf + (int64_t)m * p.ld_out + n + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        }
-        if (has_ob) {
-          uint32_t hi[CW / 2], lo[CW / 2];
-#pragma unroll
-          for (int e = 0; e < CW / 2; ++e) {
-            if (has_ol) {
-              uint16_t h0, l0, h1, l1;
-              f2bf_split(v[2 * e], h0, l0);
-              f2bf_split(v[2 * e + 1], h1, l1);
-              hi[e] = h0 | ((uint32_t)h1 << 16);
-              lo[e] = l0 | ((uint32_t)l1 << 16);
-            } else {
-              hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-            }
-          }
-          if constexpr (CW == 8) {
-            *(uint4*)(outb + (int64_t)m * p.ld_outb + n) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            if (has_ol) *(uint4*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-          } else {
-            *(uint2*)(outb + (int64_t)m * p.ld_outb + n) = make_uint2(hi[0], hi[1]);
-            if (has_ol) *(uint2*)(outbl + (int64_t)m * p.ld_outb + n) = make_uint2(lo[0], lo[1]);
-          }
-        }
-      } else {
-        for (int e = 0; e < CW; ++e) {
-          if (n + e >= p.N) break;
-          float x = v[e] * p.alpha + bias_v[e];
-          if (rv) x += rv[e];
-          x = act_apply(x, act);
-          if (mu) x *= mu[e];
-          if (rs) x += rs[e];
-          if (has_of) outf[(int64_t)m * p.ld_out + n + e] = x;
-          if (has_ob) {
-            uint16_t h, l;
-            f2bf_split(x, h, l);
-            outb[(int64_t)m * p.ld_outb + n + e] = h;
-            if (has_ol) outbl[(int64_t)m * p.ld_outb + n + e] = l;
-          }
-        }
-      }
-    }
-  };
-  using I4 = std::integral_constant<int, 4>;
-  using I8 = std::integral_constant<int, 8>;
-  using F_ = std::integral_constant<int, 0>;
-  using T_ = std::integral_constant<int, 1>;
-  using R_ = std::integral_constant<int, 2>;
-  using AN = std::integral_constant<int, 0>;
-  using AG = std::integral_constant<int, PD_ACT_GELU>;
-  using AR = std::integral_constant<int, -1>;
 #pragma unroll
   for (int js = 0; js < ESLAB; ++js) {
     __syncthreads();                               // operand stages (js == 0) / previous slab (js > 0) are no longer read
@@ -334,25 +224,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
         for (int r = 0; r < 16; ++r)
           sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * WNS + j * 32 + lrow] = acc[i][js * TNS + j][r];
     __syncthreads();
-    slab = js;
-  {
-      const bool rvp = p.rowvec != nullptr, mup = p.mul != nullptr, rsp = res != nullptr, ofp = outf != nullptr, obp = outb != nullptr,
-                 olp = outbl != nullptr;
-      const int actv = (p.debug_flags & 4) ? 0 : p.act;
-      if (p.vec_epilogue == 2 && !rvp && !mup && !rsp && !ofp && obp && !olp && (actv == 0 || actv == PD_ACT_GELU)) {
-        // bf16-only producers: QKV (no activation), FFN-1 (GELU)
-        if (actv == 0) run_epilogue(I8{}, AN{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{});
-        else run_epilogue(I8{}, AG{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{});
-      } else if (p.vec_epilogue && ofp && !obp && !mup && actv == 0 && (rsp != rvp)) {
-        // fp32 residual-stream writers: proj / FFN-2 / conv-2 (+residual), conv-1 (+timestep embedding)
-        if (rsp) run_epilogue(I4{}, AN{}, F_{}, F_{}, T_{}, T_{}, F_{}, F_{});
-        else run_epilogue(I4{}, AN{}, T_{}, F_{}, F_{}, T_{}, F_{}, F_{});
-      } else if (p.vec_epilogue == 2) {
-        run_epilogue(I8{}, AR{}, R_{}, R_{}, R_{}, R_{}, R_{}, R_{});
-      } else {
-        run_epilogue(I4{}, AR{}, R_{}, R_{}, R_{}, R_{}, R_{}, R_{});
-      }
-    }
+    igemm_epilogue<WM, WNS>(p, sC, lane, m0 + wr * WM, p.M, n0 + wc * WN + js * WNS, bz);
   }
 #endif
 }
@@ -394,7 +266,12 @@ static int dispatch_igemm(const pd_igemm_args& a, int tile, hipStream_t s) {
   }
 }
 
+// igemm256.hip: 256 x 256 x 64 eight-wave ping-pong variant for long-K launches
+bool pd_igemm256_supported(const pd_igemm_args& a, int kind);
+int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s);
+
 extern "C" int pd_igemm_default_tile = 0;   // bench / tuning override of the auto choice (0 = built-in heuristic)
+extern "C" int pd_igemm_disable_256 = 0;    // bench A/B switch: keep the auto choice away from the 256 x 256 kernel
 
 extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(pa != nullptr, "pd_igemm: null args");
@@ -435,8 +312,19 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     // measured on MI355X (scripts/bench_igemm.py): with <= 4 K-steps the 4-workgroups/CU variant (BK 32, 32 KB LDS) hides the
     // prologue/epilogue of its neighbours best; longer K prefers the BK 64 two-stage tile.
     tile = t128 >= 192 ? ((!a.split && (int64_t)a.taps * a.Cin <= 256) ? 5 : PD_BIG_TILE_DEFAULT) : 2;
+    // long K: the 256 x 256 eight-wave kernel does a round of 256 tiles (one per CU of the MI355X) in ~1.75x the time the
+    // 128 x 128 kernel needs for a round of 512 (two per CU) -- 4x the work; take it when its whole rounds are the cheaper ones
+    if (tile == PD_BIG_TILE_DEFAULT && !pd_igemm_disable_256 && !a.split && (int64_t)a.taps * a.Cin >= 1024 && pd_igemm256_supported(a, kind)) {
+      const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.nbatch > 0 ? a.nbatch : 1);
+      const int64_t r128 = (t128 + 511) / 512, r256 = (t256 + 255) / 256;
+      if (r256 * 7 <= r128 * 4) tile = 7;
+    }
   }
   if (a.split && tile == 4) tile = 1;   // 3 x 64 KB stages do not fit
+  if (tile == 7) {
+    if (pd_igemm256_supported(a, kind)) return pd_igemm256_launch(a, kind, s);
+    tile = PD_BIG_TILE_DEFAULT;
+  }
   if (a.split) {
     if (kind == 0) return dispatch_igemm<true, 0>(a, tile, s);
     if (kind == 1) return dispatch_igemm<true, 1>(a, tile, s);

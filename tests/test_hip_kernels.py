@@ -39,7 +39,9 @@ def padded_bf16(x2d, split=False):
                                         (1000, 200, 96, 2), (37, 5, 32, 2), (832, 2048, 512, 0), (128, 64, 1024, 2),
                                         (3328, 768, 256, 3), (3328, 768, 256, 4), (1000, 200, 96, 3), (1000, 200, 96, 4), (300, 130, 64, 3),
                                         (300, 130, 64, 4), (512, 256, 2048, 3), (512, 256, 2048, 4),
-                                        (3328, 768, 256, 5), (1000, 200, 96, 5), (300, 130, 64, 6), (512, 256, 2048, 6), (3328, 768, 256, 6)])
+                                        (3328, 768, 256, 5), (1000, 200, 96, 5), (300, 130, 64, 6), (512, 256, 2048, 6), (3328, 768, 256, 6),
+                                        (3328, 768, 256, 7), (1000, 200, 96, 7), (300, 130, 64, 7), (512, 256, 2048, 7), (37, 5, 32, 7),
+                                        (2048, 512, 192, 7), (106496, 256, 128, 7), (26624, 512, 64, 7), (9000, 300, 64, 7)])
 @pytest.mark.parametrize("split", [False, True])
 def test_igemm_linear(M, N, K, tile, split):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
@@ -99,7 +101,7 @@ def test_igemm_batched():
 # ------------------------------------------------------------------------------------------------ igemm: convolutions
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 5, 8, 8, 64, 64), (1, 13, 16, 16, 256, 256), (2, 3, 6, 6, 5, 32), (1, 13, 8, 8, 512, 512)])
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("tile", [0, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 3, 4, 5, 6, 7])
 def test_igemm_conv3d(B, T, H, W, Cin, Cout, split, tile):
     g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
     x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
@@ -119,8 +121,9 @@ def test_igemm_conv3d(B, T, H, W, Cin, Cout, split, tile):
     assert rel_l2(out, ref) < (3e-5 if split else 3e-6)
 
 
+@pytest.mark.parametrize("tile", [0, 7])
 @pytest.mark.parametrize("mode", ["same", "up2", "down2"])
-def test_igemm_conv2d(mode):
+def test_igemm_conv2d(mode, tile):
     N_, H, W, Cin, Cout = 3, 8, 8, 64, 96
     g = torch.Generator(device="cpu").manual_seed(11)
     x = torch.randn(N_, H, W, Cin, generator=g).to(DEV)
@@ -140,7 +143,7 @@ def test_igemm_conv2d(mode):
         ref = F.conv2d(F.pad(xc, (0, 1, 0, 1)), bf(w), bias, stride=2)
     M = N_ * geom["Ho"] * geom["Wo"]
     out = torch.empty(M, Cout, device=DEV)
-    L.igemm(a_hi, w_hi, M=M, N=Cout, Cin=64, taps=9, w_tap_stride=Cout * 64, geom=geom, bias=bias, out_f32=out)
+    L.igemm(a_hi, w_hi, M=M, N=Cout, Cin=64, taps=9, w_tap_stride=Cout * 64, geom=geom, bias=bias, out_f32=out, tile=tile)
     assert rel_l2(out, ref.permute(0, 2, 3, 1).reshape(M, Cout)) < 3e-6
 
 
