@@ -9,13 +9,15 @@
 // One workgroup = 512 threads (8 waves) owns BM = 128 token rows:
 //   phase 0   LayerNorm of the 128 rows (one wave per 16 rows, fp32, two-pass) -> bf16 A tile in LDS, K-slab swizzled exactly
 //             like the igemm operand tiles (conflict-free ds_read_b128).
-//   chunk j   (64 hidden units at a time, Hd/64 chunks)
-//       GEMM-1  H_j^T[64 x 128] = W1_j[64 x C] * A^T           one 32x32 MFMA tile per wave, K = C
-//               +b1, activation, bf16: the transposed product leaves 4 consecutive hidden units per lane -> 8 B LDS writes
-//               straight into the A-operand layout GEMM-2 reads.
-//       GEMM-2  acc[128 x C] += H_j[128 x 64] * W2_j[C x 64]^T  wave tile 32 x C/2, K = 64
-//     W1_j and W2_j stream through two single LDS buffers by buffer-descriptor DMA (16 B/lane): W2_j is in flight during
-//     GEMM-1 of chunk j, W1_{j+1} during GEMM-2 of chunk j; two barriers and 16+16 MFMAs per wave per chunk (C = 256).
+//   chunk j   (64 hidden units at a time, Hd/64 chunks), per GROUP of 4 waves = 64 of the 128 rows:
+//       MFMA slot  GEMM-2 of chunk j-1: acc[64 x C] += H_{j-1}[64 x 64] * W2_{j-1}[C x 64]^T   (wave tile 32 x C/2, K = 64)
+//                  GEMM-1 of chunk j:   H_j^T[64 x 64] = W1_j[64 x C] * A^T                     (one 32x32 tile per wave, K = C)
+//       VALU slot  +b1, activation, bf16: the transposed product leaves 4 consecutive hidden units per lane -> 8 B LDS writes
+//                  straight into the A-operand layout GEMM-2 reads.
+//     The two groups run one slot apart (one workgroup barrier per slot): each SIMD holds one wave of each group, so its MFMA
+//     pipe works on one group's GEMMs while its VALU evaluates the other group's activation (erf GELU costs more issue cycles
+//     than the chunk's 32 MFMAs; serialised it was the largest term of the kernel).
+//     W1_j and W2_j stream through two buffer sets by buffer-descriptor DMA (16 B/lane), issued two slots before first use.
 //   epilogue  acc + b2 + x -> out (fp32), staged through LDS for 16 B row segments.
 // LDS: A 128*C*2 + H 16 KB + W1 64*C*2 + W2 C*128  = 144 KB at C = 256 (one workgroup per CU, two waves per SIMD).
 #include "common.h"
@@ -77,17 +79,19 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
   // holds its A fragments in registers
   auto w1buf = [&](int b) { return b ? sA : sW1; };
   auto w2buf = [&](int b) { return b ? sA + W1_BYTES : sW2; };
-  auto issue_w = [&](int j, int b) {
+  auto issue_w1 = [&](int j, int b) {
     char* d1 = w1buf(b);
-    char* d2 = w2buf(b);
 #pragma unroll
     for (int s = 0; s < KS; ++s) BLDS16(rW1, d1 + s * 8192 + wave * 1024, w1_voff, (j * HC * C + s * 64) * 2);
+  };
+  auto issue_w2 = [&](int j, int b) {
+    char* d2 = w2buf(b);
 #pragma unroll
     for (int i = 0; i < KS; ++i) BLDS16(rW2, d2 + i * 8192 + wave * 1024, w2_voff[i], j * HC * 2);
   };
 
   for (int i = tid; i < p.Hd; i += 512) sB1[i] = p.b1[i];
-  issue_w(0, 0);
+  issue_w1(0, 0);
 
   // ---- phase 0: LayerNorm -> bf16 A tile (KS slabs of [128][64], chunk swizzle (row>>1)&7) ----
   {
@@ -122,19 +126,21 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
     }
   }
 
-  // ---- wave roles ----
+  // ---- wave roles: two groups of 4 waves (one wave of each group per SIMD), each owns 64 of the 128 token rows ----
+  const int grp = wave >> 2, wg = wave & 3;
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int swz = (lrow >> 1) & 7;
-  // GEMM-1 (transposed): wave -> hidden tile tn (of 2) x row tile tq (of 4)
-  const int tn = wave & 1, tq = wave >> 1;
-  const int g1_a_row = (tn * 32 + lrow) * 128;     // W1 chunk row (hidden unit) inside a slab
-  const int g1_b_row = (tq * 32 + lrow) * 128;     // A tile row (token) inside a slab
-  // GEMM-2: wave -> row tile wm (of 4) x column half wn (of 2)
-  const int wm = wave >> 1, wn = wave & 1;
-  const int g2_a_row = (wm * 32 + lrow) * 128;     // H row
-  const int g2_b_row = (wn * (C / 2) + lrow) * 128;   // W2 chunk row (output channel)
+  // GEMM-1 (transposed): wave -> hidden tile tn (of 2) x row tile tq (of the group's 2)
+  const int tn = wg & 1, tq = wg >> 1;
+  const int g1_a_row = (tn * 32 + lrow) * 128;                 // W1 chunk row (hidden unit) inside a slab
+  const int g1_b_row = (grp * 64 + tq * 32 + lrow) * 128;      // A tile row (token) inside a slab
+  // GEMM-2: wave -> row tile wm (of the group's 2) x column half wn (of 2)
+  const int wm = wg >> 1, wn = wg & 1;
+  char* const sHg = sH + grp * (64 * 128);                     // the group's own H tile [64 rows][64 hidden]
+  const int g2_a_row = (wm * 32 + lrow) * 128;                 // H row
+  const int g2_b_row = (wn * (C / 2) + lrow) * 128;            // W2 chunk row (output channel)
 
-  const uint32_t h_lds = (uint32_t)(uintptr_t)sH;       // LDS byte address of the H tile (low half of the flat address)
+  const uint32_t h_lds = (uint32_t)(uintptr_t)sHg;             // LDS byte address of the H tile (low half of the flat address)
   const uint32_t b1_lds = (uint32_t)(uintptr_t)sB1;
   f32x16 acc2[TN2];
 #pragma unroll
@@ -144,7 +150,7 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
 
   // ---- this wave's GEMM-1 B operand (its 32 token rows, all of K) lives in registers for the whole kernel ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                        // A tile written by all waves; chunk-0 weights landed
+  __syncthreads();                                        // A tile written by all waves; W1 of chunk 0 landed
   bf16x8 areg[KS * 4];
 #pragma unroll
   for (int s = 0; s < KS; ++s)
@@ -152,30 +158,55 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
     for (int kk = 0; kk < 4; ++kk) areg[s * 4 + kk] = *(const bf16x8*)(sA + s * (BM * 128) + g1_b_row + (((kk * 2 + lhalf) ^ swz) * 16));
   __syncthreads();                                        // A-tile region is now free: it becomes weight-buffer set 1
 
-  for (int j = 0; j < NJ; ++j) {
-    const int cur = j & 1;
-    if (j + 1 < NJ && !(p.dbg & 1)) issue_w(j + 1, cur ^ 1);              // a whole chunk of MFMA work ahead of its first use
-    const char* cW1 = w1buf(cur);
-    const char* cW2 = w2buf(cur);
-    // ---- GEMM-1: H_j^T = W1_j * A^T ----
-    f32x16 acc1, acc1b;                                  // two accumulators: no back-to-back dependent MFMA chain
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
-    if (!(p.dbg & 2))
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-        const bf16x8 a = *(const bf16x8*)(cW1 + s * 8192 + g1_a_row + pos);
-        if (kk & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, areg[s * 4 + kk], acc1b, 0, 0, 0);
-        else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, areg[s * 4 + kk], acc1, 0, 0, 0);
-      }
+  // ---- slot loop.  A chunk j of a group is: MFMA slot [GEMM-2 of chunk j-1, GEMM-1 of chunk j] then VALU slot [bias,
+  //      activation, bf16 -> H].  Group 1 runs ONE slot behind group 0, so on every SIMD one wave is in its MFMA slot while the
+  //      other is in its VALU slot: the activation (17 VALU + 2 transcendental ops per hidden value: more issue cycles than the
+  //      chunk's MFMAs) is hidden instead of serialised.  One workgroup barrier per slot.
+  //      Weights: global slot 2j issues W1_{j+1} and W2_j (both waited for at the end of slot 2j+1);  W1_j is read in slots
+  //      2j (group 0) and 2j+1 (group 1), W2_j in slots 2j+2 and 2j+3; buffer sets alternate with the chunk parity. ----
+  f32x16 acc1, acc1b;                                      // two accumulators: no back-to-back dependent MFMA chain
+  const int nslots = 2 * NJ + 2;
+  for (int s = 0; s < nslots; ++s) {
+    if (!(s & 1) && !(p.dbg & 1)) {
+      const int j = s >> 1;
+      if (j + 1 < NJ) issue_w1(j + 1, (j + 1) & 1);
+      if (j < NJ) issue_w2(j, j & 1);
     }
+    const int sl = s - grp;                                // this group's own slot index
+    const int j = sl >> 1;
+    if (sl >= 0 && !(sl & 1)) {
+      // ---- MFMA slot: GEMM-2 of chunk j-1 (acc2 += H_{j-1} * W2_{j-1}^T), then GEMM-1 of chunk j (H_j^T = W1_j * A^T) ----
+      if (j >= 1 && !(p.dbg & 8)) {
+        const char* cW2 = w2buf((j - 1) & 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
-    // lane: token row tq*32 + lrow, hidden units tn*32 + 8g + 4*lhalf + (0..3) for g = 0..3
-    if (!(p.dbg & 4)) {
+        for (int kk = 0; kk < 4; ++kk) {
+          const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
+          const bf16x8 a = *(const bf16x8*)(sHg + g2_a_row + pos);
+#pragma unroll
+          for (int t = 0; t < TN2; ++t) {
+            const bf16x8 b = *(const bf16x8*)(cW2 + g2_b_row + t * 32 * 128 + pos);
+            acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[t], 0, 0, 0);
+          }
+        }
+      }
+      if (j < NJ) {
+        const char* cW1 = w1buf(j & 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
+        if (!(p.dbg & 2))
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
+            const bf16x8 a = *(const bf16x8*)(cW1 + ks * 8192 + g1_a_row + pos);
+            if (kk & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, areg[ks * 4 + kk], acc1b, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, areg[ks * 4 + kk], acc1, 0, 0, 0);
+          }
+        }
+      }
+    } else if (sl >= 1 && j < NJ && !(p.dbg & 4)) {
+      // ---- VALU slot of chunk j.  lane: token row tq*32 + lrow, hidden units tn*32 + 8g + 4*lhalf + (0..3) for g = 0..3 ----
       const int hrow = tq * 32 + lrow;
       const int hswz = (hrow >> 1) & 7;
 #pragma unroll
@@ -183,8 +214,10 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
         const int nl = tn * 32 + 8 * g + 4 * lhalf;          // hidden unit inside the chunk (multiple of 4)
         f32x4 bb;   // opaque LDS read (+ its wait) for the same reason as the H store below
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bb) : "v"(b1_lds + (uint32_t)((j * HC + nl) * 4)) : "memory");
-        const float h0 = act_apply(acc1[4 * g] + bb[0], ACT), h1 = act_apply(acc1[4 * g + 1] + bb[1], ACT);
-        const float h2 = act_apply(acc1[4 * g + 2] + bb[2], ACT), h3 = act_apply(acc1[4 * g + 3] + bb[3], ACT);
+        // (a cheaper erf -- Abramowitz-Stegun 7.1.25 on packed v_pk_*_f32, 13 VALU + 4 transcendental ops per pair -- measured no
+        //  faster end to end: the slot is bound by LDS fragment traffic and the HBM-bound LN / epilogue phases, not VALU issue)
+        const float h0 = act_apply(acc1[4 * g] + acc1b[4 * g] + bb[0], ACT), h1 = act_apply(acc1[4 * g + 1] + acc1b[4 * g + 1] + bb[1], ACT);
+        const float h2 = act_apply(acc1[4 * g + 2] + acc1b[4 * g + 2] + bb[2], ACT), h3 = act_apply(acc1[4 * g + 3] + acc1b[4 * g + 3] + bb[3], ACT);
         const int off = hrow * 128 + (((nl >> 3) ^ hswz) << 4) + ((nl & 7) << 1);
         // Written with an opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell
         // that H and the DMA destinations are disjoint LDS regions), which would serialise the prefetch every chunk.
@@ -192,22 +225,9 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
         asm volatile("ds_write_b64 %0, %1" ::"v"(h_lds + (uint32_t)off), "v"(pk) : "memory");
       }
     }
+    if (s & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights issued in slot s-1 (first read in slot s+1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // H_j visible to every wave (the weight DMA stays in flight)
-    // ---- GEMM-2: acc2 += H_j * W2_j^T ----
-    if (!(p.dbg & 8))
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-      const bf16x8 a = *(const bf16x8*)(sH + g2_a_row + pos);
-#pragma unroll
-      for (int t = 0; t < TN2; ++t) {
-        const bf16x8 b = *(const bf16x8*)(cW2 + g2_b_row + t * 32 * 128 + pos);
-        acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[t], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk j+1 weights (issued before GEMM-1 of this chunk) landed
-    __builtin_amdgcn_s_barrier();                         // everyone is done with H_j and weight set `cur`
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- epilogue: acc2 -> per-wave LDS slab [32][C/2] fp32 -> + b2 + x -> out ----
@@ -230,14 +250,14 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
     float4 xr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int m = m0 + wm * 32 + (p0 + u) * RPP + lane / LPR;
+      const int m = m0 + (grp * 2 + wm) * 32 + (p0 + u) * RPP + lane / LPR;
       xr[u] = make_float4(0, 0, 0, 0);
       if (p0 + u < NPASS && m < p.M) xr[u] = *(const float4*)(p.x + (int64_t)m * C + n);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = (p0 + u) * RPP + lane / LPR;
-      const int m = m0 + wm * 32 + row;
+      const int m = m0 + (grp * 2 + wm) * 32 + row;
       if (p0 + u >= NPASS || m >= p.M) continue;
       const float4 a4 = *(const float4*)(sC + row * WN + c0);
       *(float4*)(p.out + (int64_t)m * C + n) =

@@ -5,7 +5,7 @@ from prediff_amd.packing import pack_linear
 import ctypes
 dbg = ctypes.c_int.in_dll(L.lib(), "pd_ffn_debug_flags")
 dbg.value = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-for B in (16,):
+for B in (16, 32):
     M, C, Hd = B * 3328, 256, 1024
     x = torch.randn(M, C, device="cuda")
     g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
