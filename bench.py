@@ -15,8 +15,9 @@ second over the whole job = gpus * batch * steps / wall (max over ranks).  Ranks
 frames, outside the step loop).
 
 Two extra objects on the JSON line:
-  roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM, igemm_kernel<128,128,64,2,false,2,...>): algorithmic FLOPs per
-                 launch / its average launch duration measured here with HIP events, against the dense bf16 MFMA peak.
+  roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM: igemm256_kernel<2> where pd_igemm's heuristic picks the
+                 256x256 tile, else igemm_kernel<128,128,64,2,false,2,...>): algorithmic FLOPs per launch / its average launch
+                 duration measured here with HIP events, against the dense bf16 MFMA peak.
   cpu_baseline - the oracle (CPU restatement of the reference forward) timed on this box's host cores on a bounded
                  sample of the same workload (kind "port").
 """
@@ -36,6 +37,7 @@ PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI
 UNET_GFLOP_PER_STEP = 653.4        # one denoiser forward, one trajectory (2*MAC)
 CONV3D_GFLOP_PER_STEP = 376.9 + 14.9   # 32 TimeEmbedResBlock convs + first_proj
 CONV3D_LAUNCHES_PER_STEP = 34
+CONV3D_KERNEL_LABEL = "igemm256_kernel<2> | igemm_kernel<128,128,64,2,false,2,2,1> per launch (Conv3d 3x3x3 implicit GEMM)"
 
 
 def v1_model(precision, device):
@@ -124,6 +126,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-ffn", action="store_true")
+    ap.add_argument("--igemm-debug", type=int, default=0, help="A/B: OR-ed into every pd_igemm launch's debug_flags")
     ap.add_argument("--no-tile256", action="store_true", help="A/B: keep pd_igemm on the 128x128 kernel for the long-K launches")
     args = ap.parse_args()
 
@@ -143,7 +146,12 @@ def main():
     from prediff_amd import _lib as L
     from prediff_amd.schedule import make_ddim_sampling_parameters, make_ddim_timesteps
     B = args.batch
+    global CONV3D_KERNEL_LABEL
+    if args.igemm_debug:
+        import ctypes
+        ctypes.c_int.in_dll(L.lib(), "pd_igemm_debug_or").value = args.igemm_debug
     if args.no_tile256:
+        CONV3D_KERNEL_LABEL = "igemm_kernel<128,128,64,2,false,2,2,1> (Conv3d 3x3x3 implicit GEMM)"
         import ctypes
         ctypes.c_int.in_dll(L.lib(), "pd_igemm_disable_256").value = 1
     ldm = v1_model(args.precision, device)
@@ -226,7 +234,7 @@ def main():
                        "parallelism": f"ensemble-shard x{n_gpus}"},
             "step_tflops": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12, 2),
             "step_frac_of_bf16_peak": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<128,128,64,2,false,2,2,1> (Conv3d 3x3x3 implicit GEMM)",
+            "roofline": {"bound": "mfma", "kernel": CONV3D_KERNEL_LABEL,
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches,

@@ -129,7 +129,7 @@ int pd_unet_build_input(const float* x, const float* cond, float* out, int B, in
  * freqs: dim/2 fp32 frequencies exp(-ln(max_period) k / half), computed once on the host exactly as the reference does. */
 int pd_timestep_embedding(const int64_t* t, const float* freqs, float* out, int B, int dim, pd_stream_t stream);
 
-/* Small dense layer for M <= 64 rows: out = act_out(W act_in(x) + b), fp32 throughout (TimeEmbedLayer models/time_embed.py:15-24,
+/* Small dense layer (one row per workgroup column, M <= 65535 rows): out = act_out(W act_in(x) + b), fp32 throughout (TimeEmbedLayer models/time_embed.py:15-24,
  * emb_layers :105-113).  W (N, K) row-major fp32. */
 int pd_linear_small(const float* x, const float* W, const float* b, float* out, int M, int K, int N, int act_in,
                     int act_out, pd_stream_t stream);

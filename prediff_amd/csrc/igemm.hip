@@ -271,11 +271,13 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind);
 int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s);
 
 extern "C" int pd_igemm_default_tile = 0;   // bench / tuning override of the auto choice (0 = built-in heuristic)
+extern "C" int pd_igemm_debug_or = 0;       // bench A/B switch: OR-ed into every launch's debug_flags
 extern "C" int pd_igemm_disable_256 = 0;    // bench A/B switch: keep the auto choice away from the 256 x 256 kernel
 
 extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(pa != nullptr, "pd_igemm: null args");
   pd_igemm_args a = *pa;
+  a.debug_flags |= pd_igemm_debug_or;
   PD_CHECK_ARG(a.A && a.W, "pd_igemm: A/W null");
   PD_CHECK_ARG(a.M > 0 && a.N > 0 && a.taps > 0, "pd_igemm: bad M/N/taps (%d,%d,%d)", a.M, a.N, a.taps);
   PD_CHECK_ARG(a.Cin > 0 && (a.Cin & 63) == 0, "pd_igemm: Cin=%d must be a positive multiple of 64 (zero padded)", a.Cin);
@@ -312,12 +314,13 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     // measured on MI355X (scripts/bench_igemm.py): with <= 4 K-steps the 4-workgroups/CU variant (BK 32, 32 KB LDS) hides the
     // prologue/epilogue of its neighbours best; longer K prefers the BK 64 two-stage tile.
     tile = t128 >= 192 ? ((!a.split && (int64_t)a.taps * a.Cin <= 256) ? 5 : PD_BIG_TILE_DEFAULT) : 2;
-    // long K: the 256 x 256 eight-wave kernel does a round of 256 tiles (one per CU of the MI355X) in ~1.75x the time the
-    // 128 x 128 kernel needs for a round of 512 (two per CU) -- 4x the work; take it when its whole rounds are the cheaper ones
+    // long K: the 256 x 256 eight-wave kernel does a round of 256 tiles (one per CU of the MI355X) in ~1.9x the time the
+    // 128 x 128 kernel needs for a round of 512 (two per CU) inside the sampling loop (1.75x in a cold micro-benchmark) -- twice
+    // the work; take it when its whole rounds are the cheaper ones (A/B at 16/32/39/64 trajectories: +1.1/+1.5/+2.9/-1.6 %)
     if (tile == PD_BIG_TILE_DEFAULT && !pd_igemm_disable_256 && !a.split && (int64_t)a.taps * a.Cin >= 1024 && pd_igemm256_supported(a, kind)) {
       const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.nbatch > 0 ? a.nbatch : 1);
       const int64_t r128 = (t128 + 511) / 512, r256 = (t256 + 255) / 256;
-      if (r256 * 7 <= r128 * 4) tile = 7;
+      if (r256 * 19 <= r128 * 10) tile = 7;
     }
   }
   if (a.split && tile == 4) tile = 1;   // 3 x 64 KB stages do not fit

@@ -23,6 +23,9 @@
 //     to turn e.g. 416 tiles on 256 CUs into a 224-row + a 192-row tile per CU.  A phase is not MFMA-bound -- barrier pair
 //     + LDS reads + DMA issue cost about as much as its 8 MFMAs -- so shorter tiles were not faster, and the wave-uniform
 //     branches cost 10 % everywhere.)
+//   * (tried and dropped: rotating the temporal tap order per tile so that the three output slices reading one input slice do
+//     so in the same third of their loops -- FETCH_SIZE went UP (L1 convs 109 -> 260 MB per launch); the un-rotated order
+//     already re-uses a slice one third-of-a-loop after the neighbour tile touched it.)
 //   * the swizzle, descriptors, zero-fill of out-of-image taps, XCD-contiguous tile order and epilogue are those of igemm.hip.
 // Supported: bf16 (non-split) operands, Cin % 64 == 0, KIND 0 (row-wise linear) and KIND 2 (stride-1, un-upsampled
 // Conv2d/Conv3d gather, any padding); pd_igemm picks it for long-K launches with enough rows (see igemm.hip).
