@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-ffn", action="store_true")
+    ap.add_argument("--no-fused-attn", action="store_true")
     ap.add_argument("--igemm-debug", type=int, default=0, help="A/B: OR-ed into every pd_igemm launch's debug_flags")
     ap.add_argument("--no-tile256", action="store_true", help="A/B: keep pd_igemm on the 128x128 kernel for the long-K launches")
     args = ap.parse_args()
@@ -156,6 +157,7 @@ def main():
         ctypes.c_int.in_dll(L.lib(), "pd_igemm_disable_256").value = 1
     ldm = v1_model(args.precision, device)
     ldm.torch_nn_module.fuse_ffn = not args.no_fused_ffn
+    ldm.torch_nn_module.fuse_attn = not args.no_fused_attn
     shape = ldm.get_batch_latent_shape(B)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     zc = torch.randn((B, 7, 16, 16, 64), generator=g).to(device)

@@ -166,6 +166,16 @@ int pd_ffn_fused_supported(int C, int Hd);
 int pd_ffn_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* W1, const float* b1,
                  const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, pd_stream_t stream);
 
+/* Fused cuboid self-attention block, bf16 engine:  out = x + proj(attention(qkv(LayerNorm(x))))  for head_dim 64 and cuboid volume
+ * <= 16 (CuboidSelfAttentionLayer.forward cuboid_transformer.py:812-966 + the residual of :1151), in place allowed (out == x).
+ * x/out (B, ntok, C) fp32; Wqkv (3C, C) and Wp (C, C) bf16 row-major; bqkv (3C) / bp (C) fp32 or NULL; tok_index, bias, mask
+ * as for pd_cuboid_attention.  Supported when pd_attn_block_fused_supported(C, heads, vol); otherwise use
+ * pd_layernorm + pd_igemm + pd_cuboid_attention + pd_igemm. */
+int pd_attn_block_fused_supported(int C, int heads, int vol);
+int pd_attn_block_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv, const float* bqkv,
+                        const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias, const uint8_t* mask,
+                        int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps, pd_stream_t stream);
+
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
  * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]
  * (int64, keep_seq) or counts[thr][3].  Tensors are (outer, T, inner) fp32 in [0,1]; divisor = fp32(1/255). */

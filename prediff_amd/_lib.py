@@ -66,6 +66,8 @@ _PROTOS = {
     "pd_nchw_to_nhwc": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "pd_nhwc_to_nchw": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "pd_ffn_fused_supported": (C.c_int, [C.c_int, C.c_int]),
+    "pd_attn_block_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pd_attn_block_fused": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),
     "pd_ffn_fused": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
@@ -263,6 +265,15 @@ def nhwc_to_nchw(x, out, N, Cn, HW, ld_in):
 def sevir_skill_counts(pred, target, thresholds, divisor, counts, outer, T, inner, keep_seq):
     _check(lib().pd_sevir_skill_counts(ptr(pred), ptr(target), ptr(thresholds), thresholds.numel(), divisor, ptr(counts), outer, T,
                                        inner, 1 if keep_seq else 0, stream_ptr()), "pd_sevir_skill_counts")
+
+
+def attn_block_fused_supported(Cn, heads, vol):
+    return bool(lib().pd_attn_block_fused_supported(Cn, heads, vol))
+
+
+def attn_block_fused(x, out, gamma, beta, Wqkv, bqkv, Wp, bp, tok_index, bias, mask, B, ntok, Cn, heads, nc, vol, scale, eps=1e-5):
+    _check(lib().pd_attn_block_fused(ptr(x), ptr(out), ptr(gamma), ptr(beta), ptr(Wqkv), ptr(bqkv), ptr(Wp), ptr(bp), ptr(tok_index),
+                                     ptr(bias), ptr(mask), B, ntok, Cn, heads, nc, vol, scale, eps, stream_ptr()), "pd_attn_block_fused")
 
 
 def ffn_fused_supported(Cn, Hd):

@@ -86,6 +86,8 @@ __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_a
     for (int r = 0; r < 4; ++r) vf[r] = vtok[r] >= 0 ? (short)vbase[(int64_t)vtok[r] * p.ld_qkv + d0] : (short)0;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o, 0, 0, 0);
+    // the result feeds inline asm (v_cvt_pk_bf16_f32) directly: hipcc does not insert the XDL-write -> VALU-read wait states for asm
+    asm volatile("s_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
     // lane: query q, d = d0 + 4g + r
     if (orow) {
       const uint32_t lo = pack_bf16x2(o[0], o[1]);

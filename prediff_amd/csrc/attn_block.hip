@@ -1,0 +1,432 @@
+// pd_attn_block_fused: x += proj(cuboid_attention(qkv(LayerNorm(x)))) in ONE kernel for head_dim 64, cuboid volume <= 16
+// (CuboidSelfAttentionLayer.forward + the residual of StackCuboidSelfAttentionBlock, reference cuboid_transformer.py:812-966,
+// :1151) -- every axial pattern of the SEVIR-LR denoiser at level 0 (units 256, 4 heads).
+//
+// Why: un-fused the block is LN -> QKV GEMM -> attention core -> proj GEMM with K = 256 GEMMs and a 2 flop/B core, i.e. four
+// HBM-bound launches that write and re-read the bf16 LN output, QKV (3 x) and attention output.  Here a workgroup owns 8 whole
+// cuboids (8 x 16 slots = 128 rows, gathered through tok_index -- the cuboid reorder / un-shift never materialises), and
+// nothing but x goes to HBM: one gathered fp32 read, one scattered fp32 write (+ the residual re-read).
+//
+// One workgroup = 512 threads (8 waves):
+//   phase 0   LayerNorm of the 128 gathered rows (wave w = the 16 slots of cuboid w) -> bf16 A tile in LDS -> each wave keeps the
+//             fragments of its 32 rows (all of K = C) in registers for the whole kernel; the A region becomes weight buffers.
+//   head h    (4 weight chunks of 32 KB: Wq_h, Wk_h, Wv_h [64 x C], Wp[:, 64h:64h+64] [C x 64], 3-deep LDS ring, DMA two chunks ahead)
+//       q, k   Q_h^T, K_h^T [64 x 128] = W * A^T (transposed product: a lane ends up with 4 consecutive d of one token -> 8 B
+//              writes into row-major [row][d] tiles, the operand layout of S^T = K Q^T)
+//       v      V_h [128 x 64] = A * Wv^T (plain product: a lane ends up with 4 consecutive tokens of one d -> 8 B writes into
+//              the [d][row] tile, the A-operand layout of O^T = V^T P^T)
+//       core   wave w, cuboid w: S^T = K Q^T (2 x mfma 16x16x32), scale, + relative-position bias, mask, softmax over keys in
+//              registers (4 values + 2 shuffles), O^T = V^T P^T (4 x mfma 16x16x16) -> O tile (over the Q tile: same rows, same wave)
+//       proj   acc[128 x C] += O_h[128 x 64] * Wp_h^T
+//   epilogue  acc + b_proj + x -> out rows (scatter through the same token table).
+// LDS: weight ring 3 x 32 KB (two of them = the A region) + Q/O, K, V^T tiles 3 x 16 KB + bias tables + token ids = 152 KB.
+// Numerics are those of the un-fused bf16 path (bf16 LN output, bf16 q/k/v/P/O, fp32 accumulation, fp32 softmax).
+#include "common.h"
+
+#define BLDS16(rsrc, ldsptr, voff, soff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
+
+struct pd_attn_block_args_k {
+  const float* x;
+  float* out;
+  const float* gamma;
+  const float* beta;
+  const pd_bf16* Wqkv;   // [3C][C]  (q rows, k rows, v rows; head h = rows 64h .. 64h+63 of each)
+  const float* bqkv;     // [3C] or null
+  const pd_bf16* Wp;     // [C][C]
+  const float* bp;       // [C] or null
+  const int32_t* tok_index;   // [nc][vol]
+  const float* bias;     // [heads][vol][vol]
+  const uint8_t* mask;   // [nc][vol][vol] or null
+  int B, ntok, nc, vol;
+  float scale, eps;
+  uint32_t wqkv_bytes, wp_bytes;
+};
+
+template <int C>
+__global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_args_k p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, HD = 64, HEADS = C / HD;
+  constexpr int KS = C / 64;                       // 64-wide K slabs of the A tile / weight chunks
+  constexpr int CHUNK = 64 * C * 2;                // bytes of one weight chunk (64 x C or C x 64 bf16)
+  constexpr int A_BYTES = BM * C * 2;
+  static_assert(A_BYTES == 2 * CHUNK, "the A region becomes two ring buffers");
+  constexpr int TILE = BM * HD * 2;                // 16 KB
+  constexpr int TN2 = (C / 2) / 32;                // 32x32 tiles per wave in the proj GEMM (wave tile 32 x C/2)
+  constexpr int NCHUNK = 4 * HEADS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                                 // A tile, then ring buffers 0 and 1
+  char* sR2 = sA + A_BYTES;                        // ring buffer 2
+  char* sQ = sR2 + CHUNK;                          // Q tile [row][d], re-used for O
+  char* sK = sQ + TILE;                            // K tile [row][d]
+  char* sVT = sK + TILE;                           // V^T tile [d][row]
+  float* sBias = (float*)(sVT + TILE);             // [HEADS][16][16]
+  int* sTok = (int*)(sBias + HEADS * 256);         // [128] global row of every slot, -1 = no token
+  float* sBq = (float*)(sTok + BM);                // [3C] qkv bias (zeros without one): an ordinary global load inside the head loop
+                                                   // would make hipcc drain the weight DMA queue (vmcnt(0)) at every use
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vol = p.vol;
+
+  const auto rWqkv = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wqkv, 0, p.wqkv_bytes, 0x00020000);
+  const auto rWp = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, p.wp_bytes, 0x00020000);
+
+  // DMA lane mapping: one 512-thread instruction fills one [64 rows][64 k] slab (8 KB), lane-linear, source-side swizzle
+  const int drow = tid >> 3, dpos = tid & 7;
+  const int dchunk = dpos ^ ((drow >> 1) & 7);
+  const uint32_t wq_voff = ((uint32_t)drow * C + dchunk * 8) * 2u;                 // + ((kind*C + h*64)*C + s*64)*2 in the SGPR offset
+  uint32_t wp_voff[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) wp_voff[i] = ((uint32_t)(i * 64 + drow) * C + dchunk * 8) * 2u;   // + h*64*2
+  auto ring = [&](int s) {                          // chunk s lives in ring buffer (s + 2) % 3
+    const int b = (s + 2) % 3;
+    return b == 2 ? sR2 : sA + b * CHUNK;
+  };
+  auto issue_chunk = [&](int s) {                   // s = 4 * head + kind (0 q, 1 k, 2 v, 3 proj)
+    char* d = ring(s) + wave * 1024;
+    const int kind = s & 3, h = s >> 2;
+    if (kind < 3) {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) BLDS16(rWqkv, d + i * 8192, wq_voff, ((kind * C + h * HD) * C + i * 64) * 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) BLDS16(rWp, d + i * 8192, wp_voff[i], h * HD * 2);
+    }
+  };
+  issue_chunk(0);
+
+  // ---- token table of the 8 cuboids, relative-position bias (padded to 16 x 16 per head) ----
+  if (tid < BM) {
+    const int cl = tid >> 4, slot = tid & 15;
+    const int64_t gc = (int64_t)blockIdx.x * 8 + cl;
+    int row = -1;
+    if (gc < (int64_t)p.B * p.nc && slot < vol) {
+      const int b = (int)(gc / p.nc), c = (int)(gc - (int64_t)b * p.nc);
+      const int tok = p.tok_index[c * vol + slot];
+      if (tok >= 0) row = b * p.ntok + tok;
+    }
+    sTok[tid] = row;
+  }
+  for (int i = tid; i < 3 * C; i += 512) sBq[i] = p.bqkv ? p.bqkv[i] : 0.f;
+  for (int i = tid; i < HEADS * 256; i += 512) {
+    const int h = i >> 8, q = (i >> 4) & 15, k = i & 15;
+    sBias[i] = (q < vol && k < vol) ? p.bias[((int64_t)h * vol + q) * vol + k] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- phase 0: LayerNorm of the gathered rows -> bf16 A tile (KS slabs of [128][64], chunk swizzle (row>>1)&7) ----
+  {
+    constexpr int LPRW = C / 4;                    // lanes holding one row (float4 each)
+    const bool act_lane = lane < LPRW;
+    float4 g4 = make_float4(0, 0, 0, 0), b4 = g4;
+    if (act_lane) { g4 = *(const float4*)(p.gamma + lane * 4); b4 = *(const float4*)(p.beta + lane * 4); }
+    float4 xv[16];                                 // all 16 rows of this wave in flight at once
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int m = sTok[wave * 16 + rr];
+      xv[rr] = make_float4(0, 0, 0, 0);
+      if (act_lane && m >= 0) xv[rr] = *(const float4*)(p.x + (int64_t)m * C + lane * 4);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = wave * 16 + rr;
+      const int m = sTok[row];
+      const float4 v = xv[rr];
+      const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)C;
+      float q = 0.f;
+      if (act_lane) { const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean; q = (a * a + b * b) + (c * c + d * d); }
+      const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
+      if (act_lane) {
+        float y0 = (v.x - mean) * rstd * g4.x + b4.x, y1 = (v.y - mean) * rstd * g4.y + b4.y;
+        float y2 = (v.z - mean) * rstd * g4.z + b4.z, y3 = (v.w - mean) * rstd * g4.w + b4.w;
+        if (m < 0) y0 = y1 = y2 = y3 = 0.f;
+        const int k = lane * 4, slab = k >> 6, chunk = (k & 63) >> 3;
+        const int off = slab * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + ((lane & 1) << 3);
+        *(uint2*)(sA + off) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+      }
+    }
+  }
+
+  // ---- wave roles ----
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int swz = (lrow >> 1) & 7;
+  // q/k/v GEMMs: wave -> d tile tn (of 2) x row tile tq (of 4)
+  const int tn = wave & 1, tq = wave >> 1;
+  const int g1_w_row = (tn * 32 + lrow) * 128;     // weight chunk row (feature d) inside a slab
+  const int g1_a_row = (tq * 32 + lrow) * 128;     // A tile row (slot) inside a slab
+  // proj GEMM: wave -> row tile wm (of 4) x column half wn (of 2)
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g2_a_row = (wm * 32 + lrow) * 128;     // O row
+  const int g2_b_row = (wn * (C / 2) + lrow) * 128;   // Wp chunk row (output channel)
+
+  f32x16 acc2[TN2];
+#pragma unroll
+  for (int t = 0; t < TN2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                        // A tile written by all waves; chunk 0 landed
+  bf16x8 areg[KS * 4];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) areg[s * 4 + kk] = *(const bf16x8*)(sA + s * (BM * 128) + g1_a_row + (((kk * 2 + lhalf) ^ swz) * 16));
+  // validity of this lane's slots: q/k tiles = its own row; v tile = 16 rows tq*32 + 8g + 4*lhalf + (0..3)
+  const bool row_ok = sTok[tq * 32 + lrow] >= 0;
+  uint32_t vrow_ok = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) vrow_ok |= (sTok[tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf] >= 0 ? 1u : 0u) << r;
+  __syncthreads();                                        // A-tile region is now free: ring buffers 0 and 1
+  issue_chunk(1);
+  issue_chunk(2);
+
+  const uint32_t q_lds = (uint32_t)(uintptr_t)sQ, k_lds = (uint32_t)(uintptr_t)sK, vt_lds = (uint32_t)(uintptr_t)sVT;
+  const uint32_t bq_lds = (uint32_t)(uintptr_t)sBq;
+  // end of a weight-chunk step: chunk s+1 has landed (chunk s+2 may stay in flight), everyone is done with chunk s, refill its buffer
+  auto step_end = [&](int s) {
+    if (s + 2 < NCHUNK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 3 < NCHUNK) issue_chunk(s + 3);
+  };
+
+  for (int h = 0; h < HEADS; ++h) {
+    // ---------------- q and k: transposed products ----------------
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      const int s = 4 * h + kind;
+      const char* cW = ring(s);
+      f32x16 acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8 w = *(const bf16x8*)(cW + ks * 8192 + g1_w_row + (((kk * 2 + lhalf) ^ swz) * 16));
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, areg[ks * 4 + kk], acc1, 0, 0, 0);
+        }
+      // lane: slot row tq*32 + lrow, features tn*32 + 8g + 4*lhalf + (0..3) for g = 0..3
+      const int trow = tq * 32 + lrow;
+      const int tswz = (trow >> 1) & 7;
+      const uint32_t t_lds = kind == 0 ? q_lds : k_lds;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = tn * 32 + 8 * g + 4 * lhalf;
+        f32x4 bb;   // opaque LDS read (+ its wait): see the note at the ds_write below
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bb) : "v"(bq_lds + (uint32_t)((kind * C + h * HD + d) * 4)) : "memory");
+        float v0 = acc1[4 * g] + bb[0], v1 = acc1[4 * g + 1] + bb[1];
+        float v2 = acc1[4 * g + 2] + bb[2], v3 = acc1[4 * g + 3] + bb[3];
+        if (!row_ok) v0 = v1 = v2 = v3 = 0.f;                 // a padded slot is a zero token (as in the un-fused path)
+        const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
+        const int off = trow * 128 + (((d >> 3) ^ tswz) << 4) + ((d & 7) << 1);
+        // opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell that the tiles and
+        // the DMA destinations are disjoint LDS regions), which would serialise the prefetch at every step
+        asm volatile("ds_write_b64 %0, %1" ::"v"(t_lds + (uint32_t)off), "v"(pk) : "memory");
+      }
+      step_end(s);
+    }
+    // ---------------- v: plain product, stored transposed ----------------
+    {
+      const int s = 4 * h + 2;
+      const char* cW = ring(s);
+      f32x16 acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8 w = *(const bf16x8*)(cW + ks * 8192 + g1_w_row + (((kk * 2 + lhalf) ^ swz) * 16));
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[ks * 4 + kk], w, acc1, 0, 0, 0);
+        }
+      // lane: feature d = tn*32 + lrow, slot rows tq*32 + 8g + 4*lhalf + (0..3) for g = 0..3
+      const int d = tn * 32 + lrow;
+      float bv;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bv) : "v"(bq_lds + (uint32_t)((2 * C + h * HD + d) * 4)) : "memory");
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v0 = acc1[4 * g] + bv, v1 = acc1[4 * g + 1] + bv;
+        float v2 = acc1[4 * g + 2] + bv, v3 = acc1[4 * g + 3] + bv;
+        if (!((vrow_ok >> (4 * g)) & 1u)) v0 = 0.f;
+        if (!((vrow_ok >> (4 * g + 1)) & 1u)) v1 = 0.f;
+        if (!((vrow_ok >> (4 * g + 2)) & 1u)) v2 = 0.f;
+        if (!((vrow_ok >> (4 * g + 3)) & 1u)) v3 = 0.f;
+        const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
+        const int c4 = tq * 8 + 2 * g + lhalf;                                   // 4-row chunk of the [d][128 rows] tile
+        const int off = d * 256 + ((c4 ^ ((d & 15) << 1)) << 3);                 // chunk XOR: conflict-free 8 B reads by (d, 4-row group)
+        asm volatile("ds_write_b64 %0, %1" ::"v"(vt_lds + (uint32_t)off), "v"(pk) : "memory");
+      }
+      step_end(s);
+    }
+    // ---------------- attention core: wave w = cuboid w of this workgroup ----------------
+    {
+      const int q = lane & 15, g = lane >> 4;
+      const int row = wave * 16 + q;
+      const int rswz = (row >> 1) & 7;
+      f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int pos = ((g + 4 * st) ^ rswz) << 4;
+        const bf16x8 kf = *(const bf16x8*)(sK + row * 128 + pos);
+        const bf16x8 qf = *(const bf16x8*)(sQ + row * 128 + pos);
+        sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc4, 0, 0, 0);
+      }
+      // lane: query q, keys 4g .. 4g+3
+      const float4 bq = *(const float4*)(sBias + h * 256 + q * 16 + 4 * g);
+      const float bk[4] = {bq.x, bq.y, bq.z, bq.w};
+      const int64_t gc = (int64_t)blockIdx.x * 8 + wave;
+      const int cub = (int)(gc % p.nc);
+      float sc[4];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 4 * g + r;
+        float v = -INFINITY;
+        if (key < vol && q < vol) {
+          v = sc4[r] * p.scale + bk[r];
+          if (p.mask && !p.mask[((int64_t)cub * vol + q) * vol + key]) v = -1e18f;
+        }
+        sc[r] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float pr[4], sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] = expf(sc[r] - mx);   // exp(-inf) = 0 for non-existent keys
+        sum += pr[r];
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = sum > 0.f ? 1.f / sum : 0.f;
+      s16x4 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = pr[r] * inv;
+        if (sc[r] <= -1e18f) v = 0.f;   // masked_softmax multiplies by the mask after the softmax
+        pf[r] = (short)f2bf(v);
+      }
+      // O^T[d][query] = sum_key V[key][d] P[query][key]: A = V^T (lane: d = d0 + q, keys 4g..4g+3), B = P^T
+#pragma unroll
+      for (int d0 = 0; d0 < HD; d0 += 16) {
+        const int d = d0 + q;
+        const s16x4 vf = *(const s16x4*)(sVT + d * 256 + (((wave * 4 + g) ^ ((d & 15) << 1)) << 3));
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o, 0, 0, 0);
+        // the MFMA result goes straight into inline asm (v_cvt_pk_bf16_f32): hipcc's hazard recogniser does not look inside asm, so
+        // the XDL-write -> VALU-read wait states have to be spelled out (the "+v" ties keep this between the MFMA and the packs)
+        asm volatile("s_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+        // lane: query q, features d0 + 4g + (0..3) -> O tile (the Q tile: these 16 rows belong to this wave only)
+        const int dd = d0 + 4 * g;
+        const uint64_t pk = (uint64_t)(pack_bf16x2(o[0], o[1])) | ((uint64_t)(pack_bf16x2(o[2], o[3])) << 32);
+        const int off = row * 128 + (((dd >> 3) ^ rswz) << 4) + ((dd & 7) << 1);
+        asm volatile("ds_write_b64 %0, %1" ::"v"(q_lds + (uint32_t)off), "v"(pk) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // O_h visible to every wave (weight DMA stays in flight)
+    }
+    // ---------------- proj: acc2 += O_h * Wp_h^T ----------------
+    {
+      const int s = 4 * h + 3;
+      const char* cW = ring(s);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
+        const bf16x8 a = *(const bf16x8*)(sQ + g2_a_row + pos);
+#pragma unroll
+        for (int t = 0; t < TN2; ++t) {
+          const bf16x8 b = *(const bf16x8*)(cW + g2_b_row + t * 32 * 128 + pos);
+          acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[t], 0, 0, 0);
+        }
+      }
+      step_end(s);
+    }
+  }
+
+  // ---- epilogue: acc2 -> per-wave LDS slab [32][C/2] fp32 -> + b_proj + x -> out rows of the token table ----
+  constexpr int WN = C / 2;
+  int mrow[32 / (64 / (WN / 4))];                       // token rows this lane stores (read before the slab overwrites nothing: sTok is outside)
+  float* sC = (float*)smem + wave * (32 * WN);
+#pragma unroll
+  for (int t = 0; t < TN2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + t * 32 + lrow] = acc2[t][r];
+  __syncthreads();
+  constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 32 at C = 256
+  constexpr int RPP = 64 / LPR;
+  constexpr int NPASS = 32 / RPP;
+  const int c0 = (lane % LPR) * 4;
+  const int n = wn * WN + c0;
+  float4 bias = make_float4(0, 0, 0, 0);
+  if (p.bp) bias = *(const float4*)(p.bp + n);
+#pragma unroll
+  for (int u = 0; u < NPASS; ++u) mrow[u] = sTok[wm * 32 + u * RPP + lane / LPR];
+#pragma unroll
+  for (int p0 = 0; p0 < NPASS; p0 += 4) {          // 4 residual loads in flight per lane
+    float4 xr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xr[u] = make_float4(0, 0, 0, 0);
+      if (p0 + u < NPASS && mrow[p0 + u] >= 0) xr[u] = *(const float4*)(p.x + (int64_t)mrow[p0 + u] * C + n);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (p0 + u >= NPASS || mrow[p0 + u] < 0) continue;
+      const int row = (p0 + u) * RPP + lane / LPR;
+      const float4 a4 = *(const float4*)(sC + row * WN + c0);
+      *(float4*)(p.out + (int64_t)mrow[p0 + u] * C + n) =
+          make_float4(a4.x + bias.x + xr[u].x, a4.y + bias.y + xr[u].y, a4.z + bias.z + xr[u].z, a4.w + bias.w + xr[u].w);
+    }
+  }
+#endif
+}
+
+template <int C>
+static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
+  constexpr int heads = C / 64;
+  constexpr int lds = 128 * C * 2 + 64 * C * 2 + 3 * 128 * 64 * 2 + heads * 256 * 4 + 128 * 4 + 3 * C * 4;
+  constexpr int epi = 8 * 32 * (C / 2) * 4;
+  static_assert(epi <= 128 * C * 2 + 64 * C * 2 + 3 * 128 * 64 * 2, "the epilogue slab must not reach the token table");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_block_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      pd_set_error("pd_attn_block_fused: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
+      return PD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int64_t cuboids = (int64_t)a.B * a.nc;
+  hipLaunchKernelGGL((attn_block_kernel<C>), dim3((unsigned)((cuboids + 7) / 8)), dim3(512), lds, s, a);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+extern "C" int pd_attn_block_fused_supported(int C, int heads, int vol) {
+  return (C == 256 || C == 128) && heads * 64 == C && vol >= 1 && vol <= 16;
+}
+
+extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
+                                   const float* bqkv, const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias,
+                                   const uint8_t* mask, int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps,
+                                   pd_stream_t stream) {
+  PD_CHECK_ARG(x && out && gamma && beta && Wqkv && Wp && tok_index && bias, "pd_attn_block_fused: null pointer");
+  PD_CHECK_ARG(pd_attn_block_fused_supported(C, heads, vol), "pd_attn_block_fused: unsupported units=%d heads=%d cuboid volume=%d "
+               "(units in {128,256}, head_dim 64, volume <= 16)", C, heads, vol);
+  PD_CHECK_ARG(B > 0 && ntok > 0 && nc > 0 && (int64_t)B * ntok < (1ll << 31), "pd_attn_block_fused: bad sizes");
+  pd_attn_block_args_k a;
+  a.x = x; a.out = out; a.gamma = gamma; a.beta = beta; a.Wqkv = Wqkv; a.bqkv = bqkv; a.Wp = Wp; a.bp = bp;
+  a.tok_index = tok_index; a.bias = bias; a.mask = mask;
+  a.B = B; a.ntok = ntok; a.nc = nc; a.vol = vol; a.scale = scale; a.eps = eps;
+  a.wqkv_bytes = (uint32_t)((int64_t)3 * C * C * 2);
+  a.wp_bytes = (uint32_t)((int64_t)C * C * 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 256) return launch_attn_block<256>(a, s);
+  return launch_attn_block<128>(a, s);
+}

@@ -331,6 +331,7 @@ class CuboidTransformerUNet(nn.Module):
             raise ValueError("precision must be 'bf16' (throughput) or 'fp32' (hi/lo split, fp32-class accuracy)")
         self.precision = precision
         self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
+        self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 16)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)
         self.depth = list(depth)
@@ -634,6 +635,13 @@ class CuboidTransformerUNet(nn.Module):
     def _attention(self, P, name, at: CuboidSelfAttentionLayer, x, B, S, C, tabs, geo, dev):
         """x += CuboidSelfAttentionLayer(x)  (cuboid_transformer.py:812-966, residual of :1151)."""
         ld = pad64(C)
+        if (self.precision == "bf16" and self.fuse_attn and at.use_final_proj and ld == C
+                and L.attn_block_fused_supported(C, at.num_heads, geo["vol"])):
+            # one launch, q/k/v/attention output never leave the CU (csrc/attn_block.hip)
+            L.attn_block_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".qkv.w"][0], P[name + ".qkv.b"],
+                               P[name + ".proj.w"][0], P[name + ".proj.b"], tabs["tok"], P[name + ".bias"], tabs["mask"],
+                               B, S, C, at.num_heads, geo["nc"], geo["vol"], float(at.scale))
+            return
         a, alo = self._bf("ln.a", B * S, ld, dev)
         L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld)
         wq, wqlo = P[name + ".qkv.w"]

@@ -386,3 +386,61 @@ def test_ffn_fused(M, Cn, act):
     xin = x.clone()
     L.ffn_fused(xin, xin, gamma, beta, w1p, b1, w2p, b2, M, Cn, Hd, act=act)      # in place
     assert torch.equal(xin, out)
+
+
+# ------------------------------------------------------------------------------------------------ fused attention block
+ATTN_BLOCK = [((13, 16, 16), (13, 1, 1), (0, 0, 0), "zeros", 256, 4, 2), ((13, 16, 16), (1, 16, 1), (0, 0, 0), "zeros", 256, 4, 3),
+              ((13, 16, 16), (1, 1, 16), (0, 0, 0), "zeros", 256, 4, 1), ((5, 8, 8), (1, 8, 1), (0, 0, 0), "zeros", 128, 2, 3),
+              ((3, 5, 6), (3, 1, 1), (0, 0, 0), "zeros", 128, 2, 1), ((5, 7, 6), (1, 4, 4), (0, 2, 2), "ignore", 128, 2, 2),
+              ((5, 7, 6), (1, 4, 4), (0, 2, 2), "zeros", 256, 4, 1)]
+
+
+@pytest.mark.parametrize("shape,cuboid,shift,padding_type,Cn,heads,B", ATTN_BLOCK)
+@pytest.mark.parametrize("qkv_bias", [False, True])
+def test_attn_block_fused(shape, cuboid, shift, padding_type, Cn, heads, B, qkv_bias):
+    """pd_attn_block_fused against the un-fused HIP chain LN -> QKV GEMM -> pd_cuboid_attention -> proj GEMM (+x) it replaces
+    (that chain is pinned against the oracle / reference goldens by the tests above and tests/test_hip_unet.py)."""
+    from oracle import unet as OU
+    from prediff_amd.cuboid_geometry import attention_tables
+    T, H, W = shape
+    ntok = T * H * W
+    g = torch.Generator(device="cpu").manual_seed(ntok + Cn + B)
+    x = (torch.randn(B, ntok, Cn, generator=g) * 1.5 + 0.2 + torch.arange(ntok)[None, :, None] * 1e-3).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(Cn, generator=g)).to(DEV), (0.1 * torch.randn(Cn, generator=g)).to(DEV)
+    wqkv = (torch.randn(3 * Cn, Cn, generator=g) / math.sqrt(Cn)).to(DEV)
+    wp = (torch.randn(Cn, Cn, generator=g) / math.sqrt(Cn)).to(DEV)
+    bq = (torch.randn(3 * Cn, generator=g) * 0.2).to(DEV) if qkv_bias else None
+    bp = (torch.randn(Cn, generator=g) * 0.1).to(DEV)
+    tabs = attention_tables(shape, cuboid, shift, LLL, padding_type)
+    vol, nc = tabs["vol"], tabs["nc"]
+    table_rows = (2 * cuboid[0] - 1) * (2 * cuboid[1] - 1) * (2 * cuboid[2] - 1)
+    bias_table = torch.randn(table_rows, heads, generator=g) * 0.5
+    relidx = OU.relative_position_index(cuboid)
+    bias = bias_table[relidx[:vol, :vol].reshape(-1)].reshape(vol, vol, heads).permute(2, 0, 1).contiguous().to(DEV)
+    tok = tabs["tok_index"].to(DEV)
+    m = tabs["mask"].to(DEV) if tabs["mask"] is not None else None
+    assert L.attn_block_fused_supported(Cn, heads, vol) and not L.attn_block_fused_supported(512, 4, 13)
+    wq_p, _ = pack_linear(wqkv, False)
+    wp_p, _ = pack_linear(wp, False)
+    scale = (Cn // heads) ** -0.5
+    # ---- un-fused chain ----
+    a = torch.empty(B * ntok, Cn, dtype=torch.bfloat16, device=DEV)
+    L.layernorm(x, gamma, beta, a, None, B * ntok, Cn, Cn)
+    qkv = torch.empty(B * ntok, 3 * Cn, dtype=torch.bfloat16, device=DEV)
+    L.igemm(a, wq_p, M=B * ntok, N=3 * Cn, Cin=Cn, bias=bq, out_bf16=qkv)
+    o = torch.zeros(B * ntok, Cn, dtype=torch.bfloat16, device=DEV)
+    L.cuboid_attention(qkv_bf16=qkv, out_bf16=o, tok_index=tok, bias=bias, mask=m, B=B, ntok=ntok, Cn=Cn, heads=heads, nc=nc,
+                       vol=vol, ld_qkv=3 * Cn, ld_out=Cn, scale=scale)
+    ref = torch.empty_like(x)
+    L.igemm(o, wp_p, M=B * ntok, N=Cn, Cin=Cn, bias=bp, residual=x, out_f32=ref)
+    # ---- fused ----
+    out = torch.full_like(x, float("nan"))
+    L.attn_block_fused(x, out, gamma, beta, wq_p, bq, wp_p, bp, tok, bias, m, B, ntok, Cn, heads, nc, vol, scale)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())               # every token row is written exactly once
+    # same roundings (bf16 LN output / q / k / v / P / O, fp32 accumulation); only the fp32 summation order of the GEMMs differs,
+    # which moves a few bf16 rounding boundaries
+    assert rel_l2(out - x, ref - x) < 3e-3
+    xin = x.clone()
+    L.attn_block_fused(xin, xin, gamma, beta, wq_p, bq, wp_p, bp, tok, bias, m, B, ntok, Cn, heads, nc, vol, scale)   # in place
+    assert torch.equal(xin, out)
