@@ -22,6 +22,7 @@
 // LDS: weight ring 3 x 32 KB (two of them = the A region) + Q/O, K, V^T tiles 3 x 16 KB + bias tables + token ids = 152 KB.
 // Numerics are those of the un-fused bf16 path (bf16 LN output, bf16 q/k/v/P/O, fp32 accumulation, fp32 softmax).
 #include "common.h"
+#include "ln_tile.h"
 
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
@@ -117,37 +118,7 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   __syncthreads();
 
   // ---- phase 0: LayerNorm of the gathered rows -> bf16 A tile (KS slabs of [128][64], chunk swizzle (row>>1)&7) ----
-  {
-    constexpr int LPRW = C / 4;                    // lanes holding one row (float4 each)
-    const bool act_lane = lane < LPRW;
-    float4 g4 = make_float4(0, 0, 0, 0), b4 = g4;
-    if (act_lane) { g4 = *(const float4*)(p.gamma + lane * 4); b4 = *(const float4*)(p.beta + lane * 4); }
-    float4 xv[16];                                 // all 16 rows of this wave in flight at once
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int m = sTok[wave * 16 + rr];
-      xv[rr] = make_float4(0, 0, 0, 0);
-      if (act_lane && m >= 0) xv[rr] = *(const float4*)(p.x + (int64_t)m * C + lane * 4);
-    }
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = wave * 16 + rr;
-      const int m = sTok[row];
-      const float4 v = xv[rr];
-      const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)C;
-      float q = 0.f;
-      if (act_lane) { const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean; q = (a * a + b * b) + (c * c + d * d); }
-      const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
-      if (act_lane) {
-        float y0 = (v.x - mean) * rstd * g4.x + b4.x, y1 = (v.y - mean) * rstd * g4.y + b4.y;
-        float y2 = (v.z - mean) * rstd * g4.z + b4.z, y3 = (v.w - mean) * rstd * g4.w + b4.w;
-        if (m < 0) y0 = y1 = y2 = y3 = 0.f;
-        const int k = lane * 4, slab = k >> 6, chunk = (k & 63) >> 3;
-        const int off = slab * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + ((lane & 1) << 3);
-        *(uint2*)(sA + off) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
-      }
-    }
-  }
+  ln_block_to_tile<C>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, false, [&](int r) { return sTok[r]; });
 
   // ---- wave roles ----
   const int lrow = lane & 31, lhalf = lane >> 5;
@@ -351,38 +322,34 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
 
   // ---- epilogue: acc2 -> per-wave LDS slab [32][C/2] fp32 -> + b_proj + x -> out rows of the token table ----
   constexpr int WN = C / 2;
-  int mrow[32 / (64 / (WN / 4))];                       // token rows this lane stores (read before the slab overwrites nothing: sTok is outside)
-  float* sC = (float*)smem + wave * (32 * WN);
-#pragma unroll
-  for (int t = 0; t < TN2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + t * 32 + lrow] = acc2[t][r];
-  __syncthreads();
   constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 32 at C = 256
   constexpr int RPP = 64 / LPR;
   constexpr int NPASS = 32 / RPP;
   const int c0 = (lane % LPR) * 4;
   const int n = wn * WN + c0;
+  float* sC = (float*)smem + wave * (32 * WN);     // (the last step_end left every wave past its weight / tile reads)
+#pragma unroll
+  for (int t = 0; t < TN2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + t * 32 + lrow] = acc2[t][r];
+  // every residual row of this lane in flight at once (the accumulators are dead now): one exposed HBM round trip
+  int mrow[NPASS];
+  float4 xr[NPASS];
+#pragma unroll
+  for (int u = 0; u < NPASS; ++u) {
+    mrow[u] = sTok[wm * 32 + u * RPP + lane / LPR];
+    xr[u] = make_float4(0, 0, 0, 0);
+    if (mrow[u] >= 0) xr[u] = *(const float4*)(p.x + (int64_t)mrow[u] * C + n);
+  }
   float4 bias = make_float4(0, 0, 0, 0);
   if (p.bp) bias = *(const float4*)(p.bp + n);
+  // (no workgroup barrier: the slab is private to the wave)
 #pragma unroll
-  for (int u = 0; u < NPASS; ++u) mrow[u] = sTok[wm * 32 + u * RPP + lane / LPR];
-#pragma unroll
-  for (int p0 = 0; p0 < NPASS; p0 += 4) {          // 4 residual loads in flight per lane
-    float4 xr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      xr[u] = make_float4(0, 0, 0, 0);
-      if (p0 + u < NPASS && mrow[p0 + u] >= 0) xr[u] = *(const float4*)(p.x + (int64_t)mrow[p0 + u] * C + n);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (p0 + u >= NPASS || mrow[p0 + u] < 0) continue;
-      const int row = (p0 + u) * RPP + lane / LPR;
-      const float4 a4 = *(const float4*)(sC + row * WN + c0);
-      *(float4*)(p.out + (int64_t)mrow[p0 + u] * C + n) =
-          make_float4(a4.x + bias.x + xr[u].x, a4.y + bias.y + xr[u].y, a4.z + bias.z + xr[u].z, a4.w + bias.w + xr[u].w);
-    }
+  for (int u = 0; u < NPASS; ++u) {
+    if (mrow[u] < 0) continue;
+    const float4 a4 = *(const float4*)(sC + (u * RPP + lane / LPR) * WN + c0);
+    *(float4*)(p.out + (int64_t)mrow[u] * C + n) =
+        make_float4(a4.x + bias.x + xr[u].x, a4.y + bias.y + xr[u].y, a4.z + bias.z + xr[u].z, a4.w + bias.w + xr[u].w);
   }
 #endif
 }

@@ -21,6 +21,7 @@
 //   epilogue  acc + b2 + x -> out (fp32), staged through LDS for 16 B row segments.
 // LDS: A 128*C*2 + H 16 KB + W1 64*C*2 + W2 C*128  = 144 KB at C = 256 (one workgroup per CU, two waves per SIMD).
 #include "common.h"
+#include "ln_tile.h"
 
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
@@ -37,7 +38,8 @@ struct pd_ffn_args_k {
   int M, Hd, act;
   float eps;
   uint32_t w1_bytes, w2_bytes;
-  int dbg;   // profiling ablations: 1 no weight DMA after chunk 0, 2 no GEMM-1, 4 no activation + H store, 8 no GEMM-2
+  int dbg;   // profiling ablations: 1 no weight DMA after chunk 0, 2 no GEMM-1, 4 no activation + H store, 8 no GEMM-2,
+             // 16 no LN loads, 32 no residual loads, 64 no stores
 };
 
 template <int C, int ACT>
@@ -94,37 +96,8 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
   issue_w1(0, 0);
 
   // ---- phase 0: LayerNorm -> bf16 A tile (KS slabs of [128][64], chunk swizzle (row>>1)&7) ----
-  {
-    constexpr int LPRW = C / 4;                    // lanes holding one row (float4 each)
-    const bool act_lane = lane < LPRW;
-    float4 g4 = make_float4(0, 0, 0, 0), b4 = g4;
-    if (act_lane) { g4 = *(const float4*)(p.gamma + lane * 4); b4 = *(const float4*)(p.beta + lane * 4); }
-    float4 xv[16];                                 // all 16 rows of this wave in flight at once (latency, not bandwidth, bound)
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int m = m0 + wave * 16 + rr;
-      xv[rr] = make_float4(0, 0, 0, 0);
-      if (act_lane && m < p.M) xv[rr] = *(const float4*)(p.x + (int64_t)m * C + lane * 4);
-    }
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = wave * 16 + rr;
-      const int m = m0 + row;
-      const float4 v = xv[rr];
-      const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)C;
-      float q = 0.f;
-      if (act_lane) { const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean; q = (a * a + b * b) + (c * c + d * d); }
-      const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
-      if (act_lane) {
-        float y0 = (v.x - mean) * rstd * g4.x + b4.x, y1 = (v.y - mean) * rstd * g4.y + b4.y;
-        float y2 = (v.z - mean) * rstd * g4.z + b4.z, y3 = (v.w - mean) * rstd * g4.w + b4.w;
-        if (m >= p.M) y0 = y1 = y2 = y3 = 0.f;
-        const int k = lane * 4, slab = k >> 6, chunk = (k & 63) >> 3;
-        const int off = slab * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + ((lane & 1) << 3);
-        *(uint2*)(sA + off) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
-      }
-    }
-  }
+  ln_block_to_tile<C>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, (p.dbg & 16) != 0,
+                      [&](int r) { const int m = m0 + r; return m < p.M ? m : -1; });
 
   // ---- wave roles: two groups of 4 waves (one wave of each group per SIMD), each owns 64 of the 128 token rows ----
   const int grp = wave >> 2, wg = wave & 3;
@@ -232,37 +205,36 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
 
   // ---- epilogue: acc2 -> per-wave LDS slab [32][C/2] fp32 -> + b2 + x -> out ----
   constexpr int WN = C / 2;
+  constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 32 at C = 256
+  constexpr int RPP = 64 / LPR;
+  constexpr int NPASS = 32 / RPP;
+  const int c0 = (lane % LPR) * 4;
+  const int n = wn * WN + c0;
+  const int mrow0 = m0 + (grp * 2 + wm) * 32 + lane / LPR;
   __syncthreads();
   float* sC = (float*)smem + wave * (32 * WN);
 #pragma unroll
   for (int t = 0; t < TN2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + t * 32 + lrow] = acc2[t][r];
-  __syncthreads();
-  constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 32 at C = 256
-  constexpr int RPP = 64 / LPR;
-  const int c0 = (lane % LPR) * 4;
-  const int n = wn * WN + c0;
+  // every residual row of this lane in flight at once (the accumulators are dead now): one exposed HBM round trip instead of
+  // NPASS / 4; the loads land while the slab is being synchronised
+  float4 xr[NPASS];
+#pragma unroll
+  for (int u = 0; u < NPASS; ++u) {
+    const int m = mrow0 + u * RPP;
+    xr[u] = make_float4(0, 0, 0, 0);
+    if (m < p.M && !(p.dbg & 32)) xr[u] = *(const float4*)(p.x + (int64_t)m * C + n);
+  }
   const float4 bias = *(const float4*)(p.b2 + n);
-  constexpr int NPASS = 32 / RPP;
+  // (no workgroup barrier: the slab is private to the wave)
 #pragma unroll
-  for (int p0 = 0; p0 < NPASS; p0 += 4) {          // 4 residual loads in flight per lane
-    float4 xr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int m = m0 + (grp * 2 + wm) * 32 + (p0 + u) * RPP + lane / LPR;
-      xr[u] = make_float4(0, 0, 0, 0);
-      if (p0 + u < NPASS && m < p.M) xr[u] = *(const float4*)(p.x + (int64_t)m * C + n);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = (p0 + u) * RPP + lane / LPR;
-      const int m = m0 + (grp * 2 + wm) * 32 + row;
-      if (p0 + u >= NPASS || m >= p.M) continue;
-      const float4 a4 = *(const float4*)(sC + row * WN + c0);
-      *(float4*)(p.out + (int64_t)m * C + n) =
-          make_float4(a4.x + bias.x + xr[u].x, a4.y + bias.y + xr[u].y, a4.z + bias.z + xr[u].z, a4.w + bias.w + xr[u].w);
-    }
+  for (int u = 0; u < NPASS; ++u) {
+    const int m = mrow0 + u * RPP;
+    if (m >= p.M || (p.dbg & 64)) continue;
+    const float4 a4 = *(const float4*)(sC + (u * RPP + lane / LPR) * WN + c0);
+    *(float4*)(p.out + (int64_t)m * C + n) =
+        make_float4(a4.x + bias.x + xr[u].x, a4.y + bias.y + xr[u].y, a4.z + bias.z + xr[u].z, a4.w + bias.w + xr[u].w);
   }
 #endif
 }
