@@ -18,6 +18,7 @@ Two extra objects on the JSON line:
   roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM: igemm256_kernel<2> where pd_igemm's heuristic picks the
                  256x256 tile, else igemm_kernel<128,128,64,2,false,2,...>): algorithmic FLOPs per launch / its average launch
                  duration measured here with HIP events, against the dense bf16 MFMA peak.
+  attention_block - the fused level-0 cuboid-attention block kernel, same measurement (second half of BASELINE.json's metric).
   cpu_baseline - the oracle (CPU restatement of the reference forward) timed on this box's host cores on a bounded
                  sample of the same workload (kind "port").
 """
@@ -53,36 +54,43 @@ def v1_model(precision, device):
     return ldm.to(device).eval()
 
 
-def conv3d_kernel_time(ldm, B, device, reps=3):
-    """Average duration (s) of the Conv3d implicit-GEMM launches of one denoiser forward, measured with HIP events on
-    the launch stream (eager mode: one event pair per launch)."""
+def kernel_times(ldm, B, device, reps=3):
+    """Average duration (s) of (a) the Conv3d implicit-GEMM launches and (b) the fused level-0 cuboid-attention block launches of
+    one denoiser forward, measured with HIP events on the launch stream (eager mode: one event pair per launch)."""
     from prediff_amd import _lib as L
     net = ldm.torch_nn_module
     z = torch.randn(ldm.get_batch_latent_shape(B), device=device)
     zc = torch.randn((B, 7, 16, 16, 64), device=device)
     t = torch.full((B,), 500, dtype=torch.long, device=device)
-    orig = L.igemm
-    pairs = []
+    orig_igemm, orig_attn = L.igemm, L.attn_block_fused
+    conv_pairs, attn_pairs = [], []
 
-    def timed(*a, **k):
+    def bracket(fn, store, a, k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*a, **k)
+        e1.record()
+        store.append((e0, e1))
+
+    def timed_igemm(*a, **k):
         if k.get("taps", 1) == 27:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(*a, **k)
-            e1.record()
-            pairs.append((e0, e1))
+            bracket(orig_igemm, conv_pairs, a, k)
         else:
-            orig(*a, **k)
+            orig_igemm(*a, **k)
+
+    def timed_attn(*a, **k):
+        bracket(orig_attn, attn_pairs, a, k)
     net(z, t, zc)
-    L.igemm = timed
+    L.igemm, L.attn_block_fused = timed_igemm, timed_attn
     try:
         for _ in range(reps):
             net(z, t, zc)
     finally:
-        L.igemm = orig
+        L.igemm, L.attn_block_fused = orig_igemm, orig_attn
     torch.cuda.synchronize(device)
-    total_ms = sum(a.elapsed_time(b) for a, b in pairs)
-    return total_ms * 1e-3 / len(pairs), len(pairs) // reps
+    conv_s = sum(a.elapsed_time(b) for a, b in conv_pairs) * 1e-3 / max(1, len(conv_pairs))
+    attn_s = sum(a.elapsed_time(b) for a, b in attn_pairs) * 1e-3 / max(1, len(attn_pairs)) if attn_pairs else None
+    return conv_s, len(conv_pairs) // reps, attn_s, len(attn_pairs) // reps
 
 
 def cpu_baseline(budget_s=15.0):
@@ -215,7 +223,7 @@ def main():
     if rank == 0:
         n_gpus = world
         value = n_gpus * B * args.steps / elapsed
-        ker_s, launches = conv3d_kernel_time(ldm, B, device)
+        ker_s, launches, attn_s, attn_launches = kernel_times(ldm, B, device)
         flops_per_launch = CONV3D_GFLOP_PER_STEP * 1e9 * B / CONV3D_LAUNCHES_PER_STEP
         achieved = flops_per_launch / ker_s / 1e12
         traffic = None
@@ -242,6 +250,13 @@ def main():
                          "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches,
                          "gflop_per_launch": round(flops_per_launch / 1e9, 3)},
         }
+        if attn_s:
+            # level-0 block: LN -> QKV (2*S*3C*C) -> core (4*S*vol*C) -> proj (2*S*C*C), S = 3328 tokens, C = 256, vol 13 or 16
+            gf = B * (2 * 3328 * 768 * 256 + 2 * 3328 * 256 * 256 + 4 * 3328 * 15 * 256) / 1e9
+            line["attention_block"] = {"kernel": "attn_block_kernel<256> (LN -> QKV -> cuboid attention -> proj -> +x, level 0)",
+                                       "achieved": round(gf / attn_s / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(gf / attn_s / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(attn_s * 1e6, 2),
+                                       "launches_per_step": attn_launches, "gflop_per_launch": round(gf, 3)}
         if not args.no_cpu_baseline and n_gpus == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

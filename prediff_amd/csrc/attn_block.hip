@@ -42,6 +42,9 @@ struct pd_attn_block_args_k {
   int B, ntok, nc, vol;
   float scale, eps;
   uint32_t wqkv_bytes, wp_bytes;
+  unsigned long long* trace;   // profiling only: per-phase clock stamps of wave 0 of workgroup 300 (null in production)
+  int dbg;   // profiling ablations: 1 no weight DMA after chunk 2, 2 no q/k/v GEMMs, 4 no attention core, 8 no proj GEMM,
+             // 16 no LN loads, 32 no residual loads, 64 no stores
 };
 
 template <int C>
@@ -66,6 +69,10 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   float* sBq = (float*)(sTok + BM);                // [3C] qkv bias (zeros without one): an ordinary global load inside the head loop
                                                    // would make hipcc drain the weight DMA queue (vmcnt(0)) at every use
 
+  if (p.dbg & 128) return;   // ablation: workgroup dispatch cost only
+  int tr_n = 0;
+#define TRACE() do { if (p.trace && blockIdx.x == 300 && threadIdx.x == 0) p.trace[tr_n] = clock64(); ++tr_n; } while (0)
+  TRACE();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,10 +123,12 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
     sBias[i] = (q < vol && k < vol) ? p.bias[((int64_t)h * vol + q) * vol + k] : 0.f;
   }
   __syncthreads();
+  TRACE();
 
   // ---- phase 0: LayerNorm of the gathered rows -> bf16 A tile (KS slabs of [128][64], chunk swizzle (row>>1)&7) ----
-  ln_block_to_tile<C>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, false, [&](int r) { return sTok[r]; });
+  ln_block_to_tile<C>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, (p.dbg & 16) != 0, [&](int r) { return sTok[r]; });
 
+  TRACE();
   // ---- wave roles ----
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int swz = (lrow >> 1) & 7;
@@ -153,19 +162,21 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   __syncthreads();                                        // A-tile region is now free: ring buffers 0 and 1
   issue_chunk(1);
   issue_chunk(2);
+  TRACE();
 
   const uint32_t q_lds = (uint32_t)(uintptr_t)sQ, k_lds = (uint32_t)(uintptr_t)sK, vt_lds = (uint32_t)(uintptr_t)sVT;
   const uint32_t bq_lds = (uint32_t)(uintptr_t)sBq;
   // end of a weight-chunk step: chunk s+1 has landed (chunk s+2 may stay in flight), everyone is done with chunk s, refill its buffer
   auto step_end = [&](int s) {
-    if (s + 2 < NCHUNK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS) : "memory");
+    if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + 3 < NCHUNK) issue_chunk(s + 3);
+    if (s + 3 < NCHUNK && !(p.dbg & 1)) issue_chunk(s + 3);
   };
 
   for (int h = 0; h < HEADS; ++h) {
+    TRACE();
     // ---------------- q and k: transposed products ----------------
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
@@ -174,6 +185,7 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
       f32x16 acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      if (!(p.dbg & 2))
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -202,12 +214,14 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
       step_end(s);
     }
     // ---------------- v: plain product, stored transposed ----------------
+    TRACE();
     {
       const int s = 4 * h + 2;
       const char* cW = ring(s);
       f32x16 acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      if (!(p.dbg & 2))
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -234,8 +248,9 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
       }
       step_end(s);
     }
+    TRACE();
     // ---------------- attention core: wave w = cuboid w of this workgroup ----------------
-    {
+    if (!(p.dbg & 4)) {
       const int q = lane & 15, g = lane >> 4;
       const int row = wave * 16 + q;
       const int rswz = (row >> 1) & 7;
@@ -246,6 +261,13 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
         const bf16x8 kf = *(const bf16x8*)(sK + row * 128 + pos);
         const bf16x8 qf = *(const bf16x8*)(sQ + row * 128 + pos);
         sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc4, 0, 0, 0);
+      }
+      // V^T fragments (lane: d = 16 i + q, keys 4g..4g+3) do not depend on the softmax: fetch them now, use them after it
+      s16x4 vf[HD / 16];
+#pragma unroll
+      for (int i = 0; i < HD / 16; ++i) {
+        const int d = 16 * i + q;
+        vf[i] = *(const s16x4*)(sVT + d * 256 + (((wave * 4 + g) ^ ((d & 15) << 1)) << 3));
       }
       // lane: query q, keys 4g .. 4g+3
       const float4 bq = *(const float4*)(sBias + h * 256 + q * 16 + 4 * g);
@@ -283,29 +305,36 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
         if (sc[r] <= -1e18f) v = 0.f;   // masked_softmax multiplies by the mask after the softmax
         pf[r] = (short)f2bf(v);
       }
-      // O^T[d][query] = sum_key V[key][d] P[query][key]: A = V^T (lane: d = d0 + q, keys 4g..4g+3), B = P^T
+      // O^T[d][query] = sum_key V[key][d] P[query][key]: A = V^T (lane: d = d0 + q, keys 4g..4g+3), B = P^T.
+      // The four MFMAs are independent: issue them back to back, wait once, then pack and store (one latency chain, not four).
+      f32x4 o[HD / 16];
 #pragma unroll
-      for (int d0 = 0; d0 < HD; d0 += 16) {
-        const int d = d0 + q;
-        const s16x4 vf = *(const s16x4*)(sVT + d * 256 + (((wave * 4 + g) ^ ((d & 15) << 1)) << 3));
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o, 0, 0, 0);
-        // the MFMA result goes straight into inline asm (v_cvt_pk_bf16_f32): hipcc's hazard recogniser does not look inside asm, so
-        // the XDL-write -> VALU-read wait states have to be spelled out (the "+v" ties keep this between the MFMA and the packs)
-        asm volatile("s_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-        // lane: query q, features d0 + 4g + (0..3) -> O tile (the Q tile: these 16 rows belong to this wave only)
-        const int dd = d0 + 4 * g;
-        const uint64_t pk = (uint64_t)(pack_bf16x2(o[0], o[1])) | ((uint64_t)(pack_bf16x2(o[2], o[3])) << 32);
+      for (int i = 0; i < HD / 16; ++i) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[i], pf, z, 0, 0, 0);
+      }
+      // the MFMA results go straight into inline asm (v_cvt_pk_bf16_f32): hipcc's hazard recogniser does not look inside asm, so
+      // the XDL-write -> VALU-read wait states have to be spelled out (the "+v" ties keep this between the MFMAs and the packs)
+      asm volatile("s_nop 15" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[0][3]), "+v"(o[1][0]), "+v"(o[1][1]), "+v"(o[1][2]),
+                   "+v"(o[1][3]), "+v"(o[2][0]), "+v"(o[2][1]), "+v"(o[2][2]), "+v"(o[2][3]), "+v"(o[3][0]), "+v"(o[3][1]), "+v"(o[3][2]),
+                   "+v"(o[3][3]));
+#pragma unroll
+      for (int i = 0; i < HD / 16; ++i) {
+        // lane: query q, features 16 i + 4g + (0..3) -> O tile (the Q tile: these 16 rows belong to this wave only)
+        const int dd = 16 * i + 4 * g;
+        const uint64_t pk = (uint64_t)(pack_bf16x2(o[i][0], o[i][1])) | ((uint64_t)(pack_bf16x2(o[i][2], o[i][3])) << 32);
         const int off = row * 128 + (((dd >> 3) ^ rswz) << 4) + ((dd & 7) << 1);
         asm volatile("ds_write_b64 %0, %1" ::"v"(q_lds + (uint32_t)off), "v"(pk) : "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                         // O_h visible to every wave (weight DMA stays in flight)
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // O_h visible to every wave (weight DMA stays in flight)
+    TRACE();
     // ---------------- proj: acc2 += O_h * Wp_h^T ----------------
     {
       const int s = 4 * h + 3;
       const char* cW = ring(s);
+      if (!(p.dbg & 8))
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
@@ -320,6 +349,7 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
     }
   }
 
+  TRACE();
   // ---- epilogue: acc2 -> per-wave LDS slab [32][C/2] fp32 -> + b_proj + x -> out rows of the token table ----
   constexpr int WN = C / 2;
   constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 32 at C = 256
@@ -339,18 +369,20 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   for (int u = 0; u < NPASS; ++u) {
     mrow[u] = sTok[wm * 32 + u * RPP + lane / LPR];
     xr[u] = make_float4(0, 0, 0, 0);
-    if (mrow[u] >= 0) xr[u] = *(const float4*)(p.x + (int64_t)mrow[u] * C + n);
+    if (mrow[u] >= 0 && !(p.dbg & 32)) xr[u] = *(const float4*)(p.x + (int64_t)mrow[u] * C + n);
   }
   float4 bias = make_float4(0, 0, 0, 0);
   if (p.bp) bias = *(const float4*)(p.bp + n);
   // (no workgroup barrier: the slab is private to the wave)
 #pragma unroll
   for (int u = 0; u < NPASS; ++u) {
-    if (mrow[u] < 0) continue;
+    if (mrow[u] < 0 || (p.dbg & 64)) continue;
     const float4 a4 = *(const float4*)(sC + (u * RPP + lane / LPR) * WN + c0);
     *(float4*)(p.out + (int64_t)mrow[u] * C + n) =
         make_float4(a4.x + bias.x + xr[u].x, a4.y + bias.y + xr[u].y, a4.z + bias.z + xr[u].z, a4.w + bias.w + xr[u].w);
   }
+  TRACE();
+#undef TRACE
 #endif
 }
 
@@ -375,6 +407,9 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   return PD_OK;
 }
 
+extern "C" int pd_attn_block_debug_flags = 0;
+extern "C" unsigned long long* pd_attn_block_trace = nullptr;   // profiling ablations only (scripts/bench_attn_block.py)
+
 extern "C" int pd_attn_block_fused_supported(int C, int heads, int vol) {
   return (C == 256 || C == 128) && heads * 64 == C && vol >= 1 && vol <= 16;
 }
@@ -393,6 +428,8 @@ extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamm
   a.B = B; a.ntok = ntok; a.nc = nc; a.vol = vol; a.scale = scale; a.eps = eps;
   a.wqkv_bytes = (uint32_t)((int64_t)3 * C * C * 2);
   a.wp_bytes = (uint32_t)((int64_t)C * C * 2);
+  a.dbg = pd_attn_block_debug_flags;
+  a.trace = pd_attn_block_trace;
   hipStream_t s = (hipStream_t)stream;
   if (C == 256) return launch_attn_block<256>(a, s);
   return launch_attn_block<128>(a, s);
