@@ -15,7 +15,7 @@ second over the whole job = gpus * batch * steps / wall (max over ranks).  Ranks
 frames, outside the step loop).
 
 Two extra objects on the JSON line:
-  roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM: igemm256_kernel<2> where pd_igemm's heuristic picks the
+  roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM: igemm256_kernel<2,8> where pd_igemm's heuristic picks the
                  256x256 tile, else igemm_kernel<128,128,64,2,false,2,...>): algorithmic FLOPs per launch / its average launch
                  duration measured here with HIP events, against the dense bf16 MFMA peak.
   attention_block - the fused level-0 cuboid-attention block kernel, same measurement (second half of BASELINE.json's metric).
@@ -38,7 +38,7 @@ PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI
 UNET_GFLOP_PER_STEP = 653.4        # one denoiser forward, one trajectory (2*MAC)
 CONV3D_GFLOP_PER_STEP = 376.9 + 14.9   # 32 TimeEmbedResBlock convs + first_proj
 CONV3D_LAUNCHES_PER_STEP = 34
-CONV3D_KERNEL_LABEL = "igemm256_kernel<2> | igemm_kernel<128,128,64,2,false,2,2,1> per launch (Conv3d 3x3x3 implicit GEMM)"
+CONV3D_KERNEL_LABEL = "igemm256_kernel<2,8> | igemm_kernel<128,128,64,2,false,2,2,1> per launch (Conv3d 3x3x3 implicit GEMM)"
 
 
 def v1_model(precision, device):

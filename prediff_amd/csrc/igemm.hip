@@ -10,7 +10,7 @@
 //     to the per-lane SOURCE address (which k-chunk a lane fetches) and undone by the ds_read_b128 address
 //     (cdna_hip_programming.md rule 21).  Out-of-image filter taps / M,N tails fetch from a zero page instead.
 //   * double-buffered LDS, one barrier per K-step: loads of step k+1 are in flight while the MFMAs of step k run.
-//   * v_mfma_f32_32x32x16_bf16, each wave owns (BM/2) x (BN/2) of the tile.
+//   * v_mfma_f32_16x16x32_bf16, each wave owns (BM/2) x (BN/2) of the tile.
 //   * epilogue in registers: alpha, bias, per-sample row vector (timestep embedding), activation, gate multiply,
 //     fp32 residual add, fp32 and/or bf16 (hi[/lo]) stores.
 //   * blockIdx -> tile mapping gives each XCD a contiguous range of tiles (A rows are then re-used out of that
@@ -52,8 +52,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
   constexpr int STAGE = (A_TILE + B_TILE) * NP;
   constexpr int AI = BM / RPI, BI = BN / RPI;     // DMA instructions per thread per tile
   constexpr int LPS = (AI + BI) * NP;             // DMA instructions per thread per stage
-  constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave
-  constexpr int KSUB = BK / 16;                   // MFMA k-substeps per stage
+  constexpr int KSUB = BK / 32;                   // MFMA k-steps (32 deep) per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -149,20 +148,22 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
     }
   };
 
-  // ---- accumulators ----
-  f32x16 acc[TM][TN];
+  // ---- accumulators: 16 x 16 MFMA tiles (v_mfma_f32_16x16x32_bf16: half-length MFMAs interleave better with the fragment reads
+  //      than 32x32x16 and leave no dependent issue pairs -- +12 % on the 256 x 256 kernel, same LDS traffic) ----
+  constexpr int TM16 = BM / 32, TN16 = BN / 32;   // 16-row / 16-column tiles per wave (wave tile BM/2 x BN/2)
+  f32x4 acc[TM16][TN16];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM16; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN16; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
   const int wr = wave >> 1, wc = wave & 1;
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  const int swz = (CPR == 8) ? ((lrow >> 1) & 7) : ((lrow >> 2) & 3);
-  const int a_row_b = (wr * (BM / 2) + lrow) * ROWB;   // byte offset of this lane's row in the A tile
-  const int b_row_b = (wc * (BN / 2) + lrow) * ROWB;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int swz = (CPR == 8) ? ((l16 >> 1) & 7) : ((l16 >> 2) & 3);
+  const int a_row_b = (wr * (BM / 2) + l16) * ROWB;   // byte offset of this lane's row in the A tile
+  const int b_row_b = (wc * (BN / 2) + l16) * ROWB;
 
   // ---- software pipeline: stages ks+1 .. ks+NS-1 are in flight while stage ks is consumed ----
   constexpr int D = NS - 1;
@@ -181,28 +182,28 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
     const char* sA = smem + stage * STAGE;
     const char* sB = sA + A_TILE * NP;
 #pragma unroll
-    for (int kk = 0; kk < KSUB; ++kk) {
-      const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-      bf16x8 a[TM], b[TN], al[TM], bl[TN];
+    for (int kk = 0; kk < KSUB; ++kk) {                 // 32-deep k-steps
+      const int pos = ((kk * 4 + lg) ^ swz) * 16;
+      bf16x8 a[TM16], b[TN16], al[TM16], bl[TN16];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        a[i] = *(const bf16x8*)(sA + a_row_b + i * 32 * ROWB + pos);
-        if (SPLIT) al[i] = *(const bf16x8*)(sA + A_TILE + a_row_b + i * 32 * ROWB + pos);
+      for (int i = 0; i < TM16; ++i) {
+        a[i] = *(const bf16x8*)(sA + a_row_b + i * 16 * ROWB + pos);
+        if (SPLIT) al[i] = *(const bf16x8*)(sA + A_TILE + a_row_b + i * 16 * ROWB + pos);
       }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        b[j] = *(const bf16x8*)(sB + b_row_b + j * 32 * ROWB + pos);
-        if (SPLIT) bl[j] = *(const bf16x8*)(sB + B_TILE + b_row_b + j * 32 * ROWB + pos);
+      for (int j = 0; j < TN16; ++j) {
+        b[j] = *(const bf16x8*)(sB + b_row_b + j * 16 * ROWB + pos);
+        if (SPLIT) bl[j] = *(const bf16x8*)(sB + B_TILE + b_row_b + j * 16 * ROWB + pos);
       }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM16; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN16; ++j) {
           if (SPLIT) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
@@ -211,18 +212,18 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
   // ---- epilogue: accumulators -> per-wave LDS slab (row major, ESLAB column slabs in turn) -> coalesced 16 B row segments ----
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int WNS = WN / ESLAB;                  // columns staged at a time
-  constexpr int TNS = TN / ESLAB;
+  constexpr int TNS = TN16 / ESLAB;                // 16-column tiles staged at a time
   float* sC = (float*)smem + wave * (WM * WNS);
 #pragma unroll
   for (int js = 0; js < ESLAB; ++js) {
     __syncthreads();                               // operand stages (js == 0) / previous slab (js > 0) are no longer read
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM16; ++i)
 #pragma unroll
       for (int j = 0; j < TNS; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * WNS + j * 32 + lrow] = acc[i][js * TNS + j][r];
+        for (int r = 0; r < 4; ++r)
+          sC[(i * 16 + 4 * lg + r) * WNS + j * 16 + l16] = acc[i][js * TNS + j][r];
     __syncthreads();
     igemm_epilogue<WM, WNS>(p, sC, lane, m0 + wr * WM, p.M, n0 + wc * WN + js * WNS, bz);
   }
@@ -314,13 +315,13 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     // measured on MI355X (scripts/bench_igemm.py): with <= 4 K-steps the 4-workgroups/CU variant (BK 32, 32 KB LDS) hides the
     // prologue/epilogue of its neighbours best; longer K prefers the BK 64 two-stage tile.
     tile = t128 >= 192 ? ((!a.split && (int64_t)a.taps * a.Cin <= 256) ? 5 : PD_BIG_TILE_DEFAULT) : 2;
-    // long K: the 256 x 256 eight-wave kernel does a round of 256 tiles (one per CU of the MI355X) in ~1.9x the time the
-    // 128 x 128 kernel needs for a round of 512 (two per CU) inside the sampling loop (1.75x in a cold micro-benchmark) -- twice
-    // the work; take it when its whole rounds are the cheaper ones (A/B at 16/32/39/64 trajectories: +1.1/+1.5/+2.9/-1.6 %)
+    // long K: the 256 x 256 eight-wave kernel does a round of 256 tiles (one per CU of the MI355X) in ~1.65x the time the
+    // 128 x 128 kernel needs for a round of 512 (two per CU) inside the sampling loop -- twice the work; take it when its whole
+    // rounds are the cheaper ones (Conv3d at 32 trajectories: 317 us in 2 rounds against 385 us in 4)
     if (tile == PD_BIG_TILE_DEFAULT && !pd_igemm_disable_256 && !a.split && (int64_t)a.taps * a.Cin >= 1024 && pd_igemm256_supported(a, kind)) {
       const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.nbatch > 0 ? a.nbatch : 1);
       const int64_t r128 = (t128 + 511) / 512, r256 = (t256 + 255) / 256;
-      if (r256 * 19 <= r128 * 10) tile = 7;
+      if (r256 * 33 <= r128 * 20) tile = 7;
     }
   }
   if (a.split && tile == 4) tile = 1;   // 3 x 64 KB stages do not fit

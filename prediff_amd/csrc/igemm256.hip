@@ -1,10 +1,12 @@
-// pd_igemm, long-K variant: 256 x 256 x 64 tile, 8 waves (2 x 4), one workgroup per CU, bf16 MFMA 32x32x16, fp32 accumulate.
+// pd_igemm, long-K variant: 256 x 256 x 64 tile, 8 waves (2 x 4), one workgroup per CU, bf16 MFMA 16x16x32, fp32 accumulate.
 //
 // The 128 x 128 two-barrier kernel in igemm.hip tops out near 0.9-1.0 PFLOP/s whatever its pipeline depth; this variant is
 // built around the structure that removes that ceiling (cdna_hip_programming.md "256^2 8-phase"):
-//   * each wave owns 128 x 64 of the tile (4 x 2 MFMA tiles, 128 accumulator registers) -> 2/3 of the LDS bytes per MFMA;
-//   * every K-tile (64 deep) is consumed in 4 phases of 8 MFMAs (one 64 x 32 quadrant, K = 64 each); a phase is
-//     [ds_read of the fragments it adds | DMA issue] s_barrier [8 MFMAs] s_barrier;
+//   * each wave owns 128 x 64 of the tile (8 x 4 MFMA tiles of 16 x 16, 128 accumulator registers) -> 2/3 of the LDS bytes per
+//     MFMA; 16x16x32 tiles measured 12 % faster than 32x32x16 here (388 vs 441 us on the level-0 Conv3d, 1.25 vs 1.09 PFLOP/s on
+//     a 4096^3 GEMM): half-length MFMAs interleave better with the fragment reads and leave no dependent issue pairs;
+//   * every K-tile (64 deep) is consumed in 4 phases of 16 MFMAs (one 64 x 32 quadrant, K = 64 each); a phase is
+//     [ds_read of the fragments it adds | DMA issue] s_barrier [16 MFMAs] s_barrier;
 //   * the two wave rows run ONE barrier apart (wave row 1 takes an extra s_barrier before the loop, wave row 0 one after),
 //     so the two waves that share a SIMD alternate: one is in its MFMA section while the other reads LDS / issues DMA;
 //   * operands arrive by buffer_load ... lds DMA (16 B/lane) as 128-row x 128-B half tiles (A half 0 / 1 is read only by wave
@@ -47,15 +49,15 @@ constexpr int KBUF = 4 * HT;    // one K-tile buffer: A half 0, A half 1, W half
 
 }
 
-// 8 MFMAs of one quadrant: 2 row tiles x 4 k-substeps, accumulators alternate so that no MFMA waits on its predecessor
-#define QUAD_MFMA(accA, accB, bfrag)                                                       \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                       \
-    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][kk], bfrag[kk], accA, 0, 0, 0);    \
-    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][kk], bfrag[kk], accB, 0, 0, 0);    \
-  }
-
-template <int KIND>
+// RT = row tiles (of 16) per wave row: 8 -> the 256-row tile.  RT = 7 gives a 208-row tile (wave row 1 = rows 96-207, the 16
+// shared rows computed twice and stored once) that turns the 416 / 208 tiles of the SEVIR-LR convolutions at 32 trajectories
+// (M = trajectories * 13 * H * W) into exactly 512 / 256 -- measured: identical launch times (388 vs 391 us, 318 vs 318 us), once
+// more because a phase is bound by its barrier pair, LDS reads and the W stream, not by its MFMA count; only RT = 8 is built.
+template <int KIND, int RT>
 __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
+  constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
+  constexpr int ROW1 = BM - 16 * RT;              // first tile row of wave row 1 (128 for RT = 8, 96 for RT = 7)
+  constexpr int RA0 = 4, RA1 = RT - 4;            // row tiles of the two A sub-halves
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -65,14 +67,14 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 
   // ---- XCD-aware tile id (bijective for any tile count) ----
   const int tiles_n = (p.N + 255) >> 8;
-  const int tiles_m = (p.M + 255) >> 8;
+  const int tiles_m = (p.M + BM - 1) / BM;
   const int nt = tiles_m * tiles_n;
   int t;
   {
     const int bid = blockIdx.x, xcd = bid & 7, q = nt >> 3, r = nt & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int m0 = (t / tiles_n) << 8;
+  const int m0 = (t / tiles_n) * BM;
   const int n0 = (t % tiles_n) << 8;
   const int bz = blockIdx.z;
 
@@ -89,8 +91,9 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int m = m0 + hh * 128 + i * 64 + srow;
-      const bool ok = m < p.M;
+      const int rloc = i * 64 + srow;                                     // row inside the half (16 * RT rows are used)
+      const int m = m0 + hh * ROW1 + rloc;
+      const bool ok = m < p.M && rloc < 16 * RT && m < m0 + BM;
       if (KIND == 0) {
         aoff[hh][i] = ok ? ((uint32_t)m * (uint32_t)p.lda + schunk * 8) * 2u : PD_OOB;
       } else {
@@ -150,19 +153,19 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     if (++w_kc == kchunks) { w_kc = 0; w_tap_b += w_tap_stride_b; }
   };
 
-  f32x16 acc[4][2];
+  f32x4 acc[RT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  const int swz = (lrow >> 1) & 7;
-  // fragment addresses inside a K-tile buffer: + row-tile * (32 * 128); the 16 B slot of k-substep kk is ((kk*2 + lhalf) ^ swz)
-  const int a_rd = wr * HT + lrow * 128;
-  const int b_rd = (2 + (wc >> 1)) * HT + ((wc & 1) * 64 + lrow) * 128;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int swz = (l16 >> 1) & 7;
+  // fragment addresses inside a K-tile buffer: + tile * (16 * 128); the 16 B slot of k-step ks (32 deep) is ((ks*4 + lg) ^ swz)
+  const int a_rd = wr * HT + l16 * 128;
+  const int b_rd = (2 + (wc >> 1)) * HT + ((wc & 1) * 64 + l16) * 128;
 
   // ---- prologue: K-tile 0 (A + W) and W of K-tile 1 ----
   if (nk > 0) {
@@ -181,49 +184,59 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
   __builtin_amdgcn_sched_barrier(0);
 
-  bf16x8 a[2][4], b0[4], b1[4];
+  bf16x8 a[4][2], b0[2][2], b1[2][2];
+  // one quadrant: NR row tiles x 2 column tiles x K = 64 (two k-steps); consecutive MFMAs hit different accumulators
+#define QUAD16(NR, R0, C0, bfrag)                                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < (NR); ++i)                                                                      \
+      _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                       \
+        acc[(R0) + i][(C0) + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bfrag[c][ks], acc[(R0) + i][(C0) + c], 0, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const char* sA = smem + cur * KBUF + a_rd;
     const char* sB = smem + cur * KBUF + b_rd;
     const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
 
-    // ---------- phase 0: W tile 0, A row tiles 0-1; quadrant (A0, W0) ----------
+    // ---------- phase 0: W column tiles 0-1, A row tiles 0-3; quadrant (A0, W0) ----------
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) b0[kk] = *(const bf16x8*)(sB + (((kk * 2 + lhalf) ^ swz) * 16));
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int ks = 0; ks < 2; ++ks) b0[c][ks] = *(const bf16x8*)(sB + c * (16 * 128) + (((ks * 4 + lg) ^ swz) * 16));
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) a[i][kk] = *(const bf16x8*)(sA + i * (32 * 128) + (((kk * 2 + lhalf) ^ swz) * 16));
+    for (int i = 0; i < RA0; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[i][ks] = *(const bf16x8*)(sA + i * (16 * 128) + (((ks * 4 + lg) ^ swz) * 16));
     if (more1) issue_a(0, cur ^ 1);
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
-    QUAD_MFMA(acc[0][0], acc[1][0], b0)
+    QUAD16(RA0, 0, 0, b0)
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
 
-    // ---------- phase 1: W tile 1; quadrant (A0, W1) ----------
+    // ---------- phase 1: W column tiles 2-3; quadrant (A0, W1) ----------
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) b1[kk] = *(const bf16x8*)(sB + 32 * 128 + (((kk * 2 + lhalf) ^ swz) * 16));
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b1[c][ks] = *(const bf16x8*)(sB + (2 + c) * (16 * 128) + (((ks * 4 + lg) ^ swz) * 16));
     if (more1) { issue_a(1, cur ^ 1); next_a(); }
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
-    QUAD_MFMA(acc[0][1], acc[1][1], b1)
+    QUAD16(RA0, 0, 2, b1)
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
 
-    // ---------- phase 2: A row tiles 2-3; quadrant (A1, W1) ----------
+    // ---------- phase 2: A row tiles 4 .. RT-1; quadrant (A1, W1) ----------
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RA1; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) a[i][kk] = *(const bf16x8*)(sA + (2 + i) * (32 * 128) + (((kk * 2 + lhalf) ^ swz) * 16));
+      for (int ks = 0; ks < 2; ++ks) a[i][ks] = *(const bf16x8*)(sA + (RA0 + i) * (16 * 128) + (((ks * 4 + lg) ^ swz) * 16));
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
-    QUAD_MFMA(acc[2][1], acc[3][1], b1)
+    QUAD16(RA1, RA0, 2, b1)
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
 
-    // ---------- phase 3: nothing to read (W tile 0 is still in registers); quadrant (A1, W0); W of kt+2; wait for kt+1 ----------
+    // ---------- phase 3: nothing to read (W tiles 0-1 are still in registers); quadrant (A1, W0); W of kt+2; wait for kt+1 ----------
     if (more2) {
       issue_w(cur);
       VMCNT(4);
@@ -232,43 +245,52 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     }
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
-    QUAD_MFMA(acc[2][0], acc[3][0], b0)
+    QUAD16(RA1, RA0, 0, b0)
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
   }
+#undef QUAD16
   if (wr == 0) __builtin_amdgcn_s_barrier();   // re-join the two wave rows
 
   // ---- epilogue: two 32-column slabs per wave (8 waves x 128 x 32 fp32 = 128 KB = the operand buffers) ----
   float* sC = (float*)smem + wave * (128 * 32);
-  const int m_base = m0 + wr * 128;
+  // wave row 1 starts ROW1 rows into the tile; when the two wave rows overlap (RT = 7) it leaves the shared rows to wave row 0
+  constexpr int SKIP1 = 16 * RT - ROW1 > 0 ? 16 * RT - ROW1 : 0;
+  const int skip = wr == 1 ? SKIP1 : 0;
+  const int m_base = m0 + wr * ROW1 + skip;
+  const int m_end = min(p.M, m0 + (wr == 0 ? 16 * RT : BM));
 #pragma unroll
   for (int js = 0; js < 2; ++js) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 32 + lrow] = acc[i][js][r];
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sC[(i * 16 + 4 * lg + r) * 32 + c * 16 + l16] = acc[i][js * 2 + c][r];
     __syncthreads();
-    igemm_epilogue<128, 32>(p, sC, lane, m_base, p.M, n0 + wc * 64 + js * 32, bz);
+    igemm_epilogue<128, 32>(p, sC + skip * 32, lane, m_base, m_end, n0 + wc * 64 + js * 32, bz);
   }
 #endif
 }
 
-template <int KIND>
+
+template <int KIND, int RT>
 static int launch256(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
+  constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + 255) / 256);
   dim3 grid(tiles, 1, a.nbatch > 0 ? a.nbatch : 1);
-  hipLaunchKernelGGL((igemm256_kernel<KIND>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((igemm256_kernel<KIND, RT>), grid, dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -282,5 +304,5 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind) {
 }
 
 int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s) {
-  return kind == 0 ? launch256<0>(a, s) : launch256<2>(a, s);
+  return kind == 0 ? launch256<0, 8>(a, s) : launch256<2, 8>(a, s);
 }

@@ -13,7 +13,7 @@ out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmcb/{c}/*counter_collection.csv")
     def is_conv3d(name):   # igemm256_kernel<2> or igemm_kernel<BM, BN, BK, NS, SPLIT, 2, ...>
-        if "igemm256_kernel<2>" in name:
+        if "igemm256_kernel<2" in name:
             return True
         return "igemm_kernel<" in name and name.split("<")[1].split(">")[0].split(",")[5].strip() == "2"
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if is_conv3d(r["Kernel_Name"])]

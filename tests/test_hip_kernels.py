@@ -41,7 +41,7 @@ def padded_bf16(x2d, split=False):
                                         (300, 130, 64, 4), (512, 256, 2048, 3), (512, 256, 2048, 4),
                                         (3328, 768, 256, 5), (1000, 200, 96, 5), (300, 130, 64, 6), (512, 256, 2048, 6), (3328, 768, 256, 6),
                                         (3328, 768, 256, 7), (1000, 200, 96, 7), (300, 130, 64, 7), (512, 256, 2048, 7), (37, 5, 32, 7),
-                                        (2048, 512, 192, 7), (106496, 256, 128, 7), (26624, 512, 64, 7), (9000, 300, 64, 7)])
+                                        (2048, 512, 192, 7), (106496, 256, 128, 7), (26624, 512, 64, 7), (9000, 300, 64, 7), (209, 256, 64, 7), (415, 256, 64, 7)])
 @pytest.mark.parametrize("split", [False, True])
 def test_igemm_linear(M, N, K, tile, split):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
