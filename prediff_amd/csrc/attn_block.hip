@@ -149,16 +149,24 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                        // A tile written by all waves; chunk 0 landed
-  bf16x8 areg[KS * 4];
+  // 16x16x32 fragments: [row tile of 16 (2)][k-step of 32 (C/32)]; lane = (row l16, 8-element k group lg)
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int swz16 = (l16 >> 1) & 7;
+  bf16x8 areg[2][KS * 2];
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+  for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) areg[s * 4 + kk] = *(const bf16x8*)(sA + s * (BM * 128) + g1_a_row + (((kk * 2 + lhalf) ^ swz) * 16));
-  // validity of this lane's slots: q/k tiles = its own row; v tile = 16 rows tq*32 + 8g + 4*lhalf + (0..3)
-  const bool row_ok = sTok[tq * 32 + lrow] >= 0;
+    for (int ks = 0; ks < KS * 2; ++ks)
+      areg[tt][ks] = *(const bf16x8*)(sA + (ks >> 1) * (BM * 128) + (tq * 32 + tt * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+  // validity of this lane's slots: q/k tiles = rows tq*32 + 16 tt + l16; v tile = rows tq*32 + 16 tt + 4 lg + (0..3)
+  bool row_ok[2];
   uint32_t vrow_ok = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) vrow_ok |= (sTok[tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf] >= 0 ? 1u : 0u) << r;
+  for (int tt = 0; tt < 2; ++tt) {
+    row_ok[tt] = sTok[tq * 32 + tt * 16 + l16] >= 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vrow_ok |= (sTok[tq * 32 + tt * 16 + 4 * lg + r] >= 0 ? 1u : 0u) << (tt * 4 + r);
+  }
   __syncthreads();                                        // A-tile region is now free: ring buffers 0 and 1
   issue_chunk(1);
   issue_chunk(2);
@@ -182,34 +190,44 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
     for (int kind = 0; kind < 2; ++kind) {
       const int s = 4 * h + kind;
       const char* cW = ring(s);
-      f32x16 acc1;
+      // 2 x 2 tiles of 16 x 16 (feature tile dt x slot tile tt): four independent accumulator chains in 16 registers
+      f32x4 acc1[2][2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc1[dt][tt][r] = 0.f;
       if (!(p.dbg & 2))
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS * 2; ++ks) {
+        bf16x8 w[2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const bf16x8 w = *(const bf16x8*)(cW + ks * 8192 + g1_w_row + (((kk * 2 + lhalf) ^ swz) * 16));
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, areg[ks * 4 + kk], acc1, 0, 0, 0);
-        }
-      // lane: slot row tq*32 + lrow, features tn*32 + 8g + 4*lhalf + (0..3) for g = 0..3
-      const int trow = tq * 32 + lrow;
-      const int tswz = (trow >> 1) & 7;
+        for (int dt = 0; dt < 2; ++dt)
+          w[dt] = *(const bf16x8*)(cW + (ks >> 1) * 8192 + (tn * 32 + dt * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) acc1[dt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[dt], areg[tt][ks], acc1[dt][tt], 0, 0, 0);
+      }
+      // tile (dt, tt): lane = slot row tq*32 + 16 tt + l16, features tn*32 + 16 dt + 4 lg + (0..3)
       const uint32_t t_lds = kind == 0 ? q_lds : k_lds;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = tn * 32 + 8 * g + 4 * lhalf;
+      for (int dt = 0; dt < 2; ++dt) {
+        const int d = tn * 32 + dt * 16 + 4 * lg;
         f32x4 bb;   // opaque LDS read (+ its wait): see the note at the ds_write below
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bb) : "v"(bq_lds + (uint32_t)((kind * C + h * HD + d) * 4)) : "memory");
-        float v0 = acc1[4 * g] + bb[0], v1 = acc1[4 * g + 1] + bb[1];
-        float v2 = acc1[4 * g + 2] + bb[2], v3 = acc1[4 * g + 3] + bb[3];
-        if (!row_ok) v0 = v1 = v2 = v3 = 0.f;                 // a padded slot is a zero token (as in the un-fused path)
-        const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
-        const int off = trow * 128 + (((d >> 3) ^ tswz) << 4) + ((d & 7) << 1);
-        // opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell that the tiles and
-        // the DMA destinations are disjoint LDS regions), which would serialise the prefetch at every step
-        asm volatile("ds_write_b64 %0, %1" ::"v"(t_lds + (uint32_t)off), "v"(pk) : "memory");
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int trow = tq * 32 + tt * 16 + l16;
+          float v0 = acc1[dt][tt][0] + bb[0], v1 = acc1[dt][tt][1] + bb[1], v2 = acc1[dt][tt][2] + bb[2], v3 = acc1[dt][tt][3] + bb[3];
+          if (!row_ok[tt]) v0 = v1 = v2 = v3 = 0.f;             // a padded slot is a zero token (as in the un-fused path)
+          const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
+          const int off = trow * 128 + (((d >> 3) ^ ((trow >> 1) & 7)) << 4) + ((d & 7) << 1);
+          // opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell that the tiles and
+          // the DMA destinations are disjoint LDS regions), which would serialise the prefetch at every step
+          asm volatile("ds_write_b64 %0, %1" ::"v"(t_lds + (uint32_t)off), "v"(pk) : "memory");
+        }
       }
       step_end(s);
     }
@@ -218,33 +236,43 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
     {
       const int s = 4 * h + 2;
       const char* cW = ring(s);
-      f32x16 acc1;
+      f32x4 acc1[2][2];                                        // [slot tile tt][feature tile dt]
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc1[tt][dt][r] = 0.f;
       if (!(p.dbg & 2))
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS * 2; ++ks) {
+        bf16x8 w[2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const bf16x8 w = *(const bf16x8*)(cW + ks * 8192 + g1_w_row + (((kk * 2 + lhalf) ^ swz) * 16));
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[ks * 4 + kk], w, acc1, 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt)
+          w[dt] = *(const bf16x8*)(cW + (ks >> 1) * 8192 + (tn * 32 + dt * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) acc1[tt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[tt][ks], w[dt], acc1[tt][dt], 0, 0, 0);
+      }
+      // tile (tt, dt): lane = feature d = tn*32 + 16 dt + l16, slot rows tq*32 + 16 tt + 4 lg + (0..3)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int d = tn * 32 + dt * 16 + l16;
+        float bv;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bv) : "v"(bq_lds + (uint32_t)((2 * C + h * HD + d) * 4)) : "memory");
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          float v0 = acc1[tt][dt][0] + bv, v1 = acc1[tt][dt][1] + bv, v2 = acc1[tt][dt][2] + bv, v3 = acc1[tt][dt][3] + bv;
+          if (!((vrow_ok >> (4 * tt)) & 1u)) v0 = 0.f;
+          if (!((vrow_ok >> (4 * tt + 1)) & 1u)) v1 = 0.f;
+          if (!((vrow_ok >> (4 * tt + 2)) & 1u)) v2 = 0.f;
+          if (!((vrow_ok >> (4 * tt + 3)) & 1u)) v3 = 0.f;
+          const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
+          const int c4 = tq * 8 + tt * 4 + lg;                                     // 4-row chunk of the [d][128 rows] tile
+          const int off = d * 256 + ((c4 ^ ((d & 15) << 1)) << 3);                 // chunk XOR: conflict-free 8 B reads by (d, 4-row group)
+          asm volatile("ds_write_b64 %0, %1" ::"v"(vt_lds + (uint32_t)off), "v"(pk) : "memory");
         }
-      // lane: feature d = tn*32 + lrow, slot rows tq*32 + 8g + 4*lhalf + (0..3) for g = 0..3
-      const int d = tn * 32 + lrow;
-      float bv;
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bv) : "v"(bq_lds + (uint32_t)((2 * C + h * HD + d) * 4)) : "memory");
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float v0 = acc1[4 * g] + bv, v1 = acc1[4 * g + 1] + bv;
-        float v2 = acc1[4 * g + 2] + bv, v3 = acc1[4 * g + 3] + bv;
-        if (!((vrow_ok >> (4 * g)) & 1u)) v0 = 0.f;
-        if (!((vrow_ok >> (4 * g + 1)) & 1u)) v1 = 0.f;
-        if (!((vrow_ok >> (4 * g + 2)) & 1u)) v2 = 0.f;
-        if (!((vrow_ok >> (4 * g + 3)) & 1u)) v3 = 0.f;
-        const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
-        const int c4 = tq * 8 + 2 * g + lhalf;                                   // 4-row chunk of the [d][128 rows] tile
-        const int off = d * 256 + ((c4 ^ ((d & 15) << 1)) << 3);                 // chunk XOR: conflict-free 8 B reads by (d, 4-row group)
-        asm volatile("ds_write_b64 %0, %1" ::"v"(vt_lds + (uint32_t)off), "v"(pk) : "memory");
       }
       step_end(s);
     }
