@@ -38,6 +38,7 @@ struct pd_ffn_args_k {
   int M, Hd, act;
   float eps;
   uint32_t w1_bytes, w2_bytes;
+  unsigned long long* trace;   // profiling only: per-slot clock stamps of waves 0 and 4 of workgroup 300 (null in production)
   int dbg;   // profiling ablations: 1 no weight DMA after chunk 0, 2 no GEMM-1, 4 no activation + H store, 8 no GEMM-2,
              // 16 no LN loads, 32 no residual loads, 64 no stores
 };
@@ -149,32 +150,45 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
     const int j = sl >> 1;
     if (sl >= 0 && !(sl & 1)) {
       // ---- MFMA slot: GEMM-2 of chunk j-1 (acc2 += H_{j-1} * W2_{j-1}^T), then GEMM-1 of chunk j (H_j^T = W1_j * A^T) ----
-      if (j >= 1 && !(p.dbg & 8)) {
-        const char* cW2 = w2buf((j - 1) & 1);
+      // explicit two-deep fragment pipeline: left to itself hipcc re-uses one register set per MFMA pair, so every pair waits for
+      // a full LDS round trip (GEMM-2 took ~1600 clocks for 512 clocks of MFMA work)
+      const bool do2 = j >= 1 && !(p.dbg & 8), do1 = j < NJ;
+      const char* cW2 = w2buf((j - 1) & 1);
+      const char* cW1 = w1buf(j & 1);
+      bf16x8 fa[2], fb[2][TN2], fw[2][4];
+      auto load2 = [&](int kk, int buf) {
+        const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
+        fa[buf] = *(const bf16x8*)(sHg + g2_a_row + pos);
+#pragma unroll
+        for (int t = 0; t < TN2; ++t) fb[buf][t] = *(const bf16x8*)(cW2 + g2_b_row + t * 32 * 128 + pos);
+      };
+      auto load1 = [&](int ks, int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fw[buf][kk] = *(const bf16x8*)(cW1 + ks * 8192 + g1_a_row + (((kk * 2 + lhalf) ^ swz) * 16));
+      };
+      if (do2) load2(0, 0);
+      if (do2) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-          const bf16x8 a = *(const bf16x8*)(sHg + g2_a_row + pos);
+          if (kk < 3) load2(kk + 1, (kk + 1) & 1);
+          else if (do1) load1(0, 0);
 #pragma unroll
-          for (int t = 0; t < TN2; ++t) {
-            const bf16x8 b = *(const bf16x8*)(cW2 + g2_b_row + t * 32 * 128 + pos);
-            acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[t], 0, 0, 0);
-          }
+          for (int t = 0; t < TN2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][t], acc2[t], 0, 0, 0);
         }
+      } else if (do1) {
+        load1(0, 0);
       }
-      if (j < NJ) {
-        const char* cW1 = w1buf(j & 1);
+      if (do1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
         if (!(p.dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+          if (ks + 1 < KS) load1(ks + 1, (ks + 1) & 1);
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
-            const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-            const bf16x8 a = *(const bf16x8*)(cW1 + ks * 8192 + g1_a_row + pos);
-            if (kk & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, areg[ks * 4 + kk], acc1b, 0, 0, 0);
-            else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, areg[ks * 4 + kk], acc1, 0, 0, 0);
+            if (kk & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][kk], areg[ks * 4 + kk], acc1b, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][kk], areg[ks * 4 + kk], acc1, 0, 0, 0);
           }
         }
       }
@@ -198,9 +212,12 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
         asm volatile("ds_write_b64 %0, %1" ::"v"(h_lds + (uint32_t)off), "v"(pk) : "memory");
       }
     }
+    if (p.trace && blockIdx.x == 300 && (tid & 255) == 0) p.trace[256 + (tid >> 8) * 64 + s] = clock64();              // before the DMA wait
     if (s & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights issued in slot s-1 (first read in slot s+1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (p.trace && blockIdx.x == 300 && (tid & 255) == 0) p.trace[(tid >> 8) * 128 + 2 * s] = clock64();       // work of the slot done
     __builtin_amdgcn_s_barrier();
+    if (p.trace && blockIdx.x == 300 && (tid & 255) == 0) p.trace[(tid >> 8) * 128 + 2 * s + 1] = clock64();   // barrier passed
   }
 
   // ---- epilogue: acc2 -> per-wave LDS slab [32][C/2] fp32 -> + b2 + x -> out ----
@@ -258,7 +275,8 @@ static int launch_ffn(const pd_ffn_args_k& a, hipStream_t s) {
   return PD_OK;
 }
 
-extern "C" int pd_ffn_debug_flags = 0;   // profiling ablations only (scripts/bench_ffn.py)
+extern "C" int pd_ffn_debug_flags = 0;
+extern "C" unsigned long long* pd_ffn_trace = nullptr;   // profiling ablations only (scripts/bench_ffn.py)
 
 extern "C" int pd_ffn_fused_supported(int C, int Hd) {
   return (C == 64 || C == 128 || C == 256) && Hd > 0 && Hd % 64 == 0 && Hd <= 3072;   // LDS: 144 KB tiles + 4*Hd bytes of bias
@@ -275,6 +293,7 @@ extern "C" int pd_ffn_fused(const float* x, float* out, const float* gamma, cons
   a.w1_bytes = (uint32_t)((int64_t)Hd * C * 2);
   a.w2_bytes = (uint32_t)((int64_t)C * Hd * 2);
   a.dbg = pd_ffn_debug_flags;
+  a.trace = pd_ffn_trace;
   hipStream_t s = (hipStream_t)stream;
 #define PD_FFN(ACT)                                  \
   if (C == 256) return launch_ffn<256, ACT>(a, s);   \

@@ -21,3 +21,19 @@ for B in (16, 32):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
     print(f"[dbg {dbg.value}] ffn_fused L0 B={B}: {us:.1f} us  {4.0 * M * C * Hd / us / 1e6:.1f} TFLOP/s")
+
+# per-slot clock stamps (waves 0 and 4 of workgroup 300): work time and barrier wait of every slot
+tr = torch.zeros(512, dtype=torch.int64, device="cuda")
+ctypes.c_void_p.in_dll(L.lib(), "pd_ffn_trace").value = tr.data_ptr()
+L.ffn_fused(x, out, g, b, w1, b1, w2, b2, M, C, Hd)
+torch.cuda.synchronize()
+ctypes.c_void_p.in_dll(L.lib(), "pd_ffn_trace").value = None
+t = tr.cpu().tolist()
+for grp in (0, 1):
+    tt = t[grp * 128:(grp + 1) * 128]
+    work = [tt[2 * s] - tt[2 * s - 1] for s in range(1, 34)]
+    wait = [tt[2 * s + 1] - tt[2 * s] for s in range(0, 34)]
+    pre = t[256 + grp * 64: 256 + grp * 64 + 34]
+    dmawait = [tt[2 * s] - pre[s] for s in range(0, 34)]
+    print(f"group {grp}: DMA/LDS wait at slot end {dmawait[:12]}")
+    print(f"group {grp}: work per slot (clocks) {work[:12]} ...  barrier wait {wait[:12]} ...  loop total {tt[67] - tt[0]}")
