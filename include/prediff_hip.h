@@ -63,7 +63,7 @@ typedef struct pd_igemm_args {
   int32_t vT, vH, vW;      /* size of the (virtually up-sampled) input the taps are bounds-checked against; 0 = Ti*ut etc. */
   int32_t rows_per_sample, ld_rowvec, ld_res, res_period, ld_mul, act, ld_out, ld_outb, split;
   float alpha;
-  int32_t tile;            /* 0 = auto, 1 = 128x128, 2 = 64x64 */
+  int32_t tile;            /* 0 = auto; 1 = 128x128, 2 = 64x64, 3-6 = pipeline variants of 128x128, 7 = 256x256 (8 waves), 8 / 9 = 128x64 / 64x128 */
   int32_t vec_epilogue;    /* set by the library */
   uint32_t a_bytes, w_bytes; /* set by the library: extent of one A / W batch (buffer-descriptor bounds) */
   int32_t debug_flags;     /* profiling ablations only: 1 skip main loop, 2 skip stores, 4 skip activation (0 in production) */

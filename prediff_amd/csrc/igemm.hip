@@ -252,7 +252,7 @@ static int launch_igemm(const pd_igemm_args& a, hipStream_t s) {
   return PD_OK;
 }
 
-// Tile / pipeline configurations (a.tile): 1 = 128x128, BK 64, 2-stage (2 workgroups/CU);  2 = 64x64, BK 64, 2-stage;
+// Tile / pipeline configurations (a.tile): 1 = 128x128, BK 64, 2-stage (2 workgroups/CU);  2 = 64x64, BK 64, 2-stage;  8 / 9 = 128x64 / 64x128;
 // 3 = 128x128, BK 32, 4-stage ring (2 workgroups/CU, 3 K-steps in flight);  4 = 128x128, BK 64, 3-stage (1 workgroup/CU).
 template <bool SPLIT, int KIND>
 static int dispatch_igemm(const pd_igemm_args& a, int tile, hipStream_t s) {
@@ -263,6 +263,8 @@ static int dispatch_igemm(const pd_igemm_args& a, int tile, hipStream_t s) {
     case 4: return launch_igemm<128, 128, 64, 3, SPLIT, KIND>(a, s);
     case 5: return launch_igemm<128, 128, 32, 2, SPLIT, KIND, (SPLIT ? 2 : 4), 2>(a, s);   // 32 KB LDS, <=128 VGPR: 4 workgroups/CU
     case 6: return launch_igemm<128, 128, 32, 3, SPLIT, KIND, (SPLIT ? 2 : 3), 2>(a, s);   // 48 KB LDS: 3 workgroups/CU
+    case 8: return launch_igemm<128, 64, 64, 2, SPLIT, KIND>(a, s);    // half-width tile for small grids (24 KB LDS per stage pair)
+    case 9: return launch_igemm<64, 128, 64, 2, SPLIT, KIND>(a, s);
     default: pd_set_error("pd_igemm: unknown tile config %d", tile); return PD_ERR_ARG;
   }
 }

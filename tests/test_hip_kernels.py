@@ -41,7 +41,7 @@ def padded_bf16(x2d, split=False):
                                         (300, 130, 64, 4), (512, 256, 2048, 3), (512, 256, 2048, 4),
                                         (3328, 768, 256, 5), (1000, 200, 96, 5), (300, 130, 64, 6), (512, 256, 2048, 6), (3328, 768, 256, 6),
                                         (3328, 768, 256, 7), (1000, 200, 96, 7), (300, 130, 64, 7), (512, 256, 2048, 7), (37, 5, 32, 7),
-                                        (2048, 512, 192, 7), (106496, 256, 128, 7), (26624, 512, 64, 7), (9000, 300, 64, 7), (209, 256, 64, 7), (415, 256, 64, 7)])
+                                        (2048, 512, 192, 7), (106496, 256, 128, 7), (26624, 512, 64, 7), (9000, 300, 64, 7), (209, 256, 64, 7), (415, 256, 64, 7), (1000, 200, 96, 8), (1000, 200, 96, 9), (300, 130, 64, 8), (3328, 768, 256, 9)])
 @pytest.mark.parametrize("split", [False, True])
 def test_igemm_linear(M, N, K, tile, split):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
@@ -101,7 +101,7 @@ def test_igemm_batched():
 # ------------------------------------------------------------------------------------------------ igemm: convolutions
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 5, 8, 8, 64, 64), (1, 13, 16, 16, 256, 256), (2, 3, 6, 6, 5, 32), (1, 13, 8, 8, 512, 512)])
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("tile", [0, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 3, 4, 5, 6, 7, 8, 9])
 def test_igemm_conv3d(B, T, H, W, Cin, Cout, split, tile):
     g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
     x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
