@@ -635,6 +635,10 @@ class CuboidTransformerUNet(nn.Module):
     def _attention(self, P, name, at: CuboidSelfAttentionLayer, x, B, S, C, tabs, geo, dev):
         """x += CuboidSelfAttentionLayer(x)  (cuboid_transformer.py:812-966, residual of :1151)."""
         ld = pad64(C)
+        if P[name + ".qkv.b"] is not None and any(geo["pad"]):
+            # the reference pads AFTER the LayerNorm (cuboid_transformer.py:829), so a padded token's q/k/v equal the qkv bias;
+            # the HIP kernels give padded slots q = k = v = 0.  Unreachable through CuboidTransformerUNet (qkv_bias is always False).
+            raise NotImplementedError("qkv_bias=True together with a padded (non-divisible) shape is not supported by the HIP path")
         if (self.precision == "bf16" and self.fuse_attn and at.use_final_proj and ld == C
                 and L.attn_block_fused_supported(C, at.num_heads, geo["vol"])):
             # one launch, q/k/v/attention output never leave the CU (csrc/attn_block.hip)
