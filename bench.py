@@ -6,7 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one DDIM step (eta = 0) of the Earthformer-UNet denoiser for a batch of `--batch` independent latent
-trajectories per GPU at the SEVIR-LR v1 configuration (BASELINE.json configs[1]: latent 6x16x16x64 <- 6x128x128
+trajectories per GPU (advanced as `--streams` equal sub-batches = lanes, each a HIP graph on its own stream: independent
+trajectories fill each other's idle CUs) at the SEVIR-LR v1 configuration (BASELINE.json configs[1]: latent 6x16x16x64 <- 6x128x128
 frames, context 7 frames, 136.8 M-parameter denoiser, bf16 MFMA operands / fp32 accumulate, no knowledge alignment):
 denoiser forward + fused step epilogue, replayed from one HIP graph.  Weights are seeded random (no checkpoints
 offline), inputs synthetic; everything is resident in HBM before the timed region.  value = trajectory-steps per
@@ -129,7 +130,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="latent trajectories (ensemble members) per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="latent trajectories (ensemble members) per GPU")
+    ap.add_argument("--streams", type=int, default=2, help="lanes: the batch advances as this many equal sub-batches on concurrent HIP streams")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,10 +182,20 @@ def main():
     coef_all = torch.tensor([[[a[order[k % 50]], a_prev[order[k % 50]], sig[order[k % 50]]]] * B for k in range(n_total)],
                             dtype=torch.float32, device=device)
 
+    S = args.streams if (not args.no_graph and args.streams > 1 and B % args.streams == 0) else 1
+    Bl = B // S
+    ldm.num_streams = S
+    lanes = None
     if args.no_graph:
         st = None
         out = torch.empty_like(z)
         noise0 = torch.zeros_like(z)
+    elif S > 1:
+        st = None
+        lanes = ldm._lanes("ddim", B, zc, device, True)
+        for l, lst in enumerate(lanes[0]):
+            lst["noise"].zero_()
+            lst["z"].copy_(z[l * Bl:(l + 1) * Bl])
     else:
         st = ldm._graph_step("ddim", B, zc, device)
         st["noise"].zero_()
@@ -191,7 +203,12 @@ def main():
 
     def one_step(k):
         nonlocal z
-        if st is not None:
+        if lanes is not None:
+            def fill(lst, sl, k=k):
+                lst["t"].copy_(t_all[k][sl])
+                lst["coef"].copy_(coef_all[k][sl])
+            ldm._lane_step(lanes[0], lanes[1], Bl, device, fill)
+        elif st is not None:
             st["t"].copy_(t_all[k])
             st["coef"].copy_(coef_all[k])
             st["graph"].replay()
@@ -217,20 +234,20 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-    final = st["z"] if st is not None else z
+    final = torch.cat([lst["z"] for lst in lanes[0]]) if lanes is not None else (st["z"] if st is not None else z)
     assert bool(torch.isfinite(final).all()), "non-finite latents after the timed steps"
 
     if rank == 0:
         n_gpus = world
         value = n_gpus * B * args.steps / elapsed
-        ker_s, launches, attn_s, attn_launches = kernel_times(ldm, B, device)
-        flops_per_launch = CONV3D_GFLOP_PER_STEP * 1e9 * B / CONV3D_LAUNCHES_PER_STEP
+        ker_s, launches, attn_s, attn_launches = kernel_times(ldm, Bl, device)     # the kernels as launched: one lane's sub-batch
+        flops_per_launch = CONV3D_GFLOP_PER_STEP * 1e9 * Bl / CONV3D_LAUNCHES_PER_STEP
         achieved = flops_per_launch / ker_s / 1e12
         traffic = None
         tp = os.path.join(ROOT, "profiles", "conv3d_hbm_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(f"B{B}")
+                traffic = json.load(open(tp)).get(f"B{Bl}")
             except Exception:
                 traffic = None
         line = {
@@ -240,23 +257,24 @@ def main():
             "data": "synthetic (seeded random weights of the v1 architecture, N(0,1) latents/context)",
             "config": {"workload": "SEVIR-LR 7->6 x128x128 (latent 13x16x16, C 256/512, depth [4,4], axial), DDIM-50 eta=0, "
                                    "no knowledge alignment (BASELINE.json configs[1])",
-                       "trajectories_per_gpu": B, "global_trajectories": B * n_gpus, "sampler": "ddim50", "hip_graph": st is not None,
+                       "trajectories_per_gpu": B, "global_trajectories": B * n_gpus, "sampler": "ddim50", "hip_graph": not args.no_graph,
+                       "lanes": S, "trajectories_per_launch": Bl,
                        "parallelism": f"ensemble-shard x{n_gpus}"},
             "step_tflops": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12, 2),
             "step_frac_of_bf16_peak": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": CONV3D_KERNEL_LABEL,
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches,
+                         "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches * S,
                          "gflop_per_launch": round(flops_per_launch / 1e9, 3)},
         }
         if attn_s:
             # level-0 block: LN -> QKV (2*S*3C*C) -> core (4*S*vol*C) -> proj (2*S*C*C), S = 3328 tokens, C = 256, vol 13 or 16
-            gf = B * (2 * 3328 * 768 * 256 + 2 * 3328 * 256 * 256 + 4 * 3328 * 15 * 256) / 1e9
+            gf = Bl * (2 * 3328 * 768 * 256 + 2 * 3328 * 256 * 256 + 4 * 3328 * 15 * 256) / 1e9
             line["attention_block"] = {"kernel": "attn_block_kernel<256> (LN -> QKV -> cuboid attention -> proj -> +x, level 0)",
                                        "achieved": round(gf / attn_s / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                        "frac": round(gf / attn_s / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(attn_s * 1e6, 2),
-                                       "launches_per_step": attn_launches, "gflop_per_launch": round(gf, 3)}
+                                       "launches_per_step": attn_launches * S, "gflop_per_launch": round(gf, 3)}
         if not args.no_cpu_baseline and n_gpus == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

