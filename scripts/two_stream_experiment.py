@@ -41,5 +41,19 @@ if ns == 1:
 else:
     ms = [make(B // ns) for _ in range(ns)]
     streams = [torch.cuda.Stream() for _ in range(ns)]
-    t = min(run([m[1] for m in ms], streams) for _ in range(3))
-    print(f"{ns} graphs on {ns} streams, {ns} x B={B // ns}: {(B // ns) * ns * steps / t:.1f} steps/s")
+    for off_ms in (0.0, 6.0, 12.0, 18.0):
+        def run_off():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(streams[1]):
+                if off_ms > 0:
+                    torch.cuda._sleep(int(off_ms * 2.1e6))       # initial skew of lane 1 (cycles at ~2.1 GHz)
+            for _ in range(steps):
+                for (m, st), s in zip(ms, streams):
+                    with torch.cuda.stream(s):
+                        st["graph"].replay()
+                        st["z"].copy_(st["out"])
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        t = min(run_off() for _ in range(3))
+        print(f"{ns} lanes x B={B // ns}, lane-1 start skew {off_ms} ms: {(B // ns) * ns * steps / (t - off_ms * 1e-3):.1f} steps/s (skew excluded)")
