@@ -298,7 +298,9 @@ class LatentDiffusion(nn.Module):
             if hasattr(net, "_ws_slot"):
                 net._ws_slot = lane
             eps = self.apply_model(st["z"], st["t"], st["zc"])
-            if kind == "ddpm":
+            if kind == "eps":            # denoiser only: the step epilogue needs the alignment shift, computed outside the graph
+                st["out"].copy_(eps)
+            elif kind == "ddpm":
                 self._ddpm_update(st["z"], eps, st["noise"], None, st["t"], 1.0, self.clip_denoised, out=st["out"])
             else:
                 L.ddim_step(st["z"], eps, st["noise"], st["coef"], st["out"], B, st["z"][0].numel())
@@ -332,7 +334,7 @@ class LatentDiffusion(nn.Module):
         return sts, self._lane_streams[key], Bl
 
     @staticmethod
-    def _lane_step(sts, streams, Bl, device, fill, keep=()):
+    def _lane_step(sts, streams, Bl, device, fill, keep=(), advance=True):
         """One step of every lane: `fill(st, sl)` writes the lane's inputs (slice sl of the batch) on the lane's stream, then the
         lane's graph is replayed and its latent advanced in place.  `keep`: tensors made on the caller's stream that `fill` reads."""
         main = torch.cuda.current_stream(device)
@@ -341,7 +343,8 @@ class LatentDiffusion(nn.Module):
             with torch.cuda.stream(stream):
                 fill(st, slice(l * Bl, (l + 1) * Bl))
                 st["graph"].replay()
-                st["z"].copy_(st["out"])
+                if advance:
+                    st["z"].copy_(st["out"])
             for t in keep:
                 if t is not None:
                     t.record_stream(stream)           # the caching allocator must not recycle it before the lane has read it
@@ -386,10 +389,40 @@ class LatentDiffusion(nn.Module):
             for stream in streams:
                 torch.cuda.current_stream(device).wait_stream(stream)
             return torch.cat([st["z"] for st in sts], dim=0)
+        # knowledge alignment: the guidance gradient depends on z_t only, not on eps, so it runs (PyTorch autograd, caller's stream)
+        # concurrently with the denoiser graphs of the lanes; the step epilogue joins them.  Same arithmetic as the eager path.
+        eps_lanes = None
+        if use_alignment and self.use_hip_graph and self.parameterization == "eps" and img.is_cuda and isinstance(cond, torch.Tensor):
+            saved = self.num_streams
+            if B % max(1, int(saved)):
+                self.num_streams = 1
+            eps_lanes = self._lanes("eps", B, cond, device, True) if self.num_streams > 1 else None
+            self.num_streams = saved
+            if eps_lanes is None:
+                key = str(device)
+                if len(self._lane_streams.get(key, ())) < 1:
+                    self._lane_streams[key] = [torch.cuda.Stream(device=device)]
+                eps_lanes = ([self._graph_step("eps", B, cond, device, lane=0)], self._lane_streams[key][:1], B)
         st = self._graph_step("ddpm", B, cond, device) if use_graph else None
         for k, i in enumerate(reversed(range(0, timesteps))):
             noise = noise_tape[1 + k].to(device) if noise_tape is not None else None
-            if st is not None:
+            if eps_lanes is not None:
+                sts, streams, Bl = eps_lanes
+                ts = torch.full((B,), i, device=device, dtype=torch.long)
+                cur = img
+
+                def fill(lst, sl, i=i, cur=cur):
+                    lst["z"].copy_(cur[sl])
+                    lst["t"].fill_(i)
+                self._lane_step(sts, streams, Bl, device, fill, keep=(cur,), advance=False)
+                shift = self.alignment_fn(cur, ts, zc=cond, y=y, **(alignment_kwargs or {})).contiguous().float()
+                for stream in streams:
+                    torch.cuda.current_stream(device).wait_stream(stream)
+                eps = sts[0]["out"] if len(sts) == 1 else torch.cat([lst["out"] for lst in sts], dim=0)
+                if noise is None:
+                    noise = torch.randn(shape, device=device)
+                img = self._ddpm_update(cur, eps, noise, shift, ts, 1.0, self.clip_denoised)
+            elif st is not None:
                 st["z"].copy_(img)
                 st["t"].fill_(i)
                 st["noise"].copy_(noise) if noise is not None else st["noise"].normal_()

@@ -1,0 +1,44 @@
+"""Wall time of one knowledge-alignment guided DDPM step at the v1 configuration (run on the GPU box):
+denoiser forward (HIP kernels) | alignment gradient (PyTorch autograd on the alignment network) | step epilogue."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench
+from _cases import V1_ALIGN_ARGS
+from prediff_amd.alignment import SEVIRAvgIntensityAlignment
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = torch.device("cuda")
+ldm = bench.v1_model("bf16", dev)
+align = SEVIRAvgIntensityAlignment(guide_scale=50.0, model_args=V1_ALIGN_ARGS)
+align.model.to(dev)
+ldm.set_alignment(align.get_mean_shift)
+zc = torch.randn((B, 7, 16, 16, 64), device=dev)
+zt = torch.randn(ldm.get_batch_latent_shape(B), device=dev)
+t = torch.full((B,), 500, dtype=torch.long, device=dev)
+kw = {"avg_x_gt": torch.rand(B, 1, device=dev)}
+
+
+def timed(fn, n=5):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+
+
+print(f"B={B}: denoiser forward (eager) {timed(lambda: ldm.apply_model(zt, t, zc)):.1f} ms; "
+      f"alignment gradient {timed(lambda: ldm.alignment_fn(zt, t, zc=zc, y=None, **kw)):.1f} ms; "
+      f"p_sample(use_alignment=True) {timed(lambda: ldm.p_sample(zt=zt, zc=zc, t=t, use_alignment=True, alignment_kwargs=kw)):.1f} ms; "
+      f"p_sample(no alignment, eager) {timed(lambda: ldm.p_sample(zt=zt, zc=zc, t=t)):.1f} ms")
+
+
+def loop(graph, n=6):
+    ldm.use_hip_graph = graph
+    tape = [torch.randn(ldm.get_batch_latent_shape(B)) for _ in range(n + 1)]
+    f = lambda: ldm.p_sample_loop(cond=zc, shape=ldm.get_batch_latent_shape(B), use_alignment=True, alignment_kwargs=kw, timesteps=n,
+                                  noise_tape=tape)
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+print(f"aligned DDPM loop, ms/step: eager {loop(False):.1f}; denoiser graphs on lane streams overlapped with the guidance {loop(True):.1f}")

@@ -102,3 +102,11 @@ def test_aligned_sampling_on_gpu(golden, precision):
     e = rel_l2(lat, g["sample_aligned_latent"])
     print(f"[aligned sample3] latent rel-L2 vs reference {e:.3e}")
     assert e < 1e-3
+    # the loop above ran the denoiser as HIP graphs on lane streams concurrently with the autograd guidance; the plain eager
+    # path (no graphs, one stream) must give the same latents bit for bit, whatever the number of lanes
+    outs = []
+    for streams, graph in ((2, True), (1, True), (2, False)):
+        ldm.num_streams, ldm.use_hip_graph = streams, graph
+        outs.append(ldm.sample(cond={"y": y}, batch_size=B, timesteps=3, use_alignment=True, alignment_kwargs={"avg_x_gt": avg},
+                               return_decoded=False, noise_tape=torch.as_tensor(g["tape"])))
+    assert torch.equal(outs[0], lat) and torch.equal(outs[1], lat) and torch.equal(outs[2], lat)
