@@ -30,10 +30,17 @@ _ACT = {"leaky": lambda v: F.leaky_relu(v, 0.1), "gelu": F.gelu, "relu": F.relu,
 # ----------------------------------------------------------------------------------------------------------------------
 # differentiable forwards of the parameter-holder modules (channels-last, (B, T, H, W, C))
 # ----------------------------------------------------------------------------------------------------------------------
+_FREQS: Dict = {}
+
+
 def timestep_embedding(t, dim, max_period=10000):
     """models/utils.py:68-88"""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(t.device)
+    key = (half, max_period, str(t.device))
+    freqs = _FREQS.get(key)
+    if freqs is None:       # computed on the host exactly as the reference does, then kept on the device (no per-call upload: the
+        freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(t.device)
+        _FREQS[key] = freqs     # guidance gradient can then be captured in a HIP graph)
     args = t[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
@@ -61,11 +68,16 @@ def attention_forward(at: CuboidSelfAttentionLayer, x, tables):
     """cuboid_transformer.py:812-966 (no global vectors): returns the layer output (no residual)."""
     B, T, H, W, C = x.shape
     S = T * H * W
-    tok = tables["tok_index"].to(x.device).long()
+    dk = ("dev", str(x.device))
+    if dk not in tables:    # device copies of the static index / mask tables, made once per device
+        tok = tables["tok_index"].to(x.device).long()
+        tables[dk] = dict(tok=tok, gather=torch.where(tok >= 0, tok, torch.full_like(tok, S)).reshape(-1),
+                          mask=tables["mask"].to(x.device).bool() if tables["mask"] is not None else None)
+    dev_t = tables[dk]
+    tok, gather = dev_t["tok"], dev_t["gather"]
     nc, vol = tok.shape
     h = at.norm(x).reshape(B, S, C)
     h = torch.cat([h, h.new_zeros(B, 1, C)], dim=1)                  # row S = the zero padding token
-    gather = torch.where(tok >= 0, tok, torch.full_like(tok, S)).reshape(-1)
     xr = h[:, gather].reshape(B, nc, vol, C)
     hd = C // at.num_heads
     qkv = at.qkv(xr).reshape(B, nc, vol, 3, at.num_heads, hd).permute(3, 0, 4, 1, 2, 5)
@@ -76,7 +88,7 @@ def attention_forward(at: CuboidSelfAttentionLayer, x, tables):
         bias = at.relative_position_bias_table[idx].reshape(vol, vol, -1).permute(2, 0, 1)
         score = score + bias.unsqueeze(1)
     if tables["mask"] is not None:
-        mask = tables["mask"].to(x.device).bool()
+        mask = dev_t["mask"]
         score = score.masked_fill(~mask, -1e4 if score.dtype == torch.float16 else -1e18)
         att = torch.softmax(score, dim=-1) * mask
     else:

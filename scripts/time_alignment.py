@@ -42,3 +42,21 @@ def loop(graph, n=6):
 
 
 print(f"aligned DDPM loop, ms/step: eager {loop(False):.1f}; denoiser graphs on lane streams overlapped with the guidance {loop(True):.1f}")
+
+
+# experiment: the guidance gradient (autograd forward + backward) captured in a HIP graph
+ldm.use_hip_graph = True
+s_zt, s_t = zt.clone(), t.clone()
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3):
+        ref = ldm.alignment_fn(s_zt, s_t, zc=zc, y=None, **kw)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    s_out = ldm.alignment_fn(s_zt, s_t, zc=zc, y=None, **kw)
+g.replay(); torch.cuda.synchronize()
+print("graphed guidance == eager:", torch.equal(s_out, ref), float((s_out - ref).abs().max()),
+      f"; replay {timed(lambda: g.replay()):.2f} ms vs eager {timed(lambda: ldm.alignment_fn(zt, t, zc=zc, y=None, **kw)):.2f} ms")
