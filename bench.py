@@ -145,13 +145,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm; communicator on the current device
 
     import numpy as np
     from prediff_amd import _lib as L
@@ -221,14 +221,14 @@ def main():
     for k in range(args.warmup):
         one_step(k)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(args.warmup, n_total):
         one_step(k)
     torch.cuda.synchronize(device)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - t0
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -279,7 +279,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
