@@ -33,7 +33,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF; 2495 TF measured)
 UNET_GFLOP_PER_STEP = 653.4        # one denoiser forward, one trajectory (2*MAC)
@@ -43,15 +42,13 @@ CONV3D_KERNEL_LABEL = "igemm256_kernel<2,8> | igemm_kernel<128,128,64,2,false,2,
 
 
 def v1_model(precision, device):
-    from _cases import V1_UNET_CFG
-    from _weights import seeded_state_dict
     from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
     from prediff_amd.latent_diffusion import LatentDiffusion
+    from prediff_amd.presets import V1_LDM_KW, V1_UNET_CFG
+    from prediff_amd.seeding import seeded_state_dict
     net = CuboidTransformerUNet(**V1_UNET_CFG, precision=precision)
     net.load_state_dict(seeded_state_dict(net.state_dict(), 1234))
-    ldm = LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(6, 128, 128, 1), timesteps=1000,
-                          beta_schedule="linear", use_ema=False, latent_shape=(6, 16, 16, 64), first_stage_model=None,
-                          cond_stage_model=None, scale_factor=1.0)
+    ldm = LatentDiffusion(torch_nn_module=net, first_stage_model=None, cond_stage_model=None, **V1_LDM_KW)
     return ldm.to(device).eval()
 
 
@@ -96,11 +93,11 @@ def kernel_times(ldm, B, device, reps=3):
 
 def cpu_baseline(budget_s=15.0):
     """Oracle forward (fp32, B=1) on the host cores: bounded sample of the same workload."""
-    from _cases import V1_UNET_CFG
-    from _templates import unet_template
-    from _weights import seeded_input, seeded_state_dict
     from oracle import unet as OU
-    sd = seeded_state_dict(unet_template(V1_UNET_CFG, "v1_unet_schema.json"), 1234)
+    from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
+    from prediff_amd.presets import V1_UNET_CFG
+    from prediff_amd.seeding import seeded_input, seeded_state_dict
+    sd = seeded_state_dict(CuboidTransformerUNet(**V1_UNET_CFG).state_dict(), 1234)     # checkpoint schema (keys, shapes, index buffers)
     x, c = seeded_input("v1x", (1, 6, 16, 16, 64), 2), seeded_input("v1c", (1, 7, 16, 16, 64), 3)
     t = torch.tensor([500])
     # many-core hosts oversubscribe on these small convolutions: time the full core count and a 32-thread run, report the better
@@ -125,6 +122,15 @@ def cpu_baseline(budget_s=15.0):
             "sample": f"{n} oracle denoiser forwards (fp32, B=1, v1 config, torch CPU, {nthr} of {ncpu} threads) in {el:.1f} s"}
 
 
+def lanes_for(batch, args):
+    """Lanes for a small per-GPU batch: sub-batches of >= 2 trajectories on concurrent streams (measured, profiles/r02_*sweep*)."""
+    if args.small_streams:
+        return args.small_streams
+    if batch >= 32:
+        return 2
+    return 2 if batch >= 4 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +140,9 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="lanes: the batch advances as this many equal sub-batches on concurrent HIP streams")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ensemble", type=int, default=32, help="members of the ONE ensemble timed as the strong-scaling line (BASELINE config 3)")
+    ap.add_argument("--small-streams", type=int, default=0, help="lanes for the small-batch / strong-scaling lines (0 = automatic)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the strong-scaling and small-batch lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-ffn", action="store_true")
     ap.add_argument("--no-fused-attn", action="store_true")
@@ -177,69 +186,97 @@ def main():
     steps = np.minimum(make_ddim_timesteps("uniform", 50, 1000), 999)
     sig, a, a_prev = make_ddim_sampling_parameters(ldm._alphas_cumprod_f64.astype(np.float32).astype(np.float64), steps, 0.0)
     order = list(reversed(range(len(steps))))
-    n_total = args.warmup + args.steps
+    n_total = max(args.warmup + args.steps, 3 + 20)      # (the strong-scaling / small-batch lines run 3 + <= 20 steps)
     t_all = torch.tensor([[int(steps[order[k % 50]])] * B for k in range(n_total)], dtype=torch.int64, device=device)
     coef_all = torch.tensor([[[a[order[k % 50]], a_prev[order[k % 50]], sig[order[k % 50]]]] * B for k in range(n_total)],
                             dtype=torch.float32, device=device)
 
-    S = args.streams if (not args.no_graph and args.streams > 1 and B % args.streams == 0) else 1
-    Bl = B // S
-    ldm.num_streams = S
-    lanes = None
-    if args.no_graph:
-        st = None
-        out = torch.empty_like(z)
-        noise0 = torch.zeros_like(z)
-    elif S > 1:
-        st = None
-        lanes = ldm._lanes("ddim", B, zc, device, True)
-        for l, lst in enumerate(lanes[0]):
-            lst["noise"].zero_()
-            lst["z"].copy_(z[l * Bl:(l + 1) * Bl])
-    else:
-        st = ldm._graph_step("ddim", B, zc, device)
-        st["noise"].zero_()
-        st["z"].copy_(z)
-
-    def one_step(k):
-        nonlocal z
-        if lanes is not None:
-            def fill(lst, sl, k=k):
-                lst["t"].copy_(t_all[k][sl])
-                lst["coef"].copy_(coef_all[k][sl])
-            ldm._lane_step(lanes[0], lanes[1], Bl, device, fill)
-        elif st is not None:
-            st["t"].copy_(t_all[k])
-            st["coef"].copy_(coef_all[k])
-            st["graph"].replay()
-            st["z"].copy_(st["out"])
+    def timed_steps(Bx, Sx, n_steps, n_warm):
+        """Advance Bx trajectories per GPU (Sx lanes) for n_warm untimed + n_steps timed DDIM steps; returns (seconds over the timed
+        steps: barrier + synchronize on both sides, max over ranks; lanes actually used; final latents)."""
+        Sx = Sx if (not args.no_graph and Sx > 1 and Bx % Sx == 0) else 1
+        Bl_ = Bx // Sx
+        zx, zcx = z[:Bx].contiguous(), zc[:Bx].contiguous()
+        ldm.num_streams = Sx
+        lanes = st = None
+        if args.no_graph:
+            out = torch.empty_like(zx)
+            noise0 = torch.zeros_like(zx)
+        elif Sx > 1:
+            lanes = ldm._lanes("ddim", Bx, zcx, device, True)
+            for l, lst in enumerate(lanes[0]):
+                lst["noise"].zero_()
+                lst["z"].copy_(zx[l * Bl_:(l + 1) * Bl_])
         else:
-            eps = ldm.apply_model(z, t_all[k], zc)
-            L.ddim_step(z, eps, noise0, coef_all[k], out, B, z[0].numel())
-            z.copy_(out)
+            st = ldm._graph_step("ddim", Bx, zcx, device)
+            st["noise"].zero_()
+            st["z"].copy_(zx)
 
-    for k in range(args.warmup):
-        one_step(k)
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for k in range(args.warmup, n_total):
-        one_step(k)
-    torch.cuda.synchronize(device)
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    final = torch.cat([lst["z"] for lst in lanes[0]]) if lanes is not None else (st["z"] if st is not None else z)
-    assert bool(torch.isfinite(final).all()), "non-finite latents after the timed steps"
+        def one_step(k):
+            nonlocal zx
+            if lanes is not None:
+                def fill(lst, sl, k=k):
+                    lst["t"].copy_(t_all[k][sl])
+                    lst["coef"].copy_(coef_all[k][sl])
+                ldm._lane_step(lanes[0], lanes[1], Bl_, device, fill)
+            elif st is not None:
+                st["t"].copy_(t_all[k][:Bx])
+                st["coef"].copy_(coef_all[k][:Bx])
+                st["graph"].replay()
+                st["z"].copy_(st["out"])
+            else:
+                eps = ldm.apply_model(zx, t_all[k][:Bx], zcx)
+                L.ddim_step(zx, eps, noise0, coef_all[k][:Bx].contiguous(), out, Bx, zx[0].numel())
+                zx.copy_(out)
+
+        for k in range(n_warm):
+            one_step(k)
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for k in range(n_warm, n_warm + n_steps):
+            one_step(k)
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        el = time.perf_counter() - t0
+        if lanes is not None:
+            for stream in lanes[1]:
+                torch.cuda.current_stream(device).wait_stream(stream)
+        if dist is not None:
+            te = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        fin = torch.cat([lst["z"] for lst in lanes[0]]) if lanes is not None else (st["z"] if st is not None else zx)
+        assert bool(torch.isfinite(fin).all()), "non-finite latents after the timed steps"
+        return el, Sx
+
+    elapsed, S = timed_steps(B, args.streams, args.steps, args.warmup)
+    Bl = B // S
+
+    # ---- BASELINE config 3 as written: ONE ensemble of `--ensemble` members sharded over the GPUs (strong scaling: global work fixed,
+    #      per-GPU sub-batch = ensemble / n_gpus), and the small per-GPU batches it implies, reported beside the headline ----
+    strong = None
+    small = {}
+    if not args.no_extra and not args.no_graph:
+        E = args.ensemble
+        k_extra = min(args.steps, 20)
+        if E % world == 0 and E // world <= B:
+            Be = E // world
+            el, Se = timed_steps(Be, lanes_for(Be, args), k_extra, 3)
+            strong = {"metric": "denoising_steps_per_sec", "ensemble": E, "trajectories_per_gpu": Be, "lanes": Se, "scaling": "strong",
+                      "value": round(E * k_extra / el, 2), "unit": "steps/s", "steps": k_extra, "ms_per_step": round(el / k_extra * 1e3, 4)}
+        if world == 1:
+            for Bs in (1, 4, 16):
+                if Bs <= B:
+                    el, Ss = timed_steps(Bs, lanes_for(Bs, args), k_extra, 3)
+                    small[f"B{Bs}"] = {"value": round(Bs * k_extra / el, 2), "unit": "steps/s", "lanes": Ss, "ms_per_step": round(el / k_extra * 1e3, 4)}
 
     if rank == 0:
         n_gpus = world
         value = n_gpus * B * args.steps / elapsed
+        ldm.num_streams = S
         ker_s, launches, attn_s, attn_launches = kernel_times(ldm, Bl, device)     # the kernels as launched: one lane's sub-batch
         flops_per_launch = CONV3D_GFLOP_PER_STEP * 1e9 * Bl / CONV3D_LAUNCHES_PER_STEP
         achieved = flops_per_launch / ker_s / 1e12
@@ -265,6 +302,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": CONV3D_KERNEL_LABEL,
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/conv3d_hbm_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch from separate "
+                                           "rocprofv3 --pmc passes of this kernel (scripts/pmc_bench.sh); not re-measured inside this run",
                          "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches * S,
                          "gflop_per_launch": round(flops_per_launch / 1e9, 3)},
         }
@@ -275,6 +314,10 @@ def main():
                                        "achieved": round(gf / attn_s / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                        "frac": round(gf / attn_s / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(attn_s * 1e6, 2),
                                        "launches_per_step": attn_launches * S, "gflop_per_launch": round(gf, 3)}
+        if strong is not None:
+            line["ensemble_strong_scaling"] = strong      # BASELINE configs[2]: ensemble=32 over the node's GPUs
+        if small:
+            line["small_batch"] = small                   # B in {1..16} beside the headline batch
         if not args.no_cpu_baseline and n_gpus == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -7,3 +7,7 @@ run hand-written HIP kernels from ``libprediff_hip.so`` (C ABI in include/predif
 There is no non-HIP execution path in this package.
 """
 __version__ = "0.1.0"
+
+from .autoencoder_kl import AutoencoderKL  # noqa: E402,F401
+from .cuboid_transformer_unet import CuboidTransformerUNet  # noqa: E402,F401
+from .latent_diffusion import LatentDiffusion  # noqa: E402,F401

@@ -100,7 +100,17 @@ def _check(rc: int, what: str):
 
 
 def stream_ptr() -> int:
+    """The current HIP stream of the current device.  Every module entry point (forward / encode / decode / sample / update) runs
+    inside `on_device(x)`, which makes the operands' device the current one, so this is the stream of the tensors' device."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def on_device(t: torch.Tensor):
+    """Context manager: make `t`'s device current (kernels are launched on the current stream of the current device; a module on
+    cuda:1 called while cuda:0 is current must not launch on a device-0 stream with device-1 pointers)."""
+    if not t.is_cuda:
+        raise PrediffHipError("prediff_amd kernels need CUDA(HIP) tensors; got a CPU tensor")
+    return torch.cuda.device(t.device)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -140,28 +140,11 @@ def pos_embed_forward(pe: PosEmbed, x):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-class QKVAttention(nn.Module):
-    """models.py:19-46"""
-
-    def __init__(self, n_heads):
-        super().__init__()
-        self.n_heads = n_heads
-
-    def forward(self, qkv):
-        bs, width, length = qkv.shape
-        assert width % (3 * self.n_heads) == 0
-        ch = width // (3 * self.n_heads)
-        q, k, v = qkv.chunk(3, dim=1)
-        scale = 1 / math.sqrt(math.sqrt(ch))
-        weight = torch.einsum("bct,bcs->bts", (q * scale).view(bs * self.n_heads, ch, length),
-                              (k * scale).view(bs * self.n_heads, ch, length))
-        weight = torch.softmax(weight.float(), dim=-1).type(weight.dtype)
-        a = torch.einsum("bts,bcs->bct", weight, v.reshape(bs * self.n_heads, ch, length))
-        return a.reshape(bs, -1, length)
-
-
 class AttentionPool3d(nn.Module):
-    """models.py:49-104"""
+    """Attention-pool read-out over the H*W tokens of one frame plus their mean token (models.py:49-104; QKV attention with the
+    ch^-1/4 scaling on q and k, fp32 softmax, models.py:19-46).  Only the mean token's output is read (models.py:100), so only
+    its query is formed: one (1 x L) score row per head instead of the (L x L) matrix -- same result, 1/L of the work and of the
+    autograd graph.  Parameters (positional_embedding, qkv_proj, c_proj) keep the checkpoint's names and shapes."""
 
     def __init__(self, data_dim: int, embed_dim: int, num_heads: int, output_dim: int = None, init_mode: str = "0"):
         super().__init__()
@@ -169,16 +152,20 @@ class AttentionPool3d(nn.Module):
         self.qkv_proj = nn.Conv1d(embed_dim, 3 * embed_dim, 1)
         self.c_proj = nn.Conv1d(embed_dim, output_dim or embed_dim, 1)
         self.num_heads = num_heads
-        self.attention = QKVAttention(self.num_heads)
         self.init_mode = init_mode
 
     def forward(self, x):
-        b, c, *_ = x.shape
-        x = x.reshape(b, c, -1)
-        x = torch.cat([x.mean(dim=-1, keepdim=True), x], dim=-1)
-        x = x + self.positional_embedding[None, :, :].to(x.dtype)
-        x = self.c_proj(self.attention(self.qkv_proj(x)))
-        return x[:, :, 0]
+        b, c = x.shape[:2]
+        tok = x.reshape(b, c, -1)
+        tok = torch.cat([tok.mean(dim=-1, keepdim=True), tok], dim=-1) + self.positional_embedding.to(x.dtype)   # (b, c, L), token 0 = mean
+        heads, ch = self.num_heads, c // self.num_heads
+        assert heads * ch == c
+        q, k, v = self.qkv_proj(tok).view(b, 3, heads, ch, -1).unbind(dim=1)          # each (b, heads, ch, L)
+        s = ch ** -0.25
+        row = ((q[..., :1] * s).transpose(-1, -2) @ (k * s)).float()                  # (b, heads, 1, L): the read-out token's scores
+        w = torch.softmax(row, dim=-1).to(v.dtype)
+        pooled = (v @ w.transpose(-1, -2)).reshape(b, c, 1)
+        return self.c_proj(pooled)[:, :, 0]
 
     def reset_parameters(self):
         self.qkv_proj.reset_parameters()

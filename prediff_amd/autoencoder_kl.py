@@ -277,6 +277,10 @@ class AutoencoderKL(nn.Module):
     @torch.no_grad()
     def encode(self, x: torch.Tensor) -> DiagonalGaussianDistribution:
         """taming/autoencoder_kl.py:80-84 (Encoder.forward taming/vae.py:70-86)."""
+        with L.on_device(x):
+            return self._encode(x)
+
+    def _encode(self, x: torch.Tensor) -> DiagonalGaussianDistribution:
         dev = x.device
         P = self._ensure_packed(dev)
         xl, N, C, hw = self._input(x, dev)
@@ -311,6 +315,10 @@ class AutoencoderKL(nn.Module):
     @torch.no_grad()
     def _decode(self, z: torch.Tensor) -> torch.Tensor:
         """taming/autoencoder_kl.py:86-89 (Decoder.forward taming/vae.py:150-166)."""
+        with L.on_device(z):
+            return self._decode_impl(z)
+
+    def _decode_impl(self, z: torch.Tensor) -> torch.Tensor:
         dev = z.device
         P = self._ensure_packed(dev)
         zl, N, Cz, hw = self._input(z, dev)

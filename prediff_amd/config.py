@@ -91,10 +91,15 @@ def build_prediff(cfg: Dict[str, Any], precision: str = "bf16", pretrained_dir: 
     vae = AutoencoderKL(**vae_kwargs(m["vae"]), precision=precision)
 
     def ckpt(name):
+        """Path of a named checkpoint.  Random initialisation is kept only when no name or no pretrained_dir is given: a name whose
+        file is absent raises, as the reference's torch.load does (final_proj is zero-initialised, so a silently skipped denoiser
+        checkpoint would give eps = 0 and plausible-looking but meaningless samples)."""
         if pretrained_dir is None or name is None:
             return None
         p = os.path.join(pretrained_dir, name)
-        return p if os.path.exists(p) else None
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"checkpoint {name!r} not found in {pretrained_dir!r}")
+        return p
     p = ckpt(m["vae"].get("pretrained_ckpt_path"))
     if p:
         vae.load_state_dict(torch.load(p, map_location="cpu"))

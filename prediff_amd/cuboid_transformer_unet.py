@@ -444,6 +444,7 @@ class CuboidTransformerUNet(nn.Module):
         # engine state
         self._packed = None
         self._packed_key = None
+        self._pack_generation = 0
         self._ws: Dict = {}
         self._ws_slot = 0             # workspace set in use: concurrent sub-batches (LatentDiffusion lanes, one HIP stream each) get their own
         self._tables_dev: Dict = {}
@@ -563,6 +564,7 @@ class CuboidTransformerUNet(nn.Module):
             L.lib()   # fail loudly before any work if the extension is missing
             self._packed = self._pack(device)
             self._packed_key = key
+            self._pack_generation += 1      # HIP graphs captured against the previous operand buffers are stale (LatentDiffusion._graph_step)
             if device not in self._tables_dev:
                 self._tables_dev[device] = [[dict(tok=g["tok_index"].to(device), mask=(g["mask"].to(device) if g["mask"] is not None else None))
                                              for g in lvl] for lvl in self._geom]
@@ -718,6 +720,10 @@ class CuboidTransformerUNet(nn.Module):
         if not x.is_cuda:
             raise L.PrediffHipError("prediff_amd.CuboidTransformerUNet runs only on an MI355X (HIP) device: move the module "
                                     "and its inputs to 'cuda'. There is no CPU path.")
+        with L.on_device(x):       # kernels go to the current stream of x's device, whatever device was current at the call
+            return self._forward(x, t, cond)
+
+    def _forward(self, x, t, cond):
         dev = x.device
         P = self._ensure_packed(dev)
         B = x.shape[0]

@@ -37,11 +37,13 @@ def member_noise_fn(latent_shape: Sequence[int], members: Sequence[int], base_se
     return noise
 
 
-def all_gather_members(local: torch.Tensor, num_members: int, rank: int, world: int, group=None) -> torch.Tensor:
-    """local: (n_local, ...) results of members rank, rank+world, ...  ->  (num_members, ...) on every rank, member order."""
-    if world == 1:
-        return local
+def all_gather_members(local: torch.Tensor, num_members: int, rank: int, world: int, group=None,
+                       force_collective: bool = False) -> torch.Tensor:
+    """local: (n_local, ...) results of members rank, rank+world, ...  ->  (num_members, ...) on every rank, member order.
+    `force_collective`: issue the all-gather even in a world of one (exercises the RCCL path on a single GPU)."""
     import torch.distributed as dist
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
+        return local
     per = (num_members + world - 1) // world
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
@@ -60,7 +62,8 @@ def all_gather_members(local: torch.Tensor, num_members: int, rank: int, world: 
 
 def sample_ensemble(ldm, cond, num_members: int, base_seed: int = 0, sampler: str = "ddim", ddim_steps: int = 50, eta: float = 0.0,
                     timesteps: Optional[int] = None, micro_batch: Optional[int] = None, group=None, return_decoded: bool = True,
-                    use_alignment: bool = False, alignment_kwargs=None, sample_fn: Optional[Callable] = None) -> torch.Tensor:
+                    use_alignment: bool = False, alignment_kwargs=None, sample_fn: Optional[Callable] = None,
+                    force_collective: bool = False) -> torch.Tensor:
     """Draw `num_members` samples for ONE context (cond["y"]: (1, T_in, H, W, C)) across all ranks of `group`.
 
     Returns (num_members, T_out, H, W, C) on every rank.  `sample_fn(cond_batch, batch, noise_fn)` can replace the call into
@@ -99,7 +102,7 @@ def sample_ensemble(ldm, cond, num_members: int, base_seed: int = 0, sampler: st
         probe = shard_members(num_members, 0, world)
         raise ValueError(f"rank {rank} has no ensemble member (num_members={num_members} < world={world}); "
                          f"use num_members >= world (rank 0 would own {probe})")
-    return all_gather_members(local, num_members, rank, world, group)
+    return all_gather_members(local, num_members, rank, world, group, force_collective=force_collective)
 
 
 class _LazyTape:

@@ -35,7 +35,59 @@ def _disabled_train(self, mode=True):
     return self
 
 
-class LatentDiffusion(nn.Module):
+def _module_base():
+    """The reference's LatentDiffusion is a ``pl.LightningModule`` (diffusion/latent_diffusion.py:25) and the SEVIR script subclasses
+    it (scripts/prediff/sevirlr/train_sevirlr_prediff.py:70 ``class PreDiffSEVIRPLModule(LatentDiffusion)``) and hands the object to
+    ``Trainer.test``.  With lightning installed the engine derives from the real LightningModule, so that subclass works unchanged;
+    without it (this image) a plain nn.Module with the few LightningModule members the script's sampling path touches
+    (save_hyperparameters / log / log_dict no-ops, device, local_rank, global_rank, current_epoch)."""
+    try:
+        from lightning.pytorch import LightningModule      # noqa: WPS433
+        if isinstance(LightningModule, type) and issubclass(LightningModule, nn.Module):
+            return LightningModule
+    except Exception:
+        pass
+
+    class _LightningModuleShim(nn.Module):
+        local_rank = 0
+        global_rank = 0
+        current_epoch = 0
+        global_step = 0
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            for t in list(self.parameters(recurse=True))[:1] + list(self.buffers(recurse=True))[:1]:
+                return t.device
+            return torch.device("cpu")
+
+    return _LightningModuleShim
+
+
+def _on_own_device(fn):
+    """Run a sampling entry point with the module's device current (kernels are launched on the current stream of the current
+    device; HIP graphs and lane streams are created with an explicit device, and both must agree)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        dev = self.betas.device
+        if dev.type != "cuda":
+            return fn(self, *a, **k)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **k)
+    return wrapped
+
+
+class LatentDiffusion(_module_base()):
 
     def __init__(self, torch_nn_module: nn.Module, layout: str = "NTHWC", data_shape: Sequence[int] = (10, 128, 128, 4),
                  timesteps=1000, beta_schedule="linear", loss_type="l2", monitor="val/loss", use_ema=True,
@@ -204,6 +256,27 @@ class LatentDiffusion(nn.Module):
             z = post.latent_dist.sample()
         return (self.scale_factor * z).detach()
 
+    def get_first_stage_encoding(self, encoder_posterior):
+        """latent_diffusion.py:382-391"""
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            z = encoder_posterior.sample()
+        elif isinstance(encoder_posterior, torch.Tensor):
+            z = encoder_posterior
+        elif hasattr(encoder_posterior, "latent_dist"):
+            z = encoder_posterior.latent_dist.sample()
+        else:
+            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+        return self.scale_factor * z
+
+    def get_input(self, batch, **kwargs):
+        """Dataset dependent (latent_diffusion.py:405-421): subclasses return (target, {"y": context}[, context])."""
+        raise NotImplementedError("get_input is dataset dependent: re-implement it in the subclass "
+                                  "(e.g. train_sevirlr_prediff.py:733-759)")
+
+    def forward(self, batch, verbose=False):
+        raise NotImplementedError("prediff_amd.LatentDiffusion is the sampling engine: the training forward / p_losses "
+                                  "(latent_diffusion.py:447-551) are out of scope")
+
     def apply_model(self, x_noisy, t, cond):
         out = self.torch_nn_module(x_noisy, t, cond)
         return out[0] if isinstance(out, tuple) else out
@@ -240,6 +313,7 @@ class LatentDiffusion(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ one step
     @torch.no_grad()
+    @_on_own_device
     def p_sample(self, zt, zc, t, y=None, use_alignment=False, alignment_kwargs=None, clip_denoised=False, return_x0=False,
                  temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None, noise=None):
         """One ancestral step.  `noise=None` draws torch.randn on zt's device exactly where the reference does (:620)."""
@@ -257,8 +331,9 @@ class LatentDiffusion(nn.Module):
     def _ddpm_update(self, zt, eps, noise, shift, t, temperature=1.0, clip_denoised=False, out=None):
         B = zt.shape[0]
         out = torch.empty_like(zt) if out is None else out
-        L.ddpm_step(zt.contiguous(), eps.contiguous(), noise.contiguous(), shift, t.to(torch.int64).contiguous(),
-                    self._step_coef, self.num_timesteps, out, B, zt[0].numel(), temperature, clip_denoised)
+        with L.on_device(zt):
+            L.ddpm_step(zt.contiguous(), eps.contiguous(), noise.contiguous(), shift, t.to(torch.int64).contiguous(),
+                            self._step_coef, self.num_timesteps, out, B, zt[0].numel(), temperature, clip_denoised)
         return out
 
     def _p_sample_torch(self, zt, zc, t, y, use_alignment, alignment_kwargs, clip_denoised, return_x0, temperature,
@@ -284,7 +359,7 @@ class LatentDiffusion(nn.Module):
         net = self.torch_nn_module
         if hasattr(net, "_ensure_packed"):
             net._ensure_packed(device)       # a weight update re-packs -> new operand buffers -> the old graph is stale
-        key = (kind, B, str(device), tuple(zc.shape), id(getattr(net, "_packed", None)), self.clip_denoised)
+        key = (kind, B, str(device), tuple(zc.shape), getattr(net, "_pack_generation", None), self.clip_denoised)
         g = self._graphs.get(lane)
         if g is not None and g[0] == key:
             g[1]["zc"].copy_(zc)
@@ -351,6 +426,7 @@ class LatentDiffusion(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ loops
     @torch.no_grad()
+    @_on_own_device
     def p_sample_loop(self, cond, shape, y=None, use_alignment=False, alignment_kwargs=None, return_intermediates=False,
                       x_T=None, verbose=False, callback=None, timesteps=None, mask=None, x0=None, img_callback=None,
                       start_T=None, log_every_t=None, noise_tape=None):
@@ -361,6 +437,8 @@ class LatentDiffusion(nn.Module):
         B = shape[self.batch_axis]
         if x_T is not None:
             img = x_T
+            if noise_tape is not None:
+                noise_tape[0]             # a step-ordered (lazy) tape still owes draw 0 = x_T: consume it, keep the caller's x_T
         elif noise_tape is not None:
             img = noise_tape[0].to(device)
         else:
@@ -371,7 +449,8 @@ class LatentDiffusion(nn.Module):
             timesteps = min(timesteps, start_T)
         if mask is not None:
             assert x0 is not None
-        use_graph = self.use_hip_graph and not use_alignment and self.parameterization == "eps" and img.is_cuda
+        use_graph = (self.use_hip_graph and not use_alignment and self.parameterization == "eps" and img.is_cuda
+                     and isinstance(cond, torch.Tensor))      # a dict / None condition cannot be a static graph input: eager path
         lanes = self._lanes("ddpm", B, cond, device, use_graph and mask is None and callback is None and img_callback is None
                             and not return_intermediates)
         if lanes is not None:
@@ -444,16 +523,23 @@ class LatentDiffusion(nn.Module):
         return (img, intermediates) if return_intermediates else img
 
     @torch.no_grad()
+    @_on_own_device
     def ddim_sample_loop(self, cond, shape, ddim_steps=50, eta=0.0, x_T=None, noise_tape=None, return_intermediates=False,
                          ddim_discretize="uniform"):
         """DDIM over the reference's timestep subset (diffusion/utils.py:42-70).  NOT in the reference:
         z_prev = sqrt(a_prev) z0 + sqrt(1 - a_prev - sigma^2) eps + sigma n, denoiser queried at t = steps[i]."""
         device = self.betas.device
         B = shape[self.batch_axis]
+        if not (1 <= int(ddim_steps) <= self.num_timesteps):
+            raise ValueError(f"ddim_steps must be in [1, {self.num_timesteps}], got {ddim_steps}")
+        if self.clip_denoised:
+            raise NotImplementedError("clip_denoised=True is defined for the ancestral sampler only (the DDIM step has no clamp)")
         steps = np.minimum(make_ddim_timesteps(ddim_discretize, ddim_steps, self.num_timesteps), self.num_timesteps - 1)
         sig, a, a_prev = make_ddim_sampling_parameters(self._alphas_cumprod_f64.astype(np.float32).astype(np.float64), steps, eta)
         if x_T is not None:
             img = x_T
+            if noise_tape is not None:
+                noise_tape[0]             # see p_sample_loop
         elif noise_tape is not None:
             img = noise_tape[0].to(device)
         else:
@@ -480,7 +566,8 @@ class LatentDiffusion(nn.Module):
             for stream in streams:
                 torch.cuda.current_stream(device).wait_stream(stream)
             return torch.cat([st["z"] for st in sts], dim=0)
-        st = self._graph_step("ddim", B, cond, device) if (self.use_hip_graph and img.is_cuda) else None
+        # a dict / None condition cannot be a static graph input: eager path
+        st = self._graph_step("ddim", B, cond, device) if (self.use_hip_graph and img.is_cuda and isinstance(cond, torch.Tensor)) else None
         for k, idx in enumerate(reversed(range(len(steps)))):
             coef = torch.tensor([[a[idx], a_prev[idx], sig[idx]]], dtype=torch.float32).repeat(B, 1)
             noise = None
@@ -505,6 +592,7 @@ class LatentDiffusion(nn.Module):
         return (img, intermediates) if return_intermediates else img
 
     @torch.no_grad()
+    @_on_own_device
     def sample(self, cond, batch_size=16, use_alignment=False, alignment_kwargs=None, return_intermediates=False, x_T=None,
                verbose=False, timesteps=None, mask=None, x0=None, shape=None, return_decoded=True, **kwargs):
         """latent_diffusion.py:686-724.  Extra keywords (new API, consumed from **kwargs): sampler="ddpm"|"ddim",

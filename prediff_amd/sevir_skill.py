@@ -69,8 +69,9 @@ class SEVIRSkillScore:
             self._counts = torch.zeros((len(self.threshold_list), T if self.keep_seq_len_dim else 1, 3), dtype=torch.int64, device=dev)
             self._thr = torch.tensor(self.threshold_list, dtype=torch.float32, device=dev)
         divisor = float(np.float32(1.0 / 255.0))       # data.float() / PREPROCESS_SCALE_01['vil'] (sevir_dataloader.py:679)
-        L.sevir_skill_counts(pred.detach().float().contiguous(), target.detach().float().contiguous(), self._thr, divisor,
-                             self._counts, outer, T, inner, self.keep_seq_len_dim)
+        with L.on_device(pred):
+            L.sevir_skill_counts(pred.detach().float().contiguous(), target.detach().float().contiguous(), self._thr, divisor,
+                                 self._counts, outer, T, inner, self.keep_seq_len_dim)
 
     def sync(self, group=None):
         import torch.distributed as dist

@@ -83,26 +83,9 @@ TINY_VAE_CFG = dict(in_channels=1, out_channels=1, down_block_types=["DownEncode
                     up_block_types=["UpDecoderBlock2D"] * 3, block_out_channels=[32, 64, 64],
                     layers_per_block=1, act_fn="silu", latent_channels=4, norm_num_groups=8)
 
-# scripts/prediff/sevirlr/prediff_sevirlr_v1.yaml:157-205 mapped through
-# scripts/prediff/sevirlr/train_sevirlr_prediff.py:91-137 (dropouts only matter in training)
-V1_UNET_CFG = dict(input_shape=[7, 16, 16, 64], target_shape=[6, 16, 16, 64], base_units=256, scale_alpha=1.0,
-                   depth=[4, 4], downsample=2, downsample_type="patch_merge", upsample_type="upsample",
-                   upsample_kernel_size=3, block_attn_patterns="axial", num_heads=4, attn_drop=0.1,
-                   proj_drop=0.1, ffn_drop=0.1, ffn_activation="gelu", gated_ffn=False, norm_layer="layer_norm",
-                   use_inter_ffn=True, hierarchical_pos_embed=False, pos_embed_type="t+h+w",
-                   padding_type="zeros", checkpoint_level=0, use_relative_pos=True,
-                   self_attn_use_final_proj=True, num_global_vectors=0, use_global_vector_ffn=False,
-                   use_global_self_attn=True, separate_global_qkv=True, global_dim_ratio=1,
-                   attn_linear_init_mode="0", ffn_linear_init_mode="0", ffn2_linear_init_mode="2",
-                   attn_proj_linear_init_mode="2", conv_init_mode="0", down_linear_init_mode="0",
-                   up_linear_init_mode="0", global_proj_linear_init_mode="2", norm_init_mode="0",
-                   time_embed_channels_mult=4, time_embed_use_scale_shift_norm=False, time_embed_dropout=0.0,
-                   unet_res_connect=True)
-
-# prediff_sevirlr_v1.yaml:206-217
-V1_VAE_CFG = dict(in_channels=1, out_channels=1, down_block_types=["DownEncoderBlock2D"] * 4,
-                  up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=[128, 256, 512, 512],
-                  layers_per_block=2, act_fn="silu", latent_channels=64, norm_num_groups=32)
+# v1 / N-body stand-in / full-res constructor keyword sets live in the package (bench.py uses them too)
+from prediff_amd.presets import (FULLRES_UNET_CFG, NBODY_LDM_KW, NBODY_UNET_CFG, NBODY_VAE_CFG, V1_LDM_KW,  # noqa: E402,F401
+                                 V1_UNET_CFG, V1_VAE_CFG)
 
 
 def _align(**over):

@@ -10,6 +10,7 @@ generator and the tests, so only inputs/outputs are stored.  Nothing here is ref
 source: the files hold numeric inputs and the outputs the reference produced for them.
 """
 import json
+import math
 import os
 import sys
 import zlib
@@ -20,6 +21,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))     # repo root: tests/_weights.py and _cases.py re-export from prediff_amd
 from _ref_import import import_reference  # noqa: E402
 from _weights import seeded_state_dict, seeded_input  # noqa: E402
 from _inputs import skill_inputs  # noqa: E402
@@ -338,8 +340,82 @@ def gen_skill():
     save("skill_score", **arrs)
 
 
+def gen_v1_aligned():
+    """BASELINE config 4 at full size: one knowledge-aligned ancestral step of the v1 denoiser + v1 alignment network at
+    t in {99, 0} (sample(timesteps=100) runs t = 99 .. 0, latent_diffusion.py:651-655), B = 2, guide_scale 50.  Stored as a strided
+    fp32 slice + checksums (the full tensors are 786 kB each)."""
+    from _cases import V1_ALIGN_ARGS
+    net = R.CuboidTransformerUNet(**V1_UNET_CFG)
+    reseed(net, 1234)
+    ldm = R.LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(6, 128, 128, 1), timesteps=1000, beta_schedule="linear",
+                            use_ema=False, latent_shape=(6, 16, 16, 64), first_stage_model=R.AutoencoderKL(**TINY_VAE_CFG),
+                            cond_stage_model="__is_first_stage__", scale_factor=1.0).eval()    # (the VAE is required by the ctor, unused by p_sample)
+    al = R.SEVIRAvgIntensityAlignment(alignment_type="avg_x", guide_scale=50.0, model_type="cuboid", model_args=dict(V1_ALIGN_ARGS))
+    reseed(al.model, 701)
+    ldm.set_alignment(al.get_mean_shift)
+    B = 2
+    zt = seeded_input("v1azt", (B, 6, 16, 16, 64), 12)
+    zc = seeded_input("v1azc", (B, 7, 16, 16, 64), 13)
+    avg = torch.tensor([[0.31], [0.07]])
+    arrs = {"avg_x_gt": avg}
+    for tt in (99, 0):
+        tv = torch.full((B,), tt, dtype=torch.long)
+        noise = seeded_input(f"v1an{tt}", (B, 6, 16, 16, 64), 14)
+        torch.manual_seed(5)
+        out = ldm.p_sample(zt=zt, zc=zc, t=tv, y=None, use_alignment=True, alignment_kwargs={"avg_x_gt": avg})
+        torch.manual_seed(5)
+        drawn = torch.randn(zt.shape)
+        # the reference draws its own noise; re-express the step with the committed seeded noise: out - sigma*drawn + sigma*noise
+        sigma = (0.5 * ldm.posterior_log_variance_clipped[tt]).exp() * (0.0 if tt == 0 else 1.0)
+        out = out - sigma * drawn + sigma * noise
+        shift = al.get_mean_shift(zt, tv, y=None, zc=zc, avg_x_gt=avg)
+        arrs[f"out_{tt}_slice"] = out[:, :, ::2, ::2, ::4].contiguous()
+        arrs[f"out_{tt}_abs_sum"] = out.double().abs().sum().reshape(1)
+        arrs[f"shift_{tt}_slice"] = shift[:, :, ::2, ::2, ::4].contiguous()
+        arrs[f"shift_{tt}_abs_sum"] = shift.double().abs().sum().reshape(1)
+    save("v1_aligned", **arrs)
+
+
+def gen_nbody():
+    """BASELINE config 1 stand-in (the reference has no N-body config, F8): the reference's own
+    AutoencoderKL / CuboidTransformerUNet / schedule helpers at the stand-in sizes, 1 sample of 10 x 64 x 64 frames, driven through
+    10 DDIM steps (eta = 0).  The reference ships no DDIM sampler (F3): the loop below is the stable-diffusion-lineage update
+    written with the reference's helper outputs; what this file pins is the two networks + helpers at this configuration."""
+    from _cases import NBODY_UNET_CFG, NBODY_VAE_CFG
+    vae = R.AutoencoderKL(**NBODY_VAE_CFG)
+    reseed(vae, 801)
+    net = R.CuboidTransformerUNet(**NBODY_UNET_CFG)
+    reseed(net, 800)
+    ldm = R.LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(10, 64, 64, 1), timesteps=1000, beta_schedule="linear",
+                            use_ema=False, latent_shape=(10, 16, 16, 4), first_stage_model=vae,
+                            cond_stage_model="__is_first_stage__", scale_factor=1.0).eval()
+    y = seeded_input("nby", (1, 10, 64, 64, 1), 0, kind="uniform")
+    zc = ldm.cond_stage_forward({"y": y})
+    steps = np.minimum(R.dutils.make_ddim_timesteps("uniform", 10, 1000, verbose=False), 999)
+    ac = ldm.alphas_cumprod.double().numpy()
+    sig, a, ap = R.dutils.make_ddim_sampling_parameters(ac, steps, 0.0, verbose=False)
+    z = seeded_input("nbxT", (1, 10, 16, 16, 4), 1)
+    for idx in reversed(range(len(steps))):
+        t = torch.full((1,), int(steps[idx]), dtype=torch.long)
+        eps = ldm.apply_model(z, t, zc)
+        z0 = (z - math.sqrt(1.0 - a[idx]) * eps) / math.sqrt(a[idx])
+        z = math.sqrt(ap[idx]) * z0 + math.sqrt(1.0 - ap[idx] - sig[idx] ** 2) * eps
+    dec = ldm.decode_first_stage(z)
+    with open(os.path.join(HERE, "nbody_schema.json"), "w") as f:
+        json.dump({"unet": {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()},
+                   "vae": {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in vae.state_dict().items()}}, f)
+    save("nbody", zc=zc, latent=z, decoded=dec)
+
+
 def main():
-    which = sys.argv[1:] or ["skill", "index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion", "alignment"]
+    which = sys.argv[1:] or ["skill", "index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion", "alignment",
+                             "v1_aligned", "nbody"]
+    if "v1_aligned" in which:
+        torch.set_grad_enabled(True)
+        gen_v1_aligned()
+        torch.set_grad_enabled(False)
+    if "nbody" in which:
+        gen_nbody()
     if "skill" in which:
         gen_skill()
     if "alignment" in which:

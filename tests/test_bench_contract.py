@@ -28,3 +28,16 @@ def test_bench_json_line():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # value = trajectories * steps / wall
     assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-2
+
+
+def test_bench_strong_scaling_and_small_batch_lines():
+    """--batch >= --ensemble: the line also carries BASELINE config 3 as written (ONE ensemble of 32 sharded over the GPUs: strong
+    scaling) and the small per-GPU batches (B in {1..16})."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "32",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    s = d["ensemble_strong_scaling"]
+    assert s["ensemble"] == 32 and s["trajectories_per_gpu"] == 32 and s["scaling"] == "strong" and s["value"] > 0
+    assert set(d["small_batch"]) == {"B1", "B4", "B16"} and all(v["value"] > 0 for v in d["small_batch"].values())
+    assert d["attention_block"]["frac"] > 0 and d["roofline"]["traffic_source"]

@@ -444,3 +444,45 @@ def test_attn_block_fused(shape, cuboid, shift, padding_type, Cn, heads, B, qkv_
     xin = x.clone()
     L.attn_block_fused(xin, xin, gamma, beta, wq_p, bq, wp_p, bp, tok, bias, m, B, ntok, Cn, heads, nc, vol, scale)   # in place
     assert torch.equal(xin, out)
+
+
+@pytest.mark.parametrize("case", [10, 11, "w"])
+def test_attn_block_fused_vs_oracle(golden, case):
+    """pd_attn_block_fused directly against the oracle's CuboidSelfAttentionLayer statement (+x) and the reference goldens
+    (tests/golden/attn_layer.npz cases 10 / 11 = the v1 level-0 axial-T / axial-H layers; the axial-W layer has no golden and is
+    checked against the oracle only).  bf16 operands, fp32 accumulation: <= 6e-3 rel-L2 on the layer output."""
+    import _templates as TP
+    from _cases import ATTN_CASES
+    from _weights import seeded_input, seeded_state_dict
+    from oracle import unet as OU
+    from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
+    if case == "w":
+        c, seed, xname = dict(ATTN_CASES[11], cuboid=(1, 1, 16)), 190, "attnw"
+    else:
+        c, seed, xname = ATTN_CASES[case], 100 + case, f"attn{case}"
+    Cn, heads, shape, cuboid = c["dim"], c["heads"], tuple(c["shape"]), tuple(c["cuboid"])
+    sd = seeded_state_dict(TP.attn_layer(Cn, heads, cuboid), seed)
+    x = seeded_input(xname, (c["B"],) + shape + (Cn,), 1)
+    y_ref = OU.cuboid_self_attention(sd, "", x, heads, cuboid, c["shift"], c["strategy"], c["padding_type"])
+    tabs = attention_tables(shape, cuboid, c["shift"], c["strategy"], c["padding_type"])
+    vol, nc = tabs["vol"], tabs["nc"]
+    assert L.attn_block_fused_supported(Cn, heads, vol)
+    bias = relative_position_bias(sd["relative_position_bias_table"], sd["relative_position_index"], vol).to(DEV)
+    wq_p, _ = pack_linear(sd["qkv.weight"].to(DEV), False)
+    wp_p, _ = pack_linear(sd["proj.weight"].to(DEV), False)
+    ntok = shape[0] * shape[1] * shape[2]
+    xd = x.reshape(c["B"], ntok, Cn).to(DEV).contiguous()
+    out = torch.full_like(xd, float("nan"))
+    L.attn_block_fused(xd, out, sd["norm.weight"].to(DEV), sd["norm.bias"].to(DEV), wq_p, None, wp_p, sd["proj.bias"].to(DEV),
+                       tabs["tok_index"].to(DEV), bias, tabs["mask"].to(DEV) if tabs["mask"] is not None else None,
+                       c["B"], ntok, Cn, heads, nc, vol, (Cn // heads) ** -0.5)
+    torch.cuda.synchronize()
+    y = (out - xd).reshape(y_ref.shape).cpu()
+    e = rel_l2(y, y_ref)
+    print(f"[attn_block_fused case {case}] layer output rel-L2 vs oracle {e:.3e}")
+    assert e < 6e-3
+    assert rel_l2(out.reshape(x.shape).cpu(), x + y_ref) < 3e-3          # the block's result x + attn(x)
+    if case != "w":
+        g = golden("attn_layer")
+        assert rel_l2(y[:, :, ::2, ::2, ::4], g[f"y_{case}_slice"]) < 6e-3
+        assert abs(float(y.double().abs().sum()) / float(g[f"y_{case}_abs_sum"][0]) - 1) < 6e-3

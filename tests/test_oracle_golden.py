@@ -268,3 +268,49 @@ def test_ddim_self_consistency():
     # with a_prev == a_t and sigma == 0 the step is the identity
     same = OD.ddim_step(zt, eps, a_t, a_t, sig0, torch.zeros_like(zt))
     assert rel_l2(same, zt) < 1e-5
+
+
+# ------------------------------------------------------------------ BASELINE config 1 stand-in and config 4 at full size
+def test_nbody_standin(golden):
+    """Config 1 ("N-body MNIST 64x64, 10-step DDIM, 1 sample, CPU"): the oracle's VAE + denoiser + DDIM loop against the run of the
+    reference's own modules at the stand-in sizes (tests/golden/gen_golden.py:gen_nbody)."""
+    from _cases import NBODY_UNET_CFG, NBODY_VAE_CFG
+    g = golden("nbody")
+    usd = seeded_state_dict(TP.unet_template(NBODY_UNET_CFG, "nbody_schema.json", "unet"), 800)
+    vsd = seeded_state_dict(TP.from_schema("nbody_schema.json", "vae"), 801)
+    y = seeded_input("nby", (1, 10, 64, 64, 1), 0, kind="uniform")
+    frames = y.permute(0, 1, 4, 2, 3).reshape(10, 1, 64, 64)
+    zc = OV.vae_encode_mode(vsd, NBODY_VAE_CFG, frames).reshape(1, 10, 4, 16, 16).permute(0, 1, 3, 4, 2)
+    assert rel_l2(zc, g["zc"]) < 1e-5
+    ac = np.cumprod(1.0 - OD.beta_schedule("linear", 1000)).astype(np.float32)
+    xT = seeded_input("nbxT", (1, 10, 16, 16, 4), 1)
+    tape = [xT] + [torch.zeros_like(xT)] * 10
+    lat = OD.ddim_sample_loop(ac, lambda z, t, c: OU.unet_forward(usd, NBODY_UNET_CFG, z, t, c), zc, tape, 10, eta=0.0)[-1]
+    assert rel_l2(lat, g["latent"]) < 1e-4
+    dec = OV.vae_decode(vsd, NBODY_VAE_CFG, lat.permute(0, 1, 4, 2, 3).reshape(10, 4, 16, 16))
+    dec = dec.reshape(1, 10, 1, 64, 64).permute(0, 1, 3, 4, 2)
+    assert rel_l2(dec, g["decoded"]) < 1e-4
+
+
+def test_v1_aligned_step(golden):
+    """Config 4 at full size: oracle denoiser + prediff_amd.alignment guidance (PyTorch autograd, CPU) + oracle step epilogue against
+    the reference's knowledge-aligned p_sample at t in {99, 0}."""
+    from _cases import V1_ALIGN_ARGS
+    from prediff_amd.alignment import SEVIRAvgIntensityAlignment
+    g = golden("v1_aligned")
+    sd = seeded_state_dict(TP.unet_template(V1_UNET_CFG, "v1_unet_schema.json"), 1234)
+    al = SEVIRAvgIntensityAlignment(alignment_type="avg_x", guide_scale=50.0, model_type="cuboid", model_args=dict(V1_ALIGN_ARGS))
+    al.model.load_state_dict(seeded_state_dict(al.model.state_dict(), 701))
+    buf = {k: torch.as_tensor(v) for k, v in OD.schedule_buffers(OD.beta_schedule("linear", 1000)).items()}
+    B = 2
+    zt, zc = seeded_input("v1azt", (B, 6, 16, 16, 64), 12), seeded_input("v1azc", (B, 7, 16, 16, 64), 13)
+    avg = torch.as_tensor(g["avg_x_gt"])
+    for tt in (99, 0):
+        t = torch.full((B,), tt, dtype=torch.long)
+        shift = al.get_mean_shift(zt, t, y=None, zc=zc, avg_x_gt=avg)
+        assert rel_l2(shift[:, :, ::2, ::2, ::4], g[f"shift_{tt}_slice"]) < 1e-4
+        with torch.no_grad():
+            out = OD.ddpm_step(buf, zt, OU.unet_forward(sd, V1_UNET_CFG, zt, t, zc), t, seeded_input(f"v1an{tt}", (B, 6, 16, 16, 64), 14),
+                               mean_shift=shift)
+        assert rel_l2(out[:, :, ::2, ::2, ::4], g[f"out_{tt}_slice"]) < 1e-4
+        assert abs(float(out.double().abs().sum()) / float(g[f"out_{tt}_abs_sum"][0]) - 1) < 1e-4

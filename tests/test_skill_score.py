@@ -61,3 +61,30 @@ def test_hip_skill_score_full_size_properties():
     tv = (target.numpy().astype(np.float32) / np.float32(1 / 255.0))
     for i, thr in enumerate(THR):
         assert np.array_equal(h[i] + ms[i], (tv >= thr).sum(axis=(0, 2, 3, 4)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["NHWT", "NTHW", "NHTW"])
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_hip_skill_score_other_layouts(golden, layout, mode):
+    """The reference's constructor default layout is "NHWT" (T last: neighbouring elements belong to different time steps) -- same
+    frames permuted into it must give the golden counts of the NTHWC run, bit exact; also at the real frame size (128 x 128 x 6)."""
+    from prediff_amd.sevir_skill import SEVIRSkillScore
+    g = golden("skill_score")
+    pred, target = skill_inputs()                       # N T H W C with C = 1
+    perm = ["NTHW".index(c) for c in layout]
+    p4, t4 = pred[..., 0].permute(*perm).contiguous(), target[..., 0].permute(*perm).contiguous()
+    pf4 = pred.flip(0)[..., 0].permute(*perm).contiguous()
+    m = SEVIRSkillScore(layout=layout, mode=mode, seq_len=6, threshold_list=THR)
+    m.update(p4.cuda(), t4.cuda())
+    m.update(pf4.cuda(), t4.cuda())
+    for name, st in (("hits", m.hits), ("misses", m.misses), ("fas", m.fas)):
+        assert np.array_equal(st.cpu().numpy().astype(np.int64), g[f"{name}_{mode}"].astype(np.int64)), name
+    gen = torch.Generator().manual_seed(1)
+    tgt = (torch.randint(0, 256, (4, 128, 128, 6), generator=gen).float() / 255) * (torch.rand(4, 128, 128, 6, generator=gen) > 0.6)
+    prd = (tgt + 0.1 * torch.randn(tgt.shape, generator=gen)).clamp(0, 1)
+    m2 = SEVIRSkillScore(mode="1", seq_len=6, threshold_list=THR)       # default layout NHWT
+    m2.update(prd.cuda(), tgt.cuda())
+    h, ms, fa = OS.counts(prd.numpy(), tgt.numpy(), 3, THR, True)
+    assert np.array_equal(m2.hits.cpu().numpy().astype(np.int64), h) and np.array_equal(m2.misses.cpu().numpy().astype(np.int64), ms)
+    assert np.array_equal(m2.fas.cpu().numpy().astype(np.int64), fa)
