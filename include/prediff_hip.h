@@ -67,7 +67,11 @@ typedef struct pd_igemm_args {
   int32_t vec_epilogue;    /* set by the library */
   uint32_t a_bytes, w_bytes; /* set by the library: extent of one A / W batch (buffer-descriptor bounds) */
   int32_t debug_flags;     /* profiling ablations only: 1 skip main loop, 2 skip stores, 4 skip activation (0 in production) */
-  int32_t reserved0;
+  int32_t ksplit;          /* set by the library: K-slices of a split-K launch (1 = none) */
+  float* splitk_ws;        /* caller workspace for split-K partial sums (fp32, splitk_ws_elems elements) or NULL: without it a launch
+                              is never split.  Used for small grids (few trajectories per launch): the K loop of a long-K launch is cut
+                              into slices that run as separate workgroups, then summed in slice order (deterministic) with the epilogue */
+  int64_t splitk_ws_elems;
 } pd_igemm_args;
 int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
 

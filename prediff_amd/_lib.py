@@ -30,7 +30,8 @@ class IgemmArgs(C.Structure):
                 ("nbatch", "M", "N", "Cin", "taps", "lda", "ldw", "B", "Ti", "Hi", "Wi", "To", "Ho", "Wo",
                  "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw", "ut", "uh", "uw", "vT", "vH", "vW",
                  "rows_per_sample", "ld_rowvec", "ld_res", "res_period", "ld_mul", "act", "ld_out", "ld_outb", "split")] + \
-               [("alpha", C.c_float), ("tile", C.c_int32), ("vec_epilogue", C.c_int32), ("a_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("debug_flags", C.c_int32), ("reserved0", C.c_int32)]
+               [("alpha", C.c_float), ("tile", C.c_int32), ("vec_epilogue", C.c_int32), ("a_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("debug_flags", C.c_int32), ("ksplit", C.c_int32),
+                ("splitk_ws", C.c_void_p), ("splitk_ws_elems", C.c_int64)]
 
 
 class CuboidAttnArgs(C.Structure):
@@ -138,7 +139,7 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
           A_lo=None, W_lo=None, bias=None, rowvec=None, rows_per_sample=0, residual=None, res_period=0,
           ld_res=None, mul=None, act="none", alpha=1.0, out_f32=None, out_bf16=None, out_bf16_lo=None,
           ld_out=None, ld_outb=None, nbatch=1, a_batch_stride=0, w_batch_stride=0, out_batch_stride=0,
-          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0):
+          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None):
     """Thin wrapper around pd_igemm.  `geom` = dict(B,Ti,Hi,Wi,To,Ho,Wo,KT,KH,KW,st,sh,sw,pt,ph,pw,ut,uh,uw) or None
     for a plain linear layer."""
     a = IgemmArgs()
@@ -168,6 +169,8 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
     a.alpha = alpha
     a.tile = tile
     a.debug_flags = debug_flags
+    if splitk_ws is not None:       # fp32 workspace: lets the library split the K loop of small-grid, long-K launches
+        a.splitk_ws, a.splitk_ws_elems = ptr(splitk_ws), splitk_ws.numel()
     _check(lib().pd_igemm(C.byref(a), stream_ptr()), "pd_igemm")
 
 

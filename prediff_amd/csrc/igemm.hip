@@ -276,6 +276,9 @@ int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s);
 extern "C" int pd_igemm_default_tile = 0;   // bench / tuning override of the auto choice (0 = built-in heuristic)
 extern "C" int pd_igemm_debug_or = 0;       // bench A/B switch: OR-ed into every launch's debug_flags
 extern "C" int pd_igemm_disable_256 = 0;    // bench A/B switch: keep the auto choice away from the 256 x 256 kernel
+extern "C" int pd_igemm_splitk_max_tiles = 128;   // split-K only for launches of at most this many 256 x 256 tiles (0 disables it)
+int pd_igemm256_ksplit(const pd_igemm_args& a, int kind);
+int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s);
 
 extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(pa != nullptr, "pd_igemm: null args");
@@ -312,6 +315,15 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   const bool pointwise = a.taps == 1 && a.st == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.ph == 0 && a.pw == 0 && a.ut == 1 &&
                          a.uh == 1 && a.uw == 1 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && a.vT <= 0 && a.vH <= 0 && a.vW <= 0;
   const int kind = pointwise ? 0 : ((a.KT == 1 && a.Ti == 1 && a.To == 1) ? 1 : 2);
+  a.ksplit = 1;
+  if (tile == 0 && !pd_igemm_disable_256) {
+    // small grids (few trajectories per launch) with a long K loop: 256 x 256 tiles x K-slices fill the CUs (igemm256.hip)
+    const int ks = pd_igemm256_ksplit(a, kind);
+    if (ks >= 2) {
+      a.ksplit = ks;
+      return pd_igemm256_launch_splitk(a, kind, s);
+    }
+  }
   if (tile == 0) {
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.nbatch > 0 ? a.nbatch : 1);
     // measured on MI355X (scripts/bench_igemm.py): with <= 4 K-steps the 4-workgroups/CU variant (BK 32, 32 KB LDS) hides the

@@ -31,6 +31,7 @@
 //   * the swizzle, descriptors, zero-fill of out-of-image taps, XCD-contiguous tile order and epilogue are those of igemm.hip.
 // Supported: bf16 (non-split) operands, Cin % 64 == 0, KIND 0 (row-wise linear) and KIND 2 (stride-1, un-upsampled
 // Conv2d/Conv3d gather, any padding); pd_igemm picks it for long-K launches with enough rows (see igemm.hip).
+#include <algorithm>
 #include "common.h"
 #include "igemm_epilogue.h"
 
@@ -53,7 +54,10 @@ constexpr int KBUF = 4 * HT;    // one K-tile buffer: A half 0, A half 1, W half
 // shared rows computed twice and stored once) that turns the 416 / 208 tiles of the SEVIR-LR convolutions at 32 trajectories
 // (M = trajectories * 13 * H * W) into exactly 512 / 256 -- measured: identical launch times (388 vs 391 us, 318 vs 318 us), once
 // more because a phase is bound by its barrier pair, LDS reads and the W stream, not by its MFMA count; only RT = 8 is built.
-template <int KIND, int RT>
+// SK: split-K launch (small grids).  blockIdx.y = K-slice; the slice's K-tiles [kt0, kt1) run through the unchanged main loop and
+// the raw fp32 accumulators go to slab `slice` of p.splitk_ws ([ksplit][M][N]); igemm_splitk_reduce_kernel sums the slabs in slice
+// order (deterministic) and applies the epilogue.
+template <int KIND, int RT, bool SK = false>
 __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
   constexpr int ROW1 = BM - 16 * RT;              // first tile row of wave row 1 (128 for RT = 8, 96 for RT = 7)
@@ -116,7 +120,10 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
       woff[hh][i] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldw + schunk * 8) * 2u : PD_OOB;
     }
   const int kchunks = p.Cin >> 6;
-  const int nk = p.taps * kchunks;
+  const int nk_all = p.taps * kchunks;
+  const int kslice = SK ? (int)blockIdx.y : 0;
+  const int kt0 = SK ? (int)((int64_t)nk_all * kslice / p.ksplit) : 0;
+  const int nk = SK ? (int)((int64_t)nk_all * (kslice + 1) / p.ksplit) - kt0 : nk_all;
   const int khw = p.KH * p.KW;
   char* const dma_dst = smem + wave * (8 * 128);   // + half * HT + i * (64 * 128) + buffer * KBUF  (lane * 16 is implicit)
 
@@ -132,9 +139,14 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     }
   };
   // K-tile counters of the DMA streams (A runs one K-tile ahead of the MFMAs, W two); all wave-uniform scalars
-  int a_tap = 0, a_kc = 0, w_kc = 0;
-  uint32_t w_tap_b = 0;                                   // byte offset of the current W tap
   const uint32_t w_tap_stride_b = (uint32_t)p.w_tap_stride * 2u;
+  int a_tap = SK ? kt0 / kchunks : 0;
+  int a_kc = SK ? kt0 - a_tap * kchunks : 0, w_kc = a_kc;
+  uint32_t w_tap_b = (uint32_t)a_tap * w_tap_stride_b;     // byte offset of the current W tap
+  if (SK && KIND != 0 && a_kc != 0) {                      // a slice that starts inside a tap: issue_a only sets a tap up at its first chunk
+    set_tap(0, a_tap);
+    set_tap(1, a_tap);
+  }
   auto issue_a = [&](int hh, int buf) {    // A half hh of the A stream's current K-tile
     if (KIND != 0 && a_kc == 0) set_tap(hh, a_tap);
     const int ka = __builtin_amdgcn_readfirstlane(a_kc * 128);
@@ -269,11 +281,113 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sC[(i * 16 + 4 * lg + r) * 32 + c * 16 + l16] = acc[i][js * 2 + c][r];
     __syncthreads();
-    igemm_epilogue<128, 32>(p, sC + skip * 32, lane, m_base, m_end, n0 + wc * 64 + js * 32, bz);
+    if (SK) {
+      pd_igemm_args q = p;         // raw partial sums -> this slice's slab
+      q.bias = nullptr; q.rowvec = nullptr; q.mul = nullptr; q.residual = nullptr; q.out_bf16 = nullptr; q.out_bf16_lo = nullptr;
+      q.out_f32 = p.splitk_ws + (int64_t)kslice * p.M * p.N;
+      q.ld_out = p.N; q.alpha = 1.f; q.act = 0; q.out_batch_stride = 0;
+      q.vec_epilogue = (p.N & 3) == 0 ? 1 : 0;
+      igemm_epilogue<128, 32>(q, sC + skip * 32, lane, m_base, m_end, n0 + wc * 64 + js * 32, 0);
+    } else {
+      igemm_epilogue<128, 32>(p, sC + skip * 32, lane, m_base, m_end, n0 + wc * 64 + js * 32, bz);
+    }
   }
 #endif
 }
 
+
+// out = epilogue(sum over K-slices of the slabs), four columns per thread; same arithmetic as igemm_epilogue_rows
+__global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const pd_igemm_args p) {
+  const int n4 = p.N >> 2;
+  const int64_t total = (int64_t)p.M * n4;
+  const int64_t slab = (int64_t)p.M * p.N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+    const float* src = p.splitk_ws + (int64_t)m * p.N + n;
+    float4 acc = *(const float4*)src;
+    for (int k = 1; k < p.ksplit; ++k) {
+      const float4 t = *(const float4*)(src + k * slab);
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+    if (p.rowvec) {
+      const float* rv = p.rowvec + (int64_t)(m / p.rows_per_sample) * p.ld_rowvec + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += rv[e];
+    }
+    if (p.act != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+    }
+    if (p.mul) {
+      const float* mu = p.mul + (int64_t)m * p.ld_mul + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= mu[e];
+    }
+    if (p.residual) {
+      const float* rs = p.residual + (int64_t)(p.res_period ? m % p.res_period : m) * p.ld_res + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += rs[e];
+    }
+    if (p.out_f32) {
+      float* o = p.out_f32 + (int64_t)m * p.ld_out + n;
+      if (p.vec_epilogue) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+      else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+    }
+    if (p.out_bf16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint16_t h, l;
+        f2bf_split(v[e], h, l);
+        p.out_bf16[(int64_t)m * p.ld_outb + n + e] = p.out_bf16_lo ? h : (uint16_t)f2bf(v[e]);
+        if (p.out_bf16_lo) p.out_bf16_lo[(int64_t)m * p.ld_outb + n + e] = l;
+      }
+    }
+  }
+}
+
+template <int KIND>
+static int launch256_splitk(const pd_igemm_args& a, hipStream_t s) {
+  constexpr int lds = 2 * KBUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
+      return PD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL((igemm256_kernel<KIND, 8, true>), dim3(tiles, a.ksplit, 1), dim3(512), lds, s, a);
+  PD_CHECK_LAUNCH();
+  const int64_t total = (int64_t)a.M * (a.N >> 2);
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+bool pd_igemm256_supported(const pd_igemm_args& a, int kind);
+
+// K-slices for a launch of `tiles` 256 x 256 tiles and nk K-tiles on the 256 CUs of the MI355X (0 = do not split): split when the
+// tiles cover at most half of the CUs, into as many slices as fit one round, each at least 8 K-tiles long, within the workspace.
+int pd_igemm256_ksplit(const pd_igemm_args& a, int kind) {
+  extern int pd_igemm_splitk_max_tiles;
+  if (!a.splitk_ws || a.split || (a.N & 3) || (a.nbatch > 1) || !pd_igemm256_supported(a, kind)) return 0;
+  const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int nk = a.taps * (a.Cin >> 6);
+  if (tiles > pd_igemm_splitk_max_tiles || nk < 32) return 0;
+  int64_t ks = std::min<int64_t>(256 / tiles, nk / 8);
+  ks = std::min<int64_t>(ks, a.splitk_ws_elems / ((int64_t)a.M * a.N));
+  return ks >= 2 ? (int)ks : 0;
+}
+
+int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s) {
+  return kind == 0 ? launch256_splitk<0>(a, s) : launch256_splitk<2>(a, s);
+}
 
 template <int KIND, int RT>
 static int launch256(const pd_igemm_args& a, hipStream_t s) {

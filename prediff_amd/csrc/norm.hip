@@ -303,13 +303,26 @@ __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restri
                                                            pd_bf16* __restrict__ out_lo, int S, int C, int G, float eps, int silu,
                                                            int nchunk) {
   __shared__ float smr[2 * 256];
+  __shared__ double spart[2 * 256];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int cpg = C / G;
   const int tid = threadIdx.x;
+  // the sample's per-chunk partial sums: 256 / G threads per group take every LP-th chunk (a single thread walking all the
+  // chunks is a chain of dependent L2 round trips -- 10+ us at 52 chunks, most of this kernel's time at small batches), then one
+  // thread per group adds the LP strided sums in a fixed order (deterministic)
+  const int LP = 256 / G;
+  if (tid < LP * G) {
+    const int g = tid % G, j = tid / G;
+    double ss = 0, qq = 0;
+    const double* pp = partials + (int64_t)b * nchunk * G * 2 + g * 2;
+    for (int k = j; k < nchunk; k += LP) { ss += pp[(int64_t)k * G * 2]; qq += pp[(int64_t)k * G * 2 + 1]; }
+    spart[tid * 2] = ss;
+    spart[tid * 2 + 1] = qq;
+  }
+  __syncthreads();
   if (tid < G) {
     double ss = 0, qq = 0;
-    const double* pp = partials + (int64_t)b * nchunk * G * 2 + tid * 2;
-    for (int k = 0; k < nchunk; ++k) { ss += pp[(int64_t)k * G * 2]; qq += pp[(int64_t)k * G * 2 + 1]; }
+    for (int j = 0; j < LP; ++j) { ss += spart[(j * G + tid) * 2]; qq += spart[(j * G + tid) * 2 + 1]; }
     const double cnt = (double)S * cpg, mean = ss / cnt;
     double var = qq / cnt - mean * mean;
     if (var < 0) var = 0;

@@ -332,6 +332,7 @@ class CuboidTransformerUNet(nn.Module):
         self.precision = precision
         self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
         self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 16)
+        self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)
         self.depth = list(depth)
@@ -602,10 +603,21 @@ class CuboidTransformerUNet(nn.Module):
         L.groupnorm_silu(x, g, beta, part, hi, lo, B, S, C, G, ld, 1e-5, silu=silu, **kw)
         return hi, lo, ld
 
+    SPLITK_WS_ELEMS = 16 * 1024 * 1024      # fp32 partial-sum workspace (64 MB per workspace set) for split-K Conv3d launches
+    SPLITK_MAX_BATCH = 16                   # launches of more trajectories fill the CUs with whole tiles: never split
+
+    def _splitk_ws(self, B, dev):
+        """Workspace that lets pd_igemm cut the K loop of the Conv3d launches into slices when a small batch leaves most CUs without
+        a tile (bf16 mode; csrc/igemm256.hip).  None = never split."""
+        if self.precision != "bf16" or B > self.SPLITK_MAX_BATCH or not self.split_k:
+            return None
+        return self._buf("splitk.ws", (self.SPLITK_WS_ELEMS,), torch.float32, dev)
+
     def _resblock(self, P, name, m: TimeEmbedResBlock, x, B, thw, emb, dev, out=None):
         """TimeEmbedResBlock.forward (models/time_embed.py:134-169) on channels-last fp32 x (B*S, Cin)."""
         T, H, W = thw
         S = T * H * W
+        ws = self._splitk_ws(B, dev)
         Cin, Cout = m.channels, m.out_channels
         geom = L.conv_geom(B, thw, (3, 3, 3))
         a1, a1lo, ld1 = self._gn(x, P[name + ".gn1.g"], P[name + ".gn1.beta"], B, S, Cin, m.in_groups, "gn.a", dev)
@@ -613,7 +625,8 @@ class CuboidTransformerUNet(nn.Module):
         w1, w1lo = P[name + ".conv1.w"]
         ssn = m.use_embed and m.use_scale_shift_norm
         L.igemm(a1, w1, A_lo=a1lo, W_lo=w1lo, M=B * S, N=Cout, Cin=ld1, taps=27, w_tap_stride=Cout * ld1, geom=geom,
-                bias=P[name + ".conv1.b"], rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h)
+                bias=P[name + ".conv1.b"], rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h,
+                splitk_ws=ws)
         ldo = pad64(Cout)
         a2, a2lo, _ = self._gn(h, P[name + ".gn2.g"], P[name + ".gn2.beta"], B, S, Cout, m.out_groups, "gn.a", dev,
                                ss=(emb if ssn else None))
@@ -632,7 +645,7 @@ class CuboidTransformerUNet(nn.Module):
                     geom=L.conv_geom(B, thw, (k, k, k), pad=(k // 2,) * 3), bias=P[name + ".skip.b"], out_f32=out)
             res = out
         L.igemm(a2, w2, A_lo=a2lo, W_lo=w2lo, M=B * S, N=Cout, Cin=ldo, taps=27, w_tap_stride=Cout * ldo, geom=geom,
-                bias=P[name + ".conv2.b"], residual=res, out_f32=out)
+                bias=P[name + ".conv2.b"], residual=res, out_f32=out, splitk_ws=ws)
         return out
 
     def _attention(self, P, name, at: CuboidSelfAttentionLayer, x, B, S, C, tabs, geo, dev):

@@ -17,7 +17,7 @@ DEV = "cuda"
 
 
 def rel_l2(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
@@ -486,3 +486,58 @@ def test_attn_block_fused_vs_oracle(golden, case):
         g = golden("attn_layer")
         assert rel_l2(y[:, :, ::2, ::2, ::4], g[f"y_{case}_slice"]) < 6e-3
         assert abs(float(y.double().abs().sum()) / float(g[f"y_{case}_abs_sum"][0]) - 1) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------------ split-K (small grids)
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(1, 13, 16, 16, 256, 256), (4, 13, 8, 8, 512, 512), (2, 5, 8, 8, 128, 192), (3, 13, 16, 16, 256, 256)])
+def test_igemm_conv3d_split_k(B, T, H, W, Cin, Cout):
+    """Conv3d with a split-K workspace (few trajectories per launch: K-slices run as extra workgroups, slabs summed in slice order
+    by the reduce kernel that also applies bias / timestep embedding / residual) against F.conv3d, and bit-reproducible."""
+    g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
+    x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    emb = torch.randn(B, Cout, generator=g).to(DEV)
+    res = torch.randn(B * T * H * W, Cout, generator=g).to(DEV)
+    a_hi, _ = padded_bf16(x.reshape(-1, Cin), False)
+    w_hi, _ = pack_conv(w, False)
+    Cp = a_hi.shape[1]
+    M = B * T * H * W
+    ws = torch.full((16 * 1024 * 1024,), float("nan"), device=DEV)
+    ref = F.conv3d(bf(x).permute(0, 4, 1, 2, 3), bf(w), bias, padding=1) + emb[:, :, None, None, None]
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(M, Cout) + res
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, Cout), float("nan"), device=DEV)
+        L.igemm(a_hi, w_hi, M=M, N=Cout, Cin=Cp, taps=27, w_tap_stride=Cout * Cp, geom=L.conv_geom(B, (T, H, W), (3, 3, 3)),
+                bias=bias, rowvec=emb, rows_per_sample=T * H * W, residual=res, out_f32=out, splitk_ws=ws)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert rel_l2(outs[0], ref) < 3e-6
+    assert torch.equal(outs[0], outs[1])
+    tiles = ((M + 255) // 256) * ((Cout + 255) // 256)
+    used = bool(torch.isfinite(ws[:M * Cout]).all())          # the first slab was written <=> the launch was split
+    assert used == (tiles <= 128 and 27 * Cp // 64 >= 32), (tiles, used)
+    # without a workspace the launch is never split and agrees to summation order
+    out0 = torch.empty(M, Cout, device=DEV)
+    L.igemm(a_hi, w_hi, M=M, N=Cout, Cin=Cp, taps=27, w_tap_stride=Cout * Cp, geom=L.conv_geom(B, (T, H, W), (3, 3, 3)),
+            bias=bias, rowvec=emb, rows_per_sample=T * H * W, residual=res, out_f32=out0)
+    assert rel_l2(outs[0], out0) < 2e-6
+
+
+def test_igemm_linear_split_k_all_epilogue_operands():
+    M, N, K = 300, 260, 4096
+    g = torch.Generator(device="cpu").manual_seed(77)
+    x = (torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.arange(N)[:, None] * 1e-3).to(DEV)
+    bias, mul, res = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    a_hi, _ = padded_bf16(x)
+    w_hi, _ = pack_linear(w, False)
+    ws = torch.full((4 * 1024 * 1024,), float("nan"), device=DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    outb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    L.igemm(a_hi, w_hi, M=M, N=N, Cin=K, bias=bias, mul=mul, residual=res, act="gelu", alpha=0.5, out_f32=out, out_bf16=outb, splitk_ws=ws)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ws[:M * N]).all())             # split
+    ref = F.gelu(0.5 * (bf(x) @ bf(w).t()) + bias) * mul + res
+    assert rel_l2(out, ref) < 3e-6 and rel_l2(outb.float(), ref) < 4e-3

@@ -70,8 +70,13 @@ def test_v1_unet_full_size(golden, precision):
     e = rel_l2(out2, ref2)
     print(f"[v1 {precision}] B=2 rel-L2 vs oracle {e:.3e}")
     assert e < TOL[precision]
-    # sample 0 must not depend on what else is in the batch (bitwise in bf16 / fp32 alike)
-    assert torch.equal(out2[0], out[0])
+    # sample 0 must not depend on what else is in the batch: bitwise, as long as the launches have the same K-slicing (the fp32
+    # engine never splits; the bf16 engine does below 17 trajectories per launch -- csrc/igemm256.hip -- which changes the fp32
+    # summation order with the batch size: then equal to fp32 round-off amplified by a few bf16 rounding boundaries)
+    net.split_k = False
+    assert torch.equal(net(x2.cuda(), t2.cuda(), c2.cuda())[0], net(x.cuda(), t.cuda(), cond.cuda())[0])
+    net.split_k = True
+    assert rel_l2(out2[0], out[0]) < (1e-6 if precision == "fp32" else 2e-3)
 
 
 def test_repack_after_weight_update():
