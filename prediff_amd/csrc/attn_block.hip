@@ -27,6 +27,43 @@
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
 
+// W fragment of k-step ks (32 deep), feature tile dt of a 32 KB weight chunk: slab (ks >> 1), row tn*32 + dt*16 + l16, 16 B chunk
+// ((ks & 1) * 4 + lg) ^ swz16.  The lane part (row, chunk of an even k-step) sits in a VGPR, an odd k-step flips bit 6 of it, the
+// rest is the instruction's immediate offset.
+#define WFRAG_LD(dst, base_vgpr, ks, dt)                                                                                          \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(((ks) & 1) ? ((base_vgpr) ^ 64u) : (base_vgpr)),               \
+               "n"(((ks) >> 1) * 8192 + (dt) * 2048))
+#define WFRAG_PROLOGUE(w, wb)                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < PF; ++i_) {                              \
+    WFRAG_LD(w[i_][0], wb, i_, 0);                                                 \
+    WFRAG_LD(w[i_][1], wb, i_, 1);                                                 \
+  }
+// issue the reads of k-step ks + PF, then wait until those of k-step ks have landed (LDS returns in order: 2 reads per step)
+#define WFRAG_STEP(w, wb, ks)                                                      \
+  if ((ks) + PF < KS * 2) {                                                        \
+    WFRAG_LD(w[((ks) + PF) % (PF + 1)][0], wb, (ks) + PF, 0);                      \
+    WFRAG_LD(w[((ks) + PF) % (PF + 1)][1], wb, (ks) + PF, 1);                      \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PF) : "memory");               \
+  } else {                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KS * 2 - 1 - (ks))) : "memory"); \
+  }                                                                                \
+  __builtin_amdgcn_sched_barrier(0);
+
+// combine a value over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48), result in every lane: v_permlane16_swap /
+// v_permlane32_swap exchange odd and even rows / the two halves in one VALU instruction each (no LDS crossbar round trip)
+__device__ __forceinline__ float rows4_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 struct pd_attn_block_args_k {
   const float* x;
   float* out;
@@ -58,6 +95,7 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   constexpr int TILE = BM * HD * 2;                // 16 KB
   constexpr int TN2 = (C / 2) / 32;                // 32x32 tiles per wave in the proj GEMM (wave tile 32 x C/2)
   constexpr int NCHUNK = 4 * HEADS;
+  constexpr int PF = 2;                            // weight-fragment prefetch distance of the q/k/v GEMMs, in k-steps of 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;                                 // A tile, then ring buffers 0 and 1
   char* sR2 = sA + A_BYTES;                        // ring buffer 2
@@ -172,8 +210,10 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   issue_chunk(2);
   TRACE();
 
+  const uint32_t w_lane_off = (uint32_t)((tn * 32 + l16) * 128 + ((lg ^ swz16) << 4));
   const uint32_t q_lds = (uint32_t)(uintptr_t)sQ, k_lds = (uint32_t)(uintptr_t)sK, vt_lds = (uint32_t)(uintptr_t)sVT;
-  const uint32_t bq_lds = (uint32_t)(uintptr_t)sBq;
+  const uint32_t bq_lds = (uint32_t)(uintptr_t)sBq, bias_lds = (uint32_t)(uintptr_t)sBias;
+  const int cub_of_wave = (int)(((int64_t)blockIdx.x * 8 + wave) % p.nc);        // cuboid (mask table row) of this wave's core
   // end of a weight-chunk step: chunk s+1 has landed (chunk s+2 may stay in flight), everyone is done with chunk s, refill its buffer
   auto step_end = [&](int s) {
     if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS) : "memory");
@@ -198,17 +238,23 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc1[dt][tt][r] = 0.f;
-      if (!(p.dbg & 2))
+      if (!(p.dbg & 2)) {
+        // Hand-placed fragment pipeline (PF k-steps ahead).  Left to itself hipcc keeps ONE fragment register set and waits
+        // lgkmcnt(0) in front of every MFMA pair (it re-serialises a source-level double buffer, too): 16 exposed LDS round trips per
+        // chunk, ~2.7k clocks for 1.0k clocks of MFMA work.  Opaque ds_reads + counted waits + sched_barrier pin the order.
+        bf16x8 w[PF + 1][2];
+        const uint32_t wb = (uint32_t)(uintptr_t)cW + w_lane_off;
+        WFRAG_PROLOGUE(w, wb)
 #pragma unroll
-      for (int ks = 0; ks < KS * 2; ++ks) {
-        bf16x8 w[2];
+        for (int ks = 0; ks < KS * 2; ++ks) {
+          WFRAG_STEP(w, wb, ks)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          w[dt] = *(const bf16x8*)(cW + (ks >> 1) * 8192 + (tn * 32 + dt * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+          for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) acc1[dt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[dt], areg[tt][ks], acc1[dt][tt], 0, 0, 0);
+            for (int tt = 0; tt < 2; ++tt)
+              acc1[dt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks % (PF + 1)][dt], areg[tt][ks], acc1[dt][tt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       // tile (dt, tt): lane = slot row tq*32 + 16 tt + l16, features tn*32 + 16 dt + 4 lg + (0..3)
       const uint32_t t_lds = kind == 0 ? q_lds : k_lds;
@@ -243,17 +289,20 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc1[tt][dt][r] = 0.f;
-      if (!(p.dbg & 2))
+      if (!(p.dbg & 2)) {
+        bf16x8 w[PF + 1][2];
+        const uint32_t wb = (uint32_t)(uintptr_t)cW + w_lane_off;
+        WFRAG_PROLOGUE(w, wb)
 #pragma unroll
-      for (int ks = 0; ks < KS * 2; ++ks) {
-        bf16x8 w[2];
+        for (int ks = 0; ks < KS * 2; ++ks) {
+          WFRAG_STEP(w, wb, ks)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          w[dt] = *(const bf16x8*)(cW + (ks >> 1) * 8192 + (tn * 32 + dt * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+          for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) acc1[tt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[tt][ks], w[dt], acc1[tt][dt], 0, 0, 0);
+            for (int dt = 0; dt < 2; ++dt)
+              acc1[tt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[tt][ks], w[ks % (PF + 1)][dt], acc1[tt][dt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       // tile (tt, dt): lane = feature d = tn*32 + 16 dt + l16, slot rows tq*32 + 16 tt + 4 lg + (0..3)
 #pragma unroll
@@ -282,26 +331,35 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
       const int q = lane & 15, g = lane >> 4;
       const int row = wave * 16 + q;
       const int rswz = (row >> 1) & 7;
-      f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
+      // every fragment of the core in flight at once, through opaque reads (a visible LDS load makes hipcc drain the weight DMA
+      // queue first -- vmcnt(0) -- because it cannot tell the tiles from the DMA destinations); consumed behind counted waits
+      bf16x8 kf[2], qf[2];
+      f32x4 bq4;
+      s16x4 vf[HD / 16];
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const int pos = ((g + 4 * st) ^ rswz) << 4;
-        const bf16x8 kf = *(const bf16x8*)(sK + row * 128 + pos);
-        const bf16x8 qf = *(const bf16x8*)(sQ + row * 128 + pos);
-        sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc4, 0, 0, 0);
+        const uint32_t pos = (uint32_t)(row * 128 + (((g + 4 * st) ^ rswz) << 4));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[st]) : "v"(k_lds + pos));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qf[st]) : "v"(q_lds + pos));
       }
-      // V^T fragments (lane: d = 16 i + q, keys 4g..4g+3) do not depend on the softmax: fetch them now, use them after it
-      s16x4 vf[HD / 16];
+      asm volatile("ds_read_b128 %0, %1" : "=v"(bq4) : "v"(bias_lds + (uint32_t)((h * 256 + q * 16 + 4 * g) * 4)));
+      // V^T fragments (lane: d = 16 i + q, keys 4g..4g+3) do not depend on the softmax: fetched now, used after it
 #pragma unroll
       for (int i = 0; i < HD / 16; ++i) {
         const int d = 16 * i + q;
-        vf[i] = *(const s16x4*)(sVT + d * 256 + (((wave * 4 + g) ^ ((d & 15) << 1)) << 3));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(vf[i]) : "v"(vt_lds + (uint32_t)(d * 256 + (((wave * 4 + g) ^ ((d & 15) << 1)) << 3))));
       }
+      f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 + HD / 16) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], sc4, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(1 + HD / 16) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[1], sc4, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       // lane: query q, keys 4g .. 4g+3
-      const float4 bq = *(const float4*)(sBias + h * 256 + q * 16 + 4 * g);
-      const float bk[4] = {bq.x, bq.y, bq.z, bq.w};
-      const int64_t gc = (int64_t)blockIdx.x * 8 + wave;
-      const int cub = (int)(gc % p.nc);
+      const float bk[4] = {bq4[0], bq4[1], bq4[2], bq4[3]};
       float sc[4];
       float mx = -3.0e38f;
 #pragma unroll
@@ -310,21 +368,21 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
         float v = -INFINITY;
         if (key < vol && q < vol) {
           v = sc4[r] * p.scale + bk[r];
-          if (p.mask && !p.mask[((int64_t)cub * vol + q) * vol + key]) v = -1e18f;
+          if (p.mask && !p.mask[((int64_t)cub_of_wave * vol + q) * vol + key]) v = -1e18f;
         }
         sc[r] = v;
         mx = fmaxf(mx, v);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // reductions over the four 16-lane rows (the key groups of one query): gfx950 row / half swaps instead of two ds_bpermute
+      // round trips each
+      mx = rows4_max(mx);
       float pr[4], sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pr[r] = expf(sc[r] - mx);   // exp(-inf) = 0 for non-existent keys
         sum += pr[r];
       }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = rows4_sum(sum);
       const float inv = sum > 0.f ? 1.f / sum : 0.f;
       s16x4 pf;
 #pragma unroll
@@ -362,15 +420,20 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
     {
       const int s = 4 * h + 3;
       const char* cW = ring(s);
-      if (!(p.dbg & 8))
+      if (!(p.dbg & 8)) {
+        bf16x8 fa[2], fb[2][TN2];                  // two-deep fragment pipeline, as above
+        auto ldp = [&](int kk, int slot) {
+          const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
+          fa[slot] = *(const bf16x8*)(sQ + g2_a_row + pos);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-        const bf16x8 a = *(const bf16x8*)(sQ + g2_a_row + pos);
+          for (int t = 0; t < TN2; ++t) fb[slot][t] = *(const bf16x8*)(cW + g2_b_row + t * 32 * 128 + pos);
+        };
+        ldp(0, 0);
 #pragma unroll
-        for (int t = 0; t < TN2; ++t) {
-          const bf16x8 b = *(const bf16x8*)(cW + g2_b_row + t * 32 * 128 + pos);
-          acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[t], 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) {
+          if (kk + 1 < 4) ldp(kk + 1, (kk + 1) & 1);
+#pragma unroll
+          for (int t = 0; t < TN2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][t], acc2[t], 0, 0, 0);
         }
       }
       step_end(s);

@@ -76,7 +76,10 @@ def test_v1_unet_full_size(golden, precision):
     net.split_k = False
     assert torch.equal(net(x2.cuda(), t2.cuda(), c2.cuda())[0], net(x.cuda(), t.cuda(), cond.cuda())[0])
     net.split_k = True
-    assert rel_l2(out2[0], out[0]) < (1e-6 if precision == "fp32" else 2e-3)
+    e_inv = rel_l2(out2[0], out[0])
+    print(f"[v1 {precision}] sample 0 alone vs in a batch of 2 (different K-slicing in bf16 mode): rel-L2 {e_inv:.3e}")
+    # a different summation order perturbs at fp32 round-off; downstream bf16 roundings amplify that to (at most) the bf16 noise level
+    assert e_inv < (1e-6 if precision == "fp32" else TOL["bf16"] / 2)
 
 
 def test_repack_after_weight_update():
