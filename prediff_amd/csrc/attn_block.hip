@@ -3,51 +3,37 @@
 // :1151) -- every axial pattern of the SEVIR-LR denoiser at level 0 (units 256, 4 heads).
 //
 // Why: un-fused the block is LN -> QKV GEMM -> attention core -> proj GEMM with K = 256 GEMMs and a 2 flop/B core, i.e. four
-// HBM-bound launches that write and re-read the bf16 LN output, QKV (3 x) and attention output.  Here a workgroup owns 8 whole
-// cuboids (8 x 16 slots = 128 rows, gathered through tok_index -- the cuboid reorder / un-shift never materialises), and
+// HBM-bound launches that write and re-read the bf16 LN output, QKV (3 x) and attention output.  Here a workgroup owns 4 whole
+// cuboids (4 x 16 slots = 64 rows, gathered through tok_index -- the cuboid reorder / un-shift never materialises), and
 // nothing but x goes to HBM: one gathered fp32 read, one scattered fp32 write (+ the residual re-read).
 //
-// One workgroup = 512 threads (8 waves):
-//   phase 0   LayerNorm of the 128 gathered rows (wave w = the 16 slots of cuboid w) -> bf16 A tile in LDS -> each wave keeps the
+// One workgroup = 256 threads (4 waves), 64 rows, < 80 KB of LDS: TWO workgroups per CU.  Round 1's kernel (128 rows, 8 waves,
+// 152 KB: one workgroup per CU) spent 58 % of its time in the HBM phases (row gather, residual re-read, scatter: 87 of 148 us
+// with every GEMM and the core ablated, profiles/r02_b_attn_block_ablations.log) with idle MFMA pipes; all CUs ran those phases
+// in lock step and nothing could overlap them (a persistent variant that requested the next tile's rows early had nowhere to
+// put them before the last head: no gain).  Two independent workgroups per CU overlap one's HBM phases with the other's GEMMs
+// by construction; the price -- every 64 rows stream the 512 KB of weights instead of every 128 -- is affordable: the LDS DMA
+// sustains 114 GB/s per CU with 64 KB in flight (profiles/r02_b_ubench_dma_rate.log), this kernel needs < 50.
+//   phase 0   LayerNorm of the 64 gathered rows (wave w = the 16 slots of cuboid w) -> bf16 A tile in LDS -> each wave keeps the
 //             fragments of its 32 rows (all of K = C) in registers for the whole kernel; the A region becomes weight buffers.
-//   head h    (4 weight chunks of 32 KB: Wq_h, Wk_h, Wv_h [64 x C], Wp[:, 64h:64h+64] [C x 64], 3-deep LDS ring, DMA two chunks ahead)
-//       q, k   Q_h^T, K_h^T [64 x 128] = W * A^T (transposed product: a lane ends up with 4 consecutive d of one token -> 8 B
-//              writes into row-major [row][d] tiles, the operand layout of S^T = K Q^T)
-//       v      V_h [128 x 64] = A * Wv^T (plain product: a lane ends up with 4 consecutive tokens of one d -> 8 B writes into
+//   head h    weight chunks of 16 KB through a 3-slot LDS ring, DMA two chunks ahead:
+//             Wq_h, Wk_h, Wv_h [64 x C] as C/128 K-halves [64 x 128]; Wp[:, 64h:64h+64] [C x 64] as C/128 output halves [128 x 64]
+//       q, k   Q_h^T, K_h^T [64 x 64] = W * A^T (transposed product: a lane ends up with 4 consecutive d of one token -> 8 B
+//              writes into row-major [row][d] tiles, the operand layout of S^T = K Q^T), accumulated over the K-halves
+//       v      V_h [64 x 64] = A * Wv^T (plain product: a lane ends up with 4 consecutive tokens of one d -> 8 B writes into
 //              the [d][row] tile, the A-operand layout of O^T = V^T P^T)
 //       core   wave w, cuboid w: S^T = K Q^T (2 x mfma 16x16x32), scale, + relative-position bias, mask, softmax over keys in
-//              registers (4 values + 2 shuffles), O^T = V^T P^T (4 x mfma 16x16x16) -> O tile (over the Q tile: same rows, same wave)
-//       proj   acc[128 x C] += O_h[128 x 64] * Wp_h^T
+//              registers (4 values + 2 row swaps), O^T = V^T P^T (4 x mfma 16x16x16) -> O tile (over the Q tile: same rows, same wave)
+//       proj   acc[64 x C] += O_h[64 x 64] * Wp_h^T, one output half per chunk
 //   epilogue  acc + b_proj + x -> out rows (scatter through the same token table).
-// LDS: weight ring 3 x 32 KB (two of them = the A region) + Q/O, K, V^T tiles 3 x 16 KB + bias tables + token ids = 152 KB.
+// LDS: weight ring 3 x 16 KB (two slots = the A region) + Q/O, K, V^T tiles 3 x 8 KB + bias tables + token ids = 79 KB.
 // Numerics are those of the un-fused bf16 path (bf16 LN output, bf16 q/k/v/P/O, fp32 accumulation, fp32 softmax).
+#include <algorithm>
 #include "common.h"
 #include "ln_tile.h"
 
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
-
-// W fragment of k-step ks (32 deep), feature tile dt of a 32 KB weight chunk: slab (ks >> 1), row tn*32 + dt*16 + l16, 16 B chunk
-// ((ks & 1) * 4 + lg) ^ swz16.  The lane part (row, chunk of an even k-step) sits in a VGPR, an odd k-step flips bit 6 of it, the
-// rest is the instruction's immediate offset.
-#define WFRAG_LD(dst, base_vgpr, ks, dt)                                                                                          \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(((ks) & 1) ? ((base_vgpr) ^ 64u) : (base_vgpr)),               \
-               "n"(((ks) >> 1) * 8192 + (dt) * 2048))
-#define WFRAG_PROLOGUE(w, wb)                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < PF; ++i_) {                              \
-    WFRAG_LD(w[i_][0], wb, i_, 0);                                                 \
-    WFRAG_LD(w[i_][1], wb, i_, 1);                                                 \
-  }
-// issue the reads of k-step ks + PF, then wait until those of k-step ks have landed (LDS returns in order: 2 reads per step)
-#define WFRAG_STEP(w, wb, ks)                                                      \
-  if ((ks) + PF < KS * 2) {                                                        \
-    WFRAG_LD(w[((ks) + PF) % (PF + 1)][0], wb, (ks) + PF, 0);                      \
-    WFRAG_LD(w[((ks) + PF) % (PF + 1)][1], wb, (ks) + PF, 1);                      \
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PF) : "memory");               \
-  } else {                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KS * 2 - 1 - (ks))) : "memory"); \
-  }                                                                                \
-  __builtin_amdgcn_sched_barrier(0);
 
 // combine a value over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48), result in every lane: v_permlane16_swap /
 // v_permlane32_swap exchange odd and even rows / the two halves in one VALU instruction each (no LDS crossbar round trip)
@@ -64,6 +50,28 @@ __device__ __forceinline__ float rows4_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// W fragment of k-step ks (32 deep, NSTEP = 4 per chunk), feature tile dt of a 16 KB [64 d][128 k] weight chunk: slab (ks >> 1),
+// row tn*32 + dt*16 + l16, 16 B chunk ((ks & 1) * 4 + lg) ^ swz16.  The lane part (row, chunk of an even k-step) sits in a VGPR,
+// an odd k-step flips bit 6 of it, the rest is the instruction's immediate offset.
+#define WFRAG_LD(dst, base_vgpr, ks, dt)                                                                                          \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(((ks) & 1) ? ((base_vgpr) ^ 64u) : (base_vgpr)),               \
+               "n"(((ks) >> 1) * 8192 + (dt) * 2048))
+#define WFRAG_PROLOGUE(w, wb)                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < PF; ++i_) {                              \
+    WFRAG_LD(w[i_][0], wb, i_, 0);                                                 \
+    WFRAG_LD(w[i_][1], wb, i_, 1);                                                 \
+  }
+// issue the reads of k-step ks + PF, then wait until those of k-step ks have landed (LDS returns in order: 2 reads per step)
+#define WFRAG_STEP(w, wb, ks)                                                      \
+  if ((ks) + PF < NSTEP) {                                                         \
+    WFRAG_LD(w[((ks) + PF) % (PF + 1)][0], wb, (ks) + PF, 0);                      \
+    WFRAG_LD(w[((ks) + PF) % (PF + 1)][1], wb, (ks) + PF, 1);                      \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PF) : "memory");               \
+  } else {                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NSTEP - 1 - (ks))) : "memory"); \
+  }                                                                                \
+  __builtin_amdgcn_sched_barrier(0);
+
 struct pd_attn_block_args_k {
   const float* x;
   float* out;
@@ -79,37 +87,41 @@ struct pd_attn_block_args_k {
   int B, ntok, nc, vol;
   float scale, eps;
   uint32_t wqkv_bytes, wp_bytes;
-  unsigned long long* trace;   // profiling only: per-phase clock stamps of wave 0 of workgroup 300 (null in production)
+  unsigned long long* trace;   // profiling only: per-phase clock stamps of wave 0 of workgroup 600 (null in production)
   int dbg;   // profiling ablations: 1 no weight DMA after chunk 2, 2 no q/k/v GEMMs, 4 no attention core, 8 no proj GEMM,
              // 16 no LN loads, 32 no residual loads, 64 no stores
 };
 
 template <int C>
-__global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_args_k p) {
+__global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 128, HD = 64, HEADS = C / HD;
-  constexpr int KS = C / 64;                       // 64-wide K slabs of the A tile / weight chunks
-  constexpr int CHUNK = 64 * C * 2;                // bytes of one weight chunk (64 x C or C x 64 bf16)
+  constexpr int BM = 64, HD = 64, HEADS = C / HD;
+  constexpr int KS = C / 64;                       // 64-wide K slabs of the A tile
+  constexpr int KH = C / 128;                      // K halves of a head's Wq / Wk / Wv slice: chunks [64 d][128 k]
+  constexpr int OH = C / 128;                      // output halves of a head's Wp slice: chunks [128 out][64 k]
+  constexpr int NSTEP = 4;                         // k-steps of 32 in a q/k/v chunk
+  constexpr int CHUNK = 16384;                     // bytes of every weight chunk = two [64 rows][64 k] bf16 slabs
   constexpr int A_BYTES = BM * C * 2;
-  static_assert(A_BYTES == 2 * CHUNK, "the A region becomes two ring buffers");
-  constexpr int TILE = BM * HD * 2;                // 16 KB
-  constexpr int TN2 = (C / 2) / 32;                // 32x32 tiles per wave in the proj GEMM (wave tile 32 x C/2)
-  constexpr int NCHUNK = 4 * HEADS;
+  static_assert(A_BYTES <= 2 * CHUNK, "the A region becomes ring slots 0 and 1");
+  constexpr int TILE = BM * HD * 2;                // 8 KB
+  constexpr int NCH = 3 * KH + OH;                 // weight chunks per head
+  constexpr int NCHUNK = HEADS * NCH;
+  constexpr int NDMA = CHUNK / 4096;               // DMA instructions per chunk (256 threads x 16 B each)
   constexpr int PF = 2;                            // weight-fragment prefetch distance of the q/k/v GEMMs, in k-steps of 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                                 // A tile, then ring buffers 0 and 1
-  char* sR2 = sA + A_BYTES;                        // ring buffer 2
+  char* sA = smem;                                 // A tile, then ring slots 0 and 1
+  char* sR2 = sA + 2 * CHUNK;                      // ring slot 2
   char* sQ = sR2 + CHUNK;                          // Q tile [row][d], re-used for O
   char* sK = sQ + TILE;                            // K tile [row][d]
   char* sVT = sK + TILE;                           // V^T tile [d][row]
   float* sBias = (float*)(sVT + TILE);             // [HEADS][16][16]
-  int* sTok = (int*)(sBias + HEADS * 256);         // [128] global row of every slot, -1 = no token
+  int* sTok = (int*)(sBias + HEADS * 256);         // [64] global row of every slot, -1 = no token
   float* sBq = (float*)(sTok + BM);                // [3C] qkv bias (zeros without one): an ordinary global load inside the head loop
                                                    // would make hipcc drain the weight DMA queue (vmcnt(0)) at every use
 
   if (p.dbg & 128) return;   // ablation: workgroup dispatch cost only
   int tr_n = 0;
-#define TRACE() do { if (p.trace && blockIdx.x == 300 && threadIdx.x == 0) p.trace[tr_n] = clock64(); ++tr_n; } while (0)
+#define TRACE() do { if (p.trace && blockIdx.x == 600 && threadIdx.x == 0) p.trace[tr_n] = clock64(); ++tr_n; } while (0)
   TRACE();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -119,34 +131,38 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   const auto rWqkv = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wqkv, 0, p.wqkv_bytes, 0x00020000);
   const auto rWp = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, p.wp_bytes, 0x00020000);
 
-  // DMA lane mapping: one 512-thread instruction fills one [64 rows][64 k] slab (8 KB), lane-linear, source-side swizzle
+  // DMA lane mapping: one 256-thread instruction fills half a slab = [32 rows][64 k] (4 KB), lane-linear, source-side swizzle.
+  // Every chunk is 2 slabs x 2 row halves; instruction i = slab (i >> 1), rows 32 (i & 1) .. +31 (the swizzle, (row >> 1) & 7,
+  // does not see the + 32): ONE per-lane offset serves all chunks, the rest is the instruction's scalar offset.
   const int drow = tid >> 3, dpos = tid & 7;
   const int dchunk = dpos ^ ((drow >> 1) & 7);
-  const uint32_t wq_voff = ((uint32_t)drow * C + dchunk * 8) * 2u;                 // + ((kind*C + h*64)*C + s*64)*2 in the SGPR offset
-  uint32_t wp_voff[KS];
-#pragma unroll
-  for (int i = 0; i < KS; ++i) wp_voff[i] = ((uint32_t)(i * 64 + drow) * C + dchunk * 8) * 2u;   // + h*64*2
-  auto ring = [&](int s) {                          // chunk s lives in ring buffer (s + 2) % 3
+  const uint32_t w_voff = ((uint32_t)drow * C + dchunk * 8) * 2u;
+  auto ring = [&](int s) {                          // chunk s lives in ring slot (s + 2) % 3
     const int b = (s + 2) % 3;
     return b == 2 ? sR2 : sA + b * CHUNK;
   };
-  auto issue_chunk = [&](int s) {                   // s = 4 * head + kind (0 q, 1 k, 2 v, 3 proj)
+  // chunk s = NCH * head + j:  j < 3 KH: kind j / KH (0 q, 1 k, 2 v), K half j % KH;  else proj output half j - 3 KH
+  auto issue_chunk = [&](int s) {
     char* d = ring(s) + wave * 1024;
-    const int kind = s & 3, h = s >> 2;
-    if (kind < 3) {
+    const int h = s / NCH, j = s - h * NCH;
+    if (j < 3 * KH) {
+      const int kind = j / KH, kh = j - kind * KH;
 #pragma unroll
-      for (int i = 0; i < KS; ++i) BLDS16(rWqkv, d + i * 8192, wq_voff, ((kind * C + h * HD) * C + i * 64) * 2);
+      for (int i = 0; i < NDMA; ++i)
+        BLDS16(rWqkv, d + i * 4096, w_voff, ((kind * C + h * HD + (i & 1) * 32) * C + (2 * kh + (i >> 1)) * 64) * 2);
     } else {
+      const int oh = j - 3 * KH;
 #pragma unroll
-      for (int i = 0; i < KS; ++i) BLDS16(rWp, d + i * 8192, wp_voff[i], h * HD * 2);
+      for (int i = 0; i < NDMA; ++i)
+        BLDS16(rWp, d + i * 4096, w_voff, ((oh * 128 + (i >> 1) * 64 + (i & 1) * 32) * C + h * HD) * 2);
     }
   };
   issue_chunk(0);
 
-  // ---- token table of the 8 cuboids, relative-position bias (padded to 16 x 16 per head) ----
+  // ---- token table of the 4 cuboids, relative-position bias (padded to 16 x 16 per head) ----
   if (tid < BM) {
     const int cl = tid >> 4, slot = tid & 15;
-    const int64_t gc = (int64_t)blockIdx.x * 8 + cl;
+    const int64_t gc = (int64_t)blockIdx.x * 4 + cl;
     int row = -1;
     if (gc < (int64_t)p.B * p.nc && slot < vol) {
       const int b = (int)(gc / p.nc), c = (int)(gc - (int64_t)b * p.nc);
@@ -155,33 +171,31 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
     }
     sTok[tid] = row;
   }
-  for (int i = tid; i < 3 * C; i += 512) sBq[i] = p.bqkv ? p.bqkv[i] : 0.f;
-  for (int i = tid; i < HEADS * 256; i += 512) {
+  for (int i = tid; i < 3 * C; i += 256) sBq[i] = p.bqkv ? p.bqkv[i] : 0.f;
+  for (int i = tid; i < HEADS * 256; i += 256) {
     const int h = i >> 8, q = (i >> 4) & 15, k = i & 15;
     sBias[i] = (q < vol && k < vol) ? p.bias[((int64_t)h * vol + q) * vol + k] : 0.f;
   }
   __syncthreads();
   TRACE();
 
-  // ---- phase 0: LayerNorm of the gathered rows -> bf16 A tile (KS slabs of [128][64], chunk swizzle (row>>1)&7) ----
-  ln_block_to_tile<C>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, (p.dbg & 16) != 0, [&](int r) { return sTok[r]; });
+  // ---- phase 0: LayerNorm of the gathered rows -> bf16 A tile (KS slabs of [64][64], chunk swizzle (row>>1)&7) ----
+  ln_block_to_tile<C, BM>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, (p.dbg & 16) != 0, [&](int r) { return sTok[r]; });
 
   TRACE();
   // ---- wave roles ----
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int swz = (lrow >> 1) & 7;
-  // q/k/v GEMMs: wave -> d tile tn (of 2) x row tile tq (of 4)
+  // q/k/v GEMMs: wave -> d tile tn (of 2) x row tile tq (of 2)
   const int tn = wave & 1, tq = wave >> 1;
-  const int g1_w_row = (tn * 32 + lrow) * 128;     // weight chunk row (feature d) inside a slab
-  const int g1_a_row = (tq * 32 + lrow) * 128;     // A tile row (slot) inside a slab
-  // proj GEMM: wave -> row tile wm (of 4) x column half wn (of 2)
+  // proj GEMM: wave -> row tile wm (of 2) x 64-column quarter wn (of 2) of every 128-column output half
   const int wm = wave >> 1, wn = wave & 1;
   const int g2_a_row = (wm * 32 + lrow) * 128;     // O row
-  const int g2_b_row = (wn * (C / 2) + lrow) * 128;   // Wp chunk row (output channel)
+  const int g2_b_row = wn * 8192 + lrow * 128;     // Wp chunk: slab wn (64 output channels), + t * 32 rows
 
-  f32x16 acc2[TN2];
+  f32x16 acc2[OH * 2];                             // [output half][32-column tile]: columns oh*128 + wn*64 + t*32 + (lane & 31)
 #pragma unroll
-  for (int t = 0; t < TN2; ++t)
+  for (int t = 0; t < OH * 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 
@@ -205,7 +219,7 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
 #pragma unroll
     for (int r = 0; r < 4; ++r) vrow_ok |= (sTok[tq * 32 + tt * 16 + 4 * lg + r] >= 0 ? 1u : 0u) << (tt * 4 + r);
   }
-  __syncthreads();                                        // A-tile region is now free: ring buffers 0 and 1
+  __syncthreads();                                        // A-tile region is now free: ring slots 0 and 1
   issue_chunk(1);
   issue_chunk(2);
   TRACE();
@@ -213,10 +227,10 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   const uint32_t w_lane_off = (uint32_t)((tn * 32 + l16) * 128 + ((lg ^ swz16) << 4));
   const uint32_t q_lds = (uint32_t)(uintptr_t)sQ, k_lds = (uint32_t)(uintptr_t)sK, vt_lds = (uint32_t)(uintptr_t)sVT;
   const uint32_t bq_lds = (uint32_t)(uintptr_t)sBq, bias_lds = (uint32_t)(uintptr_t)sBias;
-  const int cub_of_wave = (int)(((int64_t)blockIdx.x * 8 + wave) % p.nc);        // cuboid (mask table row) of this wave's core
-  // end of a weight-chunk step: chunk s+1 has landed (chunk s+2 may stay in flight), everyone is done with chunk s, refill its buffer
+  const int cub_of_wave = (int)(((int64_t)blockIdx.x * 4 + wave) % p.nc);        // cuboid (mask table row) of this wave's core
+  // end of a weight-chunk step: chunk s+1 has landed (chunk s+2 may stay in flight), everyone is done with chunk s, refill its slot
   auto step_end = [&](int s) {
-    if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS) : "memory");
+    if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -225,11 +239,9 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
 
   for (int h = 0; h < HEADS; ++h) {
     TRACE();
-    // ---------------- q and k: transposed products ----------------
+    // ---------------- q and k: transposed products, accumulated over the K halves ----------------
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
-      const int s = 4 * h + kind;
-      const char* cW = ring(s);
       // 2 x 2 tiles of 16 x 16 (feature tile dt x slot tile tt): four independent accumulator chains in 16 registers
       f32x4 acc1[2][2];
 #pragma unroll
@@ -238,23 +250,28 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc1[dt][tt][r] = 0.f;
-      if (!(p.dbg & 2)) {
-        // Hand-placed fragment pipeline (PF k-steps ahead).  Left to itself hipcc keeps ONE fragment register set and waits
-        // lgkmcnt(0) in front of every MFMA pair (it re-serialises a source-level double buffer, too): 16 exposed LDS round trips per
-        // chunk, ~2.7k clocks for 1.0k clocks of MFMA work.  Opaque ds_reads + counted waits + sched_barrier pin the order.
-        bf16x8 w[PF + 1][2];
-        const uint32_t wb = (uint32_t)(uintptr_t)cW + w_lane_off;
-        WFRAG_PROLOGUE(w, wb)
 #pragma unroll
-        for (int ks = 0; ks < KS * 2; ++ks) {
-          WFRAG_STEP(w, wb, ks)
+      for (int kh = 0; kh < KH; ++kh) {
+        const int s = NCH * h + kind * KH + kh;
+        if (!(p.dbg & 2)) {
+          // Hand-placed fragment pipeline (PF k-steps ahead).  Left to itself hipcc keeps ONE fragment register set and waits
+          // lgkmcnt(0) in front of every MFMA pair (it re-serialises a source-level double buffer, too).  Opaque ds_reads +
+          // counted waits + sched_barrier pin the order.
+          bf16x8 w[PF + 1][2];
+          const uint32_t wb = (uint32_t)(uintptr_t)ring(s) + w_lane_off;
+          WFRAG_PROLOGUE(w, wb)
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
+          for (int ks = 0; ks < NSTEP; ++ks) {
+            WFRAG_STEP(w, wb, ks)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-              acc1[dt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks % (PF + 1)][dt], areg[tt][ks], acc1[dt][tt], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+                acc1[dt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks % (PF + 1)][dt], areg[tt][kh * NSTEP + ks], acc1[dt][tt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
+        if (kh + 1 < KH) step_end(s);
       }
       // tile (dt, tt): lane = slot row tq*32 + 16 tt + l16, features tn*32 + 16 dt + 4 lg + (0..3)
       const uint32_t t_lds = kind == 0 ? q_lds : k_lds;
@@ -275,13 +292,11 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
           asm volatile("ds_write_b64 %0, %1" ::"v"(t_lds + (uint32_t)off), "v"(pk) : "memory");
         }
       }
-      step_end(s);
+      step_end(NCH * h + kind * KH + KH - 1);
     }
     // ---------------- v: plain product, stored transposed ----------------
     TRACE();
     {
-      const int s = 4 * h + 2;
-      const char* cW = ring(s);
       f32x4 acc1[2][2];                                        // [slot tile tt][feature tile dt]
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
@@ -289,20 +304,25 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc1[tt][dt][r] = 0.f;
-      if (!(p.dbg & 2)) {
-        bf16x8 w[PF + 1][2];
-        const uint32_t wb = (uint32_t)(uintptr_t)cW + w_lane_off;
-        WFRAG_PROLOGUE(w, wb)
 #pragma unroll
-        for (int ks = 0; ks < KS * 2; ++ks) {
-          WFRAG_STEP(w, wb, ks)
+      for (int kh = 0; kh < KH; ++kh) {
+        const int s = NCH * h + 2 * KH + kh;
+        if (!(p.dbg & 2)) {
+          bf16x8 w[PF + 1][2];
+          const uint32_t wb = (uint32_t)(uintptr_t)ring(s) + w_lane_off;
+          WFRAG_PROLOGUE(w, wb)
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
+          for (int ks = 0; ks < NSTEP; ++ks) {
+            WFRAG_STEP(w, wb, ks)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-              acc1[tt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[tt][ks], w[ks % (PF + 1)][dt], acc1[tt][dt], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+              for (int dt = 0; dt < 2; ++dt)
+                acc1[tt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[tt][kh * NSTEP + ks], w[ks % (PF + 1)][dt], acc1[tt][dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
+        if (kh + 1 < KH) step_end(s);
       }
       // tile (tt, dt): lane = feature d = tn*32 + 16 dt + l16, slot rows tq*32 + 16 tt + 4 lg + (0..3)
 #pragma unroll
@@ -318,12 +338,12 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
           if (!((vrow_ok >> (4 * tt + 2)) & 1u)) v2 = 0.f;
           if (!((vrow_ok >> (4 * tt + 3)) & 1u)) v3 = 0.f;
           const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
-          const int c4 = tq * 8 + tt * 4 + lg;                                     // 4-row chunk of the [d][128 rows] tile
-          const int off = d * 256 + ((c4 ^ ((d & 15) << 1)) << 3);                 // chunk XOR: conflict-free 8 B reads by (d, 4-row group)
+          const int c4 = tq * 8 + tt * 4 + lg;                                     // 4-row group of the [d][64 rows] tile
+          const int off = d * 128 + ((c4 ^ (d & 15)) << 3);                        // group XOR: conflict-free 8 B reads by (d, 4-row group)
           asm volatile("ds_write_b64 %0, %1" ::"v"(vt_lds + (uint32_t)off), "v"(pk) : "memory");
         }
       }
-      step_end(s);
+      step_end(NCH * h + 3 * KH - 1);
     }
     TRACE();
     // ---------------- attention core: wave w = cuboid w of this workgroup ----------------
@@ -347,7 +367,7 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
 #pragma unroll
       for (int i = 0; i < HD / 16; ++i) {
         const int d = 16 * i + q;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(vf[i]) : "v"(vt_lds + (uint32_t)(d * 256 + (((wave * 4 + g) ^ ((d & 15) << 1)) << 3))));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(vf[i]) : "v"(vt_lds + (uint32_t)(d * 128 + (((wave * 4 + g) ^ (d & 15)) << 3))));
       }
       f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 + HD / 16) : "memory");
@@ -416,24 +436,26 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                           // O_h visible to every wave (weight DMA stays in flight)
     TRACE();
-    // ---------------- proj: acc2 += O_h * Wp_h^T ----------------
-    {
-      const int s = 4 * h + 3;
+    // ---------------- proj: acc2 += O_h * Wp_h^T, one 128-column output half per chunk ----------------
+#pragma unroll
+    for (int oh = 0; oh < OH; ++oh) {
+      const int s = NCH * h + 3 * KH + oh;
       const char* cW = ring(s);
       if (!(p.dbg & 8)) {
-        bf16x8 fa[2], fb[2][TN2];                  // two-deep fragment pipeline, as above
+        bf16x8 fa[2], fb[2][2];                    // two-deep fragment pipeline
         auto ldp = [&](int kk, int slot) {
           const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
           fa[slot] = *(const bf16x8*)(sQ + g2_a_row + pos);
 #pragma unroll
-          for (int t = 0; t < TN2; ++t) fb[slot][t] = *(const bf16x8*)(cW + g2_b_row + t * 32 * 128 + pos);
+          for (int t = 0; t < 2; ++t) fb[slot][t] = *(const bf16x8*)(cW + g2_b_row + t * 32 * 128 + pos);
         };
         ldp(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           if (kk + 1 < 4) ldp(kk + 1, (kk + 1) & 1);
 #pragma unroll
-          for (int t = 0; t < TN2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][t], acc2[t], 0, 0, 0);
+          for (int t = 0; t < 2; ++t)
+            acc2[oh * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][t], acc2[oh * 2 + t], 0, 0, 0);
         }
       }
       step_end(s);
@@ -441,16 +463,16 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
   }
 
   TRACE();
-  // ---- epilogue: acc2 -> per-wave LDS slab [32][C/2] fp32 -> + b_proj + x -> out rows of the token table ----
-  constexpr int WN = C / 2;
+  // ---- epilogue: acc2 -> per-wave LDS slab [32][OH * 64] fp32 -> + b_proj + x -> out rows of the token table ----
+  constexpr int WN = OH * 64;                      // columns per wave: OH pieces of 64
   constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 32 at C = 256
   constexpr int RPP = 64 / LPR;
   constexpr int NPASS = 32 / RPP;
-  const int c0 = (lane % LPR) * 4;
-  const int n = wn * WN + c0;
+  const int c0 = (lane % LPR) * 4;                 // slab column; output column = 128 * (c0 / 64) + 64 wn + c0 % 64
+  const int n = (c0 >> 6) * 128 + wn * 64 + (c0 & 63);
   float* sC = (float*)smem + wave * (32 * WN);     // (the last step_end left every wave past its weight / tile reads)
 #pragma unroll
-  for (int t = 0; t < TN2; ++t)
+  for (int t = 0; t < OH * 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + t * 32 + lrow] = acc2[t][r];
   // every residual row of this lane in flight at once (the accumulators are dead now): one exposed HBM round trip
@@ -480,9 +502,11 @@ __global__ void __launch_bounds__(512) attn_block_kernel(const pd_attn_block_arg
 template <int C>
 static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   constexpr int heads = C / 64;
-  constexpr int lds = 128 * C * 2 + 64 * C * 2 + 3 * 128 * 64 * 2 + heads * 256 * 4 + 128 * 4 + 3 * C * 4;
-  constexpr int epi = 8 * 32 * (C / 2) * 4;
-  static_assert(epi <= 128 * C * 2 + 64 * C * 2 + 3 * 128 * 64 * 2, "the epilogue slab must not reach the token table");
+  constexpr int work = 3 * 16384 + 3 * 64 * 64 * 2;                 // weight ring + Q, K, V^T tiles: re-used by the epilogue slab
+  constexpr int lds = work + heads * 256 * 4 + 64 * 4 + 3 * C * 4;
+  constexpr int epi = 4 * 32 * ((C / 128) * 64) * 4;
+  static_assert(epi <= work, "the epilogue slab must not reach the bias / token tables");
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_block_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -493,7 +517,7 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
     attr_set = true;
   }
   const int64_t cuboids = (int64_t)a.B * a.nc;
-  hipLaunchKernelGGL((attn_block_kernel<C>), dim3((unsigned)((cuboids + 7) / 8)), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((attn_block_kernel<C>), dim3((unsigned)((cuboids + 3) / 4)), dim3(256), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }

@@ -1,4 +1,4 @@
-// LayerNorm of a 128-row block straight into the swizzled bf16 A tile of the fused kernels (ffn.hip, attn_block.hip).
+// LayerNorm of a BM-row block (16 rows per wave) straight into the swizzled bf16 A tile of the fused kernels (ffn.hip, attn_block.hip).
 //
 // A row is spread over the 16 lanes of one DPP row (C/64 float4 per lane), four rows per wave instruction: the two reductions
 // of a row are 4 v_add_f32 with DPP modifiers each (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) -- no LDS crossbar.
@@ -21,8 +21,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // wave `wave` normalises rows wave*16 .. wave*16+15 of the block; row_of(r) gives the global row (or -1: the tile row is zero).
-// sA: KS = C/64 slabs of [128 rows][64 k] bf16, 16 B chunk index XOR (row >> 1) & 7 (the layout the MFMA fragment reads expect).
-template <int C, typename RowOf>
+// sA: KS = C/64 slabs of [BM rows][64 k] bf16, 16 B chunk index XOR (row >> 1) & 7 (the layout the MFMA fragment reads expect).
+template <int C, int BM = 128, typename RowOf>
 __device__ __forceinline__ void ln_block_to_tile(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float eps, char* sA, int wave, int lane, bool skip_loads, RowOf row_of) {
   constexpr int NV = C / 64;                       // float4 per lane
@@ -65,7 +65,7 @@ __device__ __forceinline__ void ln_block_to_tile(const float* __restrict__ x, co
       float y2 = (xv[bt][i].z - mean) * rstd * g4[i].z + b4[i].z, y3 = (xv[bt][i].w - mean) * rstd * g4[i].w + b4[i].w;
       if (!ok) y0 = y1 = y2 = y3 = 0.f;
       // columns 4j + 64i .. +3: slab i, 16 B chunk j >> 1, half j & 1
-      const int off = i * (128 * 128) + row * 128 + (((j >> 1) ^ ((row >> 1) & 7)) << 4) + ((j & 1) << 3);
+      const int off = i * (BM * 128) + row * 128 + (((j >> 1) ^ ((row >> 1) & 7)) << 4) + ((j & 1) << 3);
       *(uint2*)(sA + off) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
     }
   }

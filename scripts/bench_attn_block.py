@@ -6,7 +6,10 @@ from prediff_amd.packing import pack_linear
 from prediff_amd.cuboid_geometry import attention_tables
 dbg = ctypes.c_int.in_dll(L.lib(), "pd_attn_block_debug_flags")
 dbg.value = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-B, Cn, heads = 32, 256, 4
+class _P:          # (round-2 experiment knob, gone: the kernel is no longer persistent)
+    value = 0
+pers = _P()
+B, Cn, heads = (int(sys.argv[3]) if len(sys.argv) > 3 else 32), 256, 4
 shape = (13, 16, 16)
 ntok = 13 * 16 * 16
 for cuboid in ((13, 1, 1), (1, 16, 1)):
@@ -31,9 +34,9 @@ for cuboid in ((13, 1, 1), (1, 16, 1)):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
     gf = B * (2 * ntok * 768 * 256 + 2 * ntok * 256 * 256 + 4 * ntok * vol * 256) / 1e9
-    print(f"[dbg {dbg.value}] attn_block L0 B={B} cuboid {cuboid}: {us:.1f} us  {gf * 1e3 / us:.1f} TFLOP/s")
+    print(f"[dbg {dbg.value} persistent {pers.value}] attn_block L0 B={B} cuboid {cuboid}: {us:.1f} us  {gf * 1e3 / us:.1f} TFLOP/s")
 
-# per-phase clock stamps (wave 0 of workgroup 300)
+# per-phase clock stamps (wave 0 of workgroup 600)
 tr = torch.zeros(64, dtype=torch.int64, device="cuda")
 ctypes.c_void_p.in_dll(L.lib(), "pd_attn_block_trace").value = tr.data_ptr()
 L.attn_block_fused(*args)
@@ -41,5 +44,5 @@ torch.cuda.synchronize()
 ctypes.c_void_p.in_dll(L.lib(), "pd_attn_block_trace").value = None
 t = tr.cpu().tolist()
 n = max(i for i, v in enumerate(t) if v) + 1
-names = ["start", "tables", "LN"," areg+issue"] + sum([[f"h{h} begin", f"h{h} q,k done", f"h{h} v done", f"h{h} core done"] for h in range(4)], []) + ["loop end", "end"]
+names = ["start", "tables", "LN", "areg+issue"] + sum([[f"h{h} begin", f"h{h} q,k done", f"h{h} v done", f"h{h} core done"] for h in range(4)], []) + ["proj3+chunk0", "epilogue"]
 print("phase durations (shader clocks): " + ", ".join(f"{names[i] if i < len(names) else i}:{t[i] - t[i - 1]}" for i in range(1, n)), " total", t[n - 1] - t[0])
