@@ -37,28 +37,39 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF; 2495 TF measured)
 UNET_GFLOP_PER_STEP = 653.4        # one denoiser forward, one trajectory (2*MAC)
 CONV3D_GFLOP_PER_STEP = 376.9 + 14.9   # 32 TimeEmbedResBlock convs + first_proj
+# --config: BASELINE.json configs[1] (the metric's configuration) and configs[4] (full resolution; its fp8 operand path is not
+# built: the line says dtype bf16 and is a bring-up measurement of the same engine on the 48x48 latent grid)
+WORKLOADS = {
+    "v1": dict(unet="V1_UNET_CFG", ldm="V1_LDM_KW", cond=(7, 16, 16, 64), unet_gflop=653.4, conv3d_gflop=376.9 + 14.9, tokens=3328,
+               label="SEVIR-LR 7->6 x128x128 (latent 13x16x16, C 256/512, depth [4,4], axial), DDIM-50 eta=0, "
+                     "no knowledge alignment (BASELINE.json configs[1])"),
+    "fullres": dict(unet="FULLRES_UNET_CFG", ldm="FULLRES_LDM_KW", cond=(13, 48, 48, 64), unet_gflop=11360.0, conv3d_gflop=6920.0, tokens=57600,
+                    label="SEVIR full-res 13->12 x384x384 (latent 25x48x48, C 256/512, depth [4,4], axial cuboids 25/48/48), DDIM-50 "
+                          "eta=0, bf16 operands (BASELINE.json configs[4] geometry; its fp8 path is not built)"),
+}
 CONV3D_LAUNCHES_PER_STEP = 34
 CONV3D_KERNEL_LABEL = "igemm256_kernel<2,8> | igemm_kernel<128,128,64,2,false,2,2,1> per launch (Conv3d 3x3x3 implicit GEMM)"
 
 
-def v1_model(precision, device):
+def v1_model(precision, device, workload="v1"):
+    from prediff_amd import presets
     from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
     from prediff_amd.latent_diffusion import LatentDiffusion
-    from prediff_amd.presets import V1_LDM_KW, V1_UNET_CFG
     from prediff_amd.seeding import seeded_state_dict
-    net = CuboidTransformerUNet(**V1_UNET_CFG, precision=precision)
+    w = WORKLOADS[workload]
+    net = CuboidTransformerUNet(**getattr(presets, w["unet"]), precision=precision)
     net.load_state_dict(seeded_state_dict(net.state_dict(), 1234))
-    ldm = LatentDiffusion(torch_nn_module=net, first_stage_model=None, cond_stage_model=None, **V1_LDM_KW)
+    ldm = LatentDiffusion(torch_nn_module=net, first_stage_model=None, cond_stage_model=None, **getattr(presets, w["ldm"]))
     return ldm.to(device).eval()
 
 
-def kernel_times(ldm, B, device, reps=3):
+def kernel_times(ldm, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
     """Average duration (s) of (a) the Conv3d implicit-GEMM launches and (b) the fused level-0 cuboid-attention block launches of
     one denoiser forward, measured with HIP events on the launch stream (eager mode: one event pair per launch)."""
     from prediff_amd import _lib as L
     net = ldm.torch_nn_module
     z = torch.randn(ldm.get_batch_latent_shape(B), device=device)
-    zc = torch.randn((B, 7, 16, 16, 64), device=device)
+    zc = torch.randn((B,) + tuple(cond_shape), device=device)
     t = torch.full((B,), 500, dtype=torch.long, device=device)
     orig_igemm, orig_attn = L.igemm, L.attn_block_fused
     conv_pairs, attn_pairs = [], []
@@ -126,9 +137,7 @@ def lanes_for(batch, args):
     """Lanes for a small per-GPU batch: sub-batches of >= 2 trajectories on concurrent streams (measured, profiles/r02_*sweep*)."""
     if args.small_streams:
         return args.small_streams
-    if batch >= 32:
-        return 2
-    return 2 if batch >= 4 else 1
+    return 2 if batch >= 16 else 1      # r02 sweeps: 4 x 1 / 4 x 2 = 543 / 527 steps/s, 8 x 1 / 8 x 2 = 802 / 827, 16 x 2 best
 
 
 def main():
@@ -139,6 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="latent trajectories (ensemble members) per GPU")
     ap.add_argument("--streams", type=int, default=2, help="lanes: the batch advances as this many equal sub-batches on concurrent HIP streams")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--config", default="v1", choices=sorted(WORKLOADS), help="v1 = BASELINE configs[1] (the metric); fullres = configs[4] geometry, bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ensemble", type=int, default=32, help="members of the ONE ensemble timed as the strong-scaling line (BASELINE config 3)")
     ap.add_argument("--small-streams", type=int, default=0, help="lanes for the small-batch / strong-scaling lines (0 = automatic)")
@@ -166,6 +176,9 @@ def main():
     import numpy as np
     from prediff_amd import _lib as L
     from prediff_amd.schedule import make_ddim_sampling_parameters, make_ddim_timesteps
+    WL = WORKLOADS[args.config]
+    if args.config == "fullres" and args.batch == 64:
+        args.batch = 8            # BASELINE config 5: ensemble 64 over 8 GPUs
     B = args.batch
     global CONV3D_KERNEL_LABEL
     if args.igemm_debug:
@@ -178,12 +191,12 @@ def main():
         CONV3D_KERNEL_LABEL = "igemm_kernel<128,128,64,2,false,2,2,1> (Conv3d 3x3x3 implicit GEMM)"
         import ctypes
         ctypes.c_int.in_dll(L.lib(), "pd_igemm_disable_256").value = 1
-    ldm = v1_model(args.precision, device)
+    ldm = v1_model(args.precision, device, args.config)
     ldm.torch_nn_module.fuse_ffn = not args.no_fused_ffn
     ldm.torch_nn_module.fuse_attn = not args.no_fused_attn
     shape = ldm.get_batch_latent_shape(B)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    zc = torch.randn((B, 7, 16, 16, 64), generator=g).to(device)
+    zc = torch.randn((B,) + WL["cond"], generator=g).to(device)
     z = torch.randn(shape, generator=g).to(device)
 
     # DDIM-50 schedule of the reference helpers, cycled if steps > 50
@@ -263,7 +276,7 @@ def main():
     #      per-GPU sub-batch = ensemble / n_gpus), and the small per-GPU batches it implies, reported beside the headline ----
     strong = None
     small = {}
-    if not args.no_extra and not args.no_graph:
+    if not args.no_extra and not args.no_graph and args.config == "v1":
         E = args.ensemble
         k_extra = min(args.steps, 20)
         if E % world == 0 and E // world <= B:
@@ -281,12 +294,12 @@ def main():
         n_gpus = world
         value = n_gpus * B * args.steps / elapsed
         ldm.num_streams = S
-        ker_s, launches, attn_s, attn_launches = kernel_times(ldm, Bl, device)     # the kernels as launched: one lane's sub-batch
-        flops_per_launch = CONV3D_GFLOP_PER_STEP * 1e9 * Bl / CONV3D_LAUNCHES_PER_STEP
+        ker_s, launches, attn_s, attn_launches = kernel_times(ldm, Bl, device, cond_shape=WL["cond"])     # the kernels as launched: one lane's sub-batch
+        flops_per_launch = WL["conv3d_gflop"] * 1e9 * Bl / CONV3D_LAUNCHES_PER_STEP
         achieved = flops_per_launch / ker_s / 1e12
         traffic = None
         tp = os.path.join(ROOT, "profiles", "conv3d_hbm_traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and args.config == "v1":
             try:
                 traffic = json.load(open(tp)).get(f"B{Bl}")
             except Exception:
@@ -296,13 +309,12 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision if args.precision == "bf16" else "bf16x3",
             "data": "synthetic (seeded random weights of the v1 architecture, N(0,1) latents/context)",
-            "config": {"workload": "SEVIR-LR 7->6 x128x128 (latent 13x16x16, C 256/512, depth [4,4], axial), DDIM-50 eta=0, "
-                                   "no knowledge alignment (BASELINE.json configs[1])",
+            "config": {"workload": WL["label"],
                        "trajectories_per_gpu": B, "global_trajectories": B * n_gpus, "sampler": "ddim50", "hip_graph": not args.no_graph,
                        "lanes": S, "trajectories_per_launch": Bl,
                        "parallelism": f"ensemble-shard x{n_gpus}"},
-            "step_tflops": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12, 2),
-            "step_frac_of_bf16_peak": round(UNET_GFLOP_PER_STEP * 1e9 * value / n_gpus / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "step_tflops": round(WL["unet_gflop"] * 1e9 * value / n_gpus / 1e12, 2),
+            "step_frac_of_bf16_peak": round(WL["unet_gflop"] * 1e9 * value / n_gpus / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": CONV3D_KERNEL_LABEL,
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -311,7 +323,7 @@ def main():
                          "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches * S,
                          "gflop_per_launch": round(flops_per_launch / 1e9, 3)},
         }
-        if attn_s:
+        if attn_s and args.config == "v1":
             # level-0 block: LN -> QKV (2*S*3C*C) -> core (4*S*vol*C) -> proj (2*S*C*C), S = 3328 tokens, C = 256, vol 13 or 16
             gf = Bl * (2 * 3328 * 768 * 256 + 2 * 3328 * 256 * 256 + 4 * 3328 * 15 * 256) / 1e9
             line["attention_block"] = {"kernel": "attn_block_kernel<256> (LN -> QKV -> cuboid attention -> proj -> +x, level 0)",
@@ -322,7 +334,7 @@ def main():
             line["ensemble_strong_scaling"] = strong      # BASELINE configs[2]: ensemble=32 over the node's GPUs
         if small:
             line["small_batch"] = small                   # B in {1..16} beside the headline batch
-        if not args.no_cpu_baseline and n_gpus == 1:
+        if not args.no_cpu_baseline and n_gpus == 1 and args.config == "v1":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -7,22 +7,26 @@
 // cuboids (4 x 16 slots = 64 rows, gathered through tok_index -- the cuboid reorder / un-shift never materialises), and
 // nothing but x goes to HBM: one gathered fp32 read, one scattered fp32 write (+ the residual re-read).
 //
-// One workgroup = 256 threads (4 waves), 64 rows, < 80 KB of LDS: TWO workgroups per CU.  Round 1's kernel (128 rows, 8 waves,
+// One workgroup = 512 threads (8 waves), 64 rows, < 80 KB of LDS, <= 128 VGPRs: TWO workgroups = 16 waves per CU.  Round 1's kernel (128 rows, 8 waves,
 // 152 KB: one workgroup per CU) spent 58 % of its time in the HBM phases (row gather, residual re-read, scatter: 87 of 148 us
 // with every GEMM and the core ablated, profiles/r02_b_attn_block_ablations.log) with idle MFMA pipes; all CUs ran those phases
 // in lock step and nothing could overlap them (a persistent variant that requested the next tile's rows early had nowhere to
 // put them before the last head: no gain).  Two independent workgroups per CU overlap one's HBM phases with the other's GEMMs
 // by construction; the price -- every 64 rows stream the 512 KB of weights instead of every 128 -- is affordable: the LDS DMA
 // sustains 114 GB/s per CU with 64 KB in flight (profiles/r02_b_ubench_dma_rate.log), this kernel needs < 50.
-//   phase 0   LayerNorm of the 64 gathered rows (wave w = the 16 slots of cuboid w) -> bf16 A tile in LDS -> each wave keeps the
-//             fragments of its 32 rows (all of K = C) in registers for the whole kernel; the A region becomes weight buffers.
+// A 4-wave version of the 64-row tile (same 2 waves per SIMD as round 1) ran no faster: every wave's instruction stream is a
+// latency chain (LDS round trips, MFMA -> VALU -> LDS epilogues, barriers) with the MFMA pipe 25 % busy, so throughput follows the
+// number of resident waves.  Eight waves per 64 rows halve the per-wave state (A fragments of 16 rows, 32 accumulator registers
+// of the proj GEMM) and fit four waves on every SIMD.
+//   phase 0   LayerNorm of the 64 gathered rows (8 per wave) -> bf16 A tile in LDS -> each wave keeps the fragments of its 16 rows
+//             (all of K = C) in registers for the whole kernel; the A region becomes weight buffers.
 //   head h    weight chunks of 16 KB through a 3-slot LDS ring, DMA two chunks ahead:
 //             Wq_h, Wk_h, Wv_h [64 x C] as C/128 K-halves [64 x 128]; Wp[:, 64h:64h+64] [C x 64] as C/128 output halves [128 x 64]
 //       q, k   Q_h^T, K_h^T [64 x 64] = W * A^T (transposed product: a lane ends up with 4 consecutive d of one token -> 8 B
 //              writes into row-major [row][d] tiles, the operand layout of S^T = K Q^T), accumulated over the K-halves
 //       v      V_h [64 x 64] = A * Wv^T (plain product: a lane ends up with 4 consecutive tokens of one d -> 8 B writes into
 //              the [d][row] tile, the A-operand layout of O^T = V^T P^T)
-//       core   wave w, cuboid w: S^T = K Q^T (2 x mfma 16x16x32), scale, + relative-position bias, mask, softmax over keys in
+//       core   waves 0-3, wave w = cuboid w: S^T = K Q^T (2 x mfma 16x16x32), scale, + relative-position bias, mask, softmax over keys in
 //              registers (4 values + 2 row swaps), O^T = V^T P^T (4 x mfma 16x16x16) -> O tile (over the Q tile: same rows, same wave)
 //       proj   acc[64 x C] += O_h[64 x 64] * Wp_h^T, one output half per chunk
 //   epilogue  acc + b_proj + x -> out rows (scatter through the same token table).
@@ -93,7 +97,7 @@ struct pd_attn_block_args_k {
 };
 
 template <int C>
-__global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_args_k p) {
+__global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 64, HD = 64, HEADS = C / HD;
   constexpr int KS = C / 64;                       // 64-wide K slabs of the A tile
@@ -106,8 +110,8 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
   constexpr int TILE = BM * HD * 2;                // 8 KB
   constexpr int NCH = 3 * KH + OH;                 // weight chunks per head
   constexpr int NCHUNK = HEADS * NCH;
-  constexpr int NDMA = CHUNK / 4096;               // DMA instructions per chunk (256 threads x 16 B each)
-  constexpr int PF = 2;                            // weight-fragment prefetch distance of the q/k/v GEMMs, in k-steps of 32
+  constexpr int NDMA = CHUNK / 8192;               // DMA instructions per chunk (512 threads x 16 B each)
+  constexpr int PF = 1;                            // weight-fragment prefetch distance of the q/k/v GEMMs, in k-steps of 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;                                 // A tile, then ring slots 0 and 1
   char* sR2 = sA + 2 * CHUNK;                      // ring slot 2
@@ -131,9 +135,8 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
   const auto rWqkv = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wqkv, 0, p.wqkv_bytes, 0x00020000);
   const auto rWp = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, p.wp_bytes, 0x00020000);
 
-  // DMA lane mapping: one 256-thread instruction fills half a slab = [32 rows][64 k] (4 KB), lane-linear, source-side swizzle.
-  // Every chunk is 2 slabs x 2 row halves; instruction i = slab (i >> 1), rows 32 (i & 1) .. +31 (the swizzle, (row >> 1) & 7,
-  // does not see the + 32): ONE per-lane offset serves all chunks, the rest is the instruction's scalar offset.
+  // DMA lane mapping: one 512-thread instruction fills one slab = [64 rows][64 k] (8 KB), lane-linear, source-side swizzle.
+  // Every chunk is 2 slabs: ONE per-lane offset serves all chunks, the rest is the instruction's scalar offset.
   const int drow = tid >> 3, dpos = tid & 7;
   const int dchunk = dpos ^ ((drow >> 1) & 7);
   const uint32_t w_voff = ((uint32_t)drow * C + dchunk * 8) * 2u;
@@ -149,12 +152,12 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
       const int kind = j / KH, kh = j - kind * KH;
 #pragma unroll
       for (int i = 0; i < NDMA; ++i)
-        BLDS16(rWqkv, d + i * 4096, w_voff, ((kind * C + h * HD + (i & 1) * 32) * C + (2 * kh + (i >> 1)) * 64) * 2);
+        BLDS16(rWqkv, d + i * 8192, w_voff, ((kind * C + h * HD) * C + (2 * kh + i) * 64) * 2);
     } else {
       const int oh = j - 3 * KH;
 #pragma unroll
       for (int i = 0; i < NDMA; ++i)
-        BLDS16(rWp, d + i * 4096, w_voff, ((oh * 128 + (i >> 1) * 64 + (i & 1) * 32) * C + h * HD) * 2);
+        BLDS16(rWp, d + i * 8192, w_voff, ((oh * 128 + i * 64) * C + h * HD) * 2);
     }
   };
   issue_chunk(0);
@@ -171,54 +174,50 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
     }
     sTok[tid] = row;
   }
-  for (int i = tid; i < 3 * C; i += 256) sBq[i] = p.bqkv ? p.bqkv[i] : 0.f;
-  for (int i = tid; i < HEADS * 256; i += 256) {
-    const int h = i >> 8, q = (i >> 4) & 15, k = i & 15;
-    sBias[i] = (q < vol && k < vol) ? p.bias[((int64_t)h * vol + q) * vol + k] : 0.f;
-  }
   __syncthreads();
   TRACE();
 
-  // ---- phase 0: LayerNorm of the gathered rows -> bf16 A tile (KS slabs of [64][64], chunk swizzle (row>>1)&7) ----
-  ln_block_to_tile<C, BM>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, (p.dbg & 16) != 0, [&](int r) { return sTok[r]; });
+  // ---- phase 0: LayerNorm of the gathered rows -> bf16 A tile (KS slabs of [64][64], chunk swizzle (row>>1)&7); the qkv-bias and
+  //      relative-position-bias tables are built while the row loads are in flight ----
+  ln_block_to_tile<C, BM, 8>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, (p.dbg & 16) != 0, [&](int r) { return sTok[r]; }, [&]() {
+    for (int i = tid; i < 3 * C; i += 512) sBq[i] = p.bqkv ? p.bqkv[i] : 0.f;
+    for (int i = tid; i < HEADS * 256; i += 512) {
+      const int h = i >> 8, q = (i >> 4) & 15, k = i & 15;
+      sBias[i] = (q < vol && k < vol) ? p.bias[((int64_t)h * vol + q) * vol + k] : 0.f;
+    }
+  });
 
   TRACE();
   // ---- wave roles ----
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int swz = (lrow >> 1) & 7;
-  // q/k/v GEMMs: wave -> d tile tn (of 2) x row tile tq (of 2)
+  // q/k/v GEMMs: wave -> d tile tn (of 2) x 16-row tile tq (of 4)
   const int tn = wave & 1, tq = wave >> 1;
-  // proj GEMM: wave -> row tile wm (of 2) x 64-column quarter wn (of 2) of every 128-column output half
-  const int wm = wave >> 1, wn = wave & 1;
-  const int g2_a_row = (wm * 32 + lrow) * 128;     // O row
-  const int g2_b_row = wn * 8192 + lrow * 128;     // Wp chunk: slab wn (64 output channels), + t * 32 rows
+  // proj GEMM: wave -> 32-row tile wm (of 2) x 32-column tile wn (of 4) of every 128-column output half
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g2_a_row = (wm * 32 + lrow) * 128;                       // O row
+  const int g2_b_row = (wn >> 1) * 8192 + ((wn & 1) * 32 + lrow) * 128;   // Wp chunk: slab wn >> 1 (64 output channels), row in it
 
-  f32x16 acc2[OH * 2];                             // [output half][32-column tile]: columns oh*128 + wn*64 + t*32 + (lane & 31)
+  f32x16 acc2[OH];                                 // [output half]: columns oh*128 + wn*32 + (lane & 31)
 #pragma unroll
-  for (int t = 0; t < OH * 2; ++t)
+  for (int t = 0; t < OH; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                        // A tile written by all waves; chunk 0 landed
-  // 16x16x32 fragments: [row tile of 16 (2)][k-step of 32 (C/32)]; lane = (row l16, 8-element k group lg)
+  // 16x16x32 fragments of the wave's 16 rows: [k-step of 32 (C/32)]; lane = (row l16, 8-element k group lg)
   const int l16 = lane & 15, lg = lane >> 4;
   const int swz16 = (l16 >> 1) & 7;
-  bf16x8 areg[2][KS * 2];
+  bf16x8 areg[KS * 2];
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int ks = 0; ks < KS * 2; ++ks)
-      areg[tt][ks] = *(const bf16x8*)(sA + (ks >> 1) * (BM * 128) + (tq * 32 + tt * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
-  // validity of this lane's slots: q/k tiles = rows tq*32 + 16 tt + l16; v tile = rows tq*32 + 16 tt + 4 lg + (0..3)
-  bool row_ok[2];
+  for (int ks = 0; ks < KS * 2; ++ks)
+    areg[ks] = *(const bf16x8*)(sA + (ks >> 1) * (BM * 128) + (tq * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+  // validity of this lane's slots: q/k tiles = row tq*16 + l16; v tile = rows tq*16 + 4 lg + (0..3)
+  const bool row_ok = sTok[tq * 16 + l16] >= 0;
   uint32_t vrow_ok = 0;
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    row_ok[tt] = sTok[tq * 32 + tt * 16 + l16] >= 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) vrow_ok |= (sTok[tq * 32 + tt * 16 + 4 * lg + r] >= 0 ? 1u : 0u) << (tt * 4 + r);
-  }
+  for (int r = 0; r < 4; ++r) vrow_ok |= (sTok[tq * 16 + 4 * lg + r] >= 0 ? 1u : 0u) << r;
   __syncthreads();                                        // A-tile region is now free: ring slots 0 and 1
   issue_chunk(1);
   issue_chunk(2);
@@ -227,7 +226,7 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
   const uint32_t w_lane_off = (uint32_t)((tn * 32 + l16) * 128 + ((lg ^ swz16) << 4));
   const uint32_t q_lds = (uint32_t)(uintptr_t)sQ, k_lds = (uint32_t)(uintptr_t)sK, vt_lds = (uint32_t)(uintptr_t)sVT;
   const uint32_t bq_lds = (uint32_t)(uintptr_t)sBq, bias_lds = (uint32_t)(uintptr_t)sBias;
-  const int cub_of_wave = (int)(((int64_t)blockIdx.x * 4 + wave) % p.nc);        // cuboid (mask table row) of this wave's core
+  const int cub_of_wave = (int)(((int64_t)blockIdx.x * 4 + (wave & 3)) % p.nc);  // cuboid (mask table row) of this wave's core
   // end of a weight-chunk step: chunk s+1 has landed (chunk s+2 may stay in flight), everyone is done with chunk s, refill its slot
   auto step_end = [&](int s) {
     if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
@@ -239,17 +238,21 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
 
   for (int h = 0; h < HEADS; ++h) {
     TRACE();
+    // (opaque copy of the lane id per head: the per-lane addresses of the tile epilogues and of the core derived from it cannot be
+    //  hoisted out of the head loop, where two dozen of them would sit in registers through every phase -- the kernel has to stay
+    //  within 128 VGPRs for four waves per SIMD, and a spill reload is a VMEM load that drains the weight DMA queue)
+    int lane_h = lane;
+    asm volatile("" : "+v"(lane_h));
+    const int l16h = lane_h & 15, lgh = lane_h >> 4;
     // ---------------- q and k: transposed products, accumulated over the K halves ----------------
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
-      // 2 x 2 tiles of 16 x 16 (feature tile dt x slot tile tt): four independent accumulator chains in 16 registers
-      f32x4 acc1[2][2];
+      // 2 tiles of 16 x 16 (feature tile dt) on the wave's 16 slots: two independent accumulator chains
+      f32x4 acc1[2];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc1[dt][tt][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc1[dt][r] = 0.f;
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) {
         const int s = NCH * h + kind * KH + kh;
@@ -265,26 +268,23 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
             WFRAG_STEP(w, wb, ks)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-              for (int tt = 0; tt < 2; ++tt)
-                acc1[dt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks % (PF + 1)][dt], areg[tt][kh * NSTEP + ks], acc1[dt][tt], 0, 0, 0);
+              acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks % (PF + 1)][dt], areg[kh * NSTEP + ks], acc1[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
         if (kh + 1 < KH) step_end(s);
       }
-      // tile (dt, tt): lane = slot row tq*32 + 16 tt + l16, features tn*32 + 16 dt + 4 lg + (0..3)
+      // tile dt: lane = slot row tq*16 + l16, features tn*32 + 16 dt + 4 lg + (0..3)
       const uint32_t t_lds = kind == 0 ? q_lds : k_lds;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const int d = tn * 32 + dt * 16 + 4 * lg;
+        const int d = tn * 32 + dt * 16 + 4 * lgh;
         f32x4 bb;   // opaque LDS read (+ its wait): see the note at the ds_write below
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bb) : "v"(bq_lds + (uint32_t)((kind * C + h * HD + d) * 4)) : "memory");
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int trow = tq * 32 + tt * 16 + l16;
-          float v0 = acc1[dt][tt][0] + bb[0], v1 = acc1[dt][tt][1] + bb[1], v2 = acc1[dt][tt][2] + bb[2], v3 = acc1[dt][tt][3] + bb[3];
-          if (!row_ok[tt]) v0 = v1 = v2 = v3 = 0.f;             // a padded slot is a zero token (as in the un-fused path)
+        {
+          const int trow = tq * 16 + l16h;
+          float v0 = acc1[dt][0] + bb[0], v1 = acc1[dt][1] + bb[1], v2 = acc1[dt][2] + bb[2], v3 = acc1[dt][3] + bb[3];
+          if (!row_ok) v0 = v1 = v2 = v3 = 0.f;                 // a padded slot is a zero token (as in the un-fused path)
           const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
           const int off = trow * 128 + (((d >> 3) ^ ((trow >> 1) & 7)) << 4) + ((d & 7) << 1);
           // opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell that the tiles and
@@ -297,13 +297,11 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
     // ---------------- v: plain product, stored transposed ----------------
     TRACE();
     {
-      f32x4 acc1[2][2];                                        // [slot tile tt][feature tile dt]
+      f32x4 acc1[2];                                           // [feature tile dt]
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc1[tt][dt][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc1[dt][r] = 0.f;
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) {
         const int s = NCH * h + 2 * KH + kh;
@@ -315,30 +313,27 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
           for (int ks = 0; ks < NSTEP; ++ks) {
             WFRAG_STEP(w, wb, ks)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-              for (int dt = 0; dt < 2; ++dt)
-                acc1[tt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[tt][kh * NSTEP + ks], w[ks % (PF + 1)][dt], acc1[tt][dt], 0, 0, 0);
+            for (int dt = 0; dt < 2; ++dt)
+              acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[kh * NSTEP + ks], w[ks % (PF + 1)][dt], acc1[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
         if (kh + 1 < KH) step_end(s);
       }
-      // tile (tt, dt): lane = feature d = tn*32 + 16 dt + l16, slot rows tq*32 + 16 tt + 4 lg + (0..3)
+      // tile dt: lane = feature d = tn*32 + 16 dt + l16, slot rows tq*16 + 4 lg + (0..3)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const int d = tn * 32 + dt * 16 + l16;
+        const int d = tn * 32 + dt * 16 + l16h;
         float bv;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bv) : "v"(bq_lds + (uint32_t)((2 * C + h * HD + d) * 4)) : "memory");
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          float v0 = acc1[tt][dt][0] + bv, v1 = acc1[tt][dt][1] + bv, v2 = acc1[tt][dt][2] + bv, v3 = acc1[tt][dt][3] + bv;
-          if (!((vrow_ok >> (4 * tt)) & 1u)) v0 = 0.f;
-          if (!((vrow_ok >> (4 * tt + 1)) & 1u)) v1 = 0.f;
-          if (!((vrow_ok >> (4 * tt + 2)) & 1u)) v2 = 0.f;
-          if (!((vrow_ok >> (4 * tt + 3)) & 1u)) v3 = 0.f;
+        {
+          float v0 = acc1[dt][0] + bv, v1 = acc1[dt][1] + bv, v2 = acc1[dt][2] + bv, v3 = acc1[dt][3] + bv;
+          if (!(vrow_ok & 1u)) v0 = 0.f;
+          if (!(vrow_ok & 2u)) v1 = 0.f;
+          if (!(vrow_ok & 4u)) v2 = 0.f;
+          if (!(vrow_ok & 8u)) v3 = 0.f;
           const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
-          const int c4 = tq * 8 + tt * 4 + lg;                                     // 4-row group of the [d][64 rows] tile
+          const int c4 = tq * 4 + lgh;                                             // 4-row group of the [d][64 rows] tile
           const int off = d * 128 + ((c4 ^ (d & 15)) << 3);                        // group XOR: conflict-free 8 B reads by (d, 4-row group)
           asm volatile("ds_write_b64 %0, %1" ::"v"(vt_lds + (uint32_t)off), "v"(pk) : "memory");
         }
@@ -346,9 +341,9 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
       step_end(NCH * h + 3 * KH - 1);
     }
     TRACE();
-    // ---------------- attention core: wave w = cuboid w of this workgroup ----------------
-    if (!(p.dbg & 4)) {
-      const int q = lane & 15, g = lane >> 4;
+    // ---------------- attention core: waves 0-3, wave w = cuboid w of this workgroup ----------------
+    if (wave < 4 && !(p.dbg & 4)) {
+      const int q = l16h, g = lgh;
       const int row = wave * 16 + q;
       const int rswz = (row >> 1) & 7;
       // every fragment of the core in flight at once, through opaque reads (a visible LDS load makes hipcc drain the weight DMA
@@ -363,20 +358,22 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
         asm volatile("ds_read_b128 %0, %1" : "=v"(qf[st]) : "v"(q_lds + pos));
       }
       asm volatile("ds_read_b128 %0, %1" : "=v"(bq4) : "v"(bias_lds + (uint32_t)((h * 256 + q * 16 + 4 * g) * 4)));
-      // V^T fragments (lane: d = 16 i + q, keys 4g..4g+3) do not depend on the softmax: fetched now, used after it
+      f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
+      asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], sc4, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[1], sc4, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // V^T fragments (lane: d = 16 i + q, keys 4g..4g+3) do not depend on the softmax: requested once the K / Q fragments are
+      // dead, their latency hides behind the softmax
 #pragma unroll
       for (int i = 0; i < HD / 16; ++i) {
         const int d = 16 * i + q;
         asm volatile("ds_read_b64 %0, %1" : "=v"(vf[i]) : "v"(vt_lds + (uint32_t)(d * 128 + (((wave * 4 + g) ^ (d & 15)) << 3))));
       }
-      f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
-      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 + HD / 16) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], sc4, 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(1 + HD / 16) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[1], sc4, 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(HD / 16) : "memory");      // the bias row
       __builtin_amdgcn_sched_barrier(0);
       // lane: query q, keys 4g .. 4g+3
       const float bk[4] = {bq4[0], bq4[1], bq4[2], bq4[3]};
@@ -411,6 +408,8 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
         if (sc[r] <= -1e18f) v = 0.f;   // masked_softmax multiplies by the mask after the softmax
         pf[r] = (short)f2bf(v);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // the V^T fragments
+      __builtin_amdgcn_sched_barrier(0);
       // O^T[d][query] = sum_key V[key][d] P[query][key]: A = V^T (lane: d = d0 + q, keys 4g..4g+3), B = P^T.
       // The four MFMAs are independent: issue them back to back, wait once, then pack and store (one latency chain, not four).
       f32x4 o[HD / 16];
@@ -442,20 +441,17 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
       const int s = NCH * h + 3 * KH + oh;
       const char* cW = ring(s);
       if (!(p.dbg & 8)) {
-        bf16x8 fa[2], fb[2][2];                    // two-deep fragment pipeline
+        bf16x8 fa[2], fb[2];                       // two-deep fragment pipeline
         auto ldp = [&](int kk, int slot) {
           const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
           fa[slot] = *(const bf16x8*)(sQ + g2_a_row + pos);
-#pragma unroll
-          for (int t = 0; t < 2; ++t) fb[slot][t] = *(const bf16x8*)(cW + g2_b_row + t * 32 * 128 + pos);
+          fb[slot] = *(const bf16x8*)(cW + g2_b_row + pos);
         };
         ldp(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           if (kk + 1 < 4) ldp(kk + 1, (kk + 1) & 1);
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            acc2[oh * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][t], acc2[oh * 2 + t], 0, 0, 0);
+          acc2[oh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1], acc2[oh], 0, 0, 0);
         }
       }
       step_end(s);
@@ -463,16 +459,16 @@ __global__ void __launch_bounds__(256, 2) attn_block_kernel(const pd_attn_block_
   }
 
   TRACE();
-  // ---- epilogue: acc2 -> per-wave LDS slab [32][OH * 64] fp32 -> + b_proj + x -> out rows of the token table ----
-  constexpr int WN = OH * 64;                      // columns per wave: OH pieces of 64
-  constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 32 at C = 256
+  // ---- epilogue: acc2 -> per-wave LDS slab [32][OH * 32] fp32 -> + b_proj + x -> out rows of the token table ----
+  constexpr int WN = OH * 32;                      // columns per wave: OH pieces of 32
+  constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 16 at C = 256
   constexpr int RPP = 64 / LPR;
   constexpr int NPASS = 32 / RPP;
-  const int c0 = (lane % LPR) * 4;                 // slab column; output column = 128 * (c0 / 64) + 64 wn + c0 % 64
-  const int n = (c0 >> 6) * 128 + wn * 64 + (c0 & 63);
+  const int c0 = (lane % LPR) * 4;                 // slab column; output column = 128 * (c0 / 32) + 32 wn + c0 % 32
+  const int n = (c0 >> 5) * 128 + wn * 32 + (c0 & 31);
   float* sC = (float*)smem + wave * (32 * WN);     // (the last step_end left every wave past its weight / tile reads)
 #pragma unroll
-  for (int t = 0; t < OH * 2; ++t)
+  for (int t = 0; t < OH; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + t * 32 + lrow] = acc2[t][r];
   // every residual row of this lane in flight at once (the accumulators are dead now): one exposed HBM round trip
@@ -504,7 +500,7 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   constexpr int heads = C / 64;
   constexpr int work = 3 * 16384 + 3 * 64 * 64 * 2;                 // weight ring + Q, K, V^T tiles: re-used by the epilogue slab
   constexpr int lds = work + heads * 256 * 4 + 64 * 4 + 3 * C * 4;
-  constexpr int epi = 4 * 32 * ((C / 128) * 64) * 4;
+  constexpr int epi = 8 * 32 * ((C / 128) * 32) * 4;
   static_assert(epi <= work, "the epilogue slab must not reach the bias / token tables");
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
   static bool attr_set = false;
@@ -517,7 +513,7 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
     attr_set = true;
   }
   const int64_t cuboids = (int64_t)a.B * a.nc;
-  hipLaunchKernelGGL((attn_block_kernel<C>), dim3((unsigned)((cuboids + 3) / 4)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn_block_kernel<C>), dim3((unsigned)((cuboids + 3) / 4)), dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }

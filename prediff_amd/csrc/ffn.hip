@@ -179,8 +179,15 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
         load1(0, 0);
       }
       if (do1) {
+        // GEMM-1 accumulates on top of the bias: lane element r = hidden unit tn*32 + 8 (r >> 2) + 4 lhalf + (r & 3) of the chunk.
+        // (Read here, behind GEMM-2's MFMAs, the four LDS round trips cost nothing; read in the VALU slot they were a serial
+        //  read -> wait per group of four values and made that slot the longer one of the two.)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bb = *(const f32x4*)(sB1 + j * HC + tn * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { acc1[4 * g + i] = bb[i]; acc1b[4 * g + i] = 0.f; }
+        }
         if (!(p.dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -199,12 +206,9 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = tn * 32 + 8 * g + 4 * lhalf;          // hidden unit inside the chunk (multiple of 4)
-        f32x4 bb;   // opaque LDS read (+ its wait) for the same reason as the H store below
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bb) : "v"(b1_lds + (uint32_t)((j * HC + nl) * 4)) : "memory");
-        // (a cheaper erf -- Abramowitz-Stegun 7.1.25 on packed v_pk_*_f32, 13 VALU + 4 transcendental ops per pair -- measured no
-        //  faster end to end: the slot is bound by LDS fragment traffic and the HBM-bound LN / epilogue phases, not VALU issue)
-        const float h0 = act_apply(acc1[4 * g] + acc1b[4 * g] + bb[0], ACT), h1 = act_apply(acc1[4 * g + 1] + acc1b[4 * g + 1] + bb[1], ACT);
-        const float h2 = act_apply(acc1[4 * g + 2] + acc1b[4 * g + 2] + bb[2], ACT), h3 = act_apply(acc1[4 * g + 3] + acc1b[4 * g + 3] + bb[3], ACT);
+        // (the bias is already in the accumulator: GEMM-1 started from it)
+        const float h0 = act_apply(acc1[4 * g] + acc1b[4 * g], ACT), h1 = act_apply(acc1[4 * g + 1] + acc1b[4 * g + 1], ACT);
+        const float h2 = act_apply(acc1[4 * g + 2] + acc1b[4 * g + 2], ACT), h3 = act_apply(acc1[4 * g + 3] + acc1b[4 * g + 3], ACT);
         const int off = hrow * 128 + (((nl >> 3) ^ hswz) << 4) + ((nl & 7) << 1);
         // Written with an opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell
         // that H and the DMA destinations are disjoint LDS regions), which would serialise the prefetch every chunk.

@@ -20,11 +20,15 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// wave `wave` normalises rows wave*16 .. wave*16+15 of the block; row_of(r) gives the global row (or -1: the tile row is zero).
+// wave `wave` normalises rows wave*RPW .. wave*RPW+RPW-1 of the block (RPW = 16, or 8 when 8 waves share a 64-row block);
+// row_of(r) gives the global row (or -1: the tile row is zero).
 // sA: KS = C/64 slabs of [BM rows][64 k] bf16, 16 B chunk index XOR (row >> 1) & 7 (the layout the MFMA fragment reads expect).
-template <int C, int BM = 128, typename RowOf>
+// while_loading(): independent work done while the row loads are in flight (table set-up of the caller); default none.
+struct ln_no_overlap { __device__ __forceinline__ void operator()() const {} };
+template <int C, int BM = 128, int RPW = 16, typename RowOf, typename Overlap = ln_no_overlap>
 __device__ __forceinline__ void ln_block_to_tile(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 float eps, char* sA, int wave, int lane, bool skip_loads, RowOf row_of) {
+                                                 float eps, char* sA, int wave, int lane, bool skip_loads, RowOf row_of,
+                                                 Overlap while_loading = Overlap()) {
   constexpr int NV = C / 64;                       // float4 per lane
   const int rsub = lane >> 4, j = lane & 15;
   float4 g4[NV], b4[NV];
@@ -33,20 +37,22 @@ __device__ __forceinline__ void ln_block_to_tile(const float* __restrict__ x, co
     g4[i] = *(const float4*)(gamma + (j + 16 * i) * 4);
     b4[i] = *(const float4*)(beta + (j + 16 * i) * 4);
   }
-  float4 xv[4][NV];                                // all 16 rows of this wave in flight at once
-  int mrow[4];
+  constexpr int NB = RPW / 4;                      // four rows per wave instruction
+  float4 xv[NB][NV];                               // all rows of this wave in flight at once
+  int mrow[NB];
 #pragma unroll
-  for (int bt = 0; bt < 4; ++bt) {
-    mrow[bt] = row_of(wave * 16 + bt * 4 + rsub);
+  for (int bt = 0; bt < NB; ++bt) {
+    mrow[bt] = row_of(wave * RPW + bt * 4 + rsub);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       xv[bt][i] = make_float4(0, 0, 0, 0);
       if (mrow[bt] >= 0 && !skip_loads) xv[bt][i] = *(const float4*)(x + (int64_t)mrow[bt] * C + (j + 16 * i) * 4);
     }
   }
+  while_loading();
 #pragma unroll
-  for (int bt = 0; bt < 4; ++bt) {
-    const int row = wave * 16 + bt * 4 + rsub;
+  for (int bt = 0; bt < NB; ++bt) {
+    const int row = wave * RPW + bt * 4 + rsub;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (xv[bt][i].x + xv[bt][i].y) + (xv[bt][i].z + xv[bt][i].w);

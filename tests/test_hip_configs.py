@@ -5,6 +5,8 @@ config 2  SEVIR-LR v1, DDIM-50: fp32 engine vs the oracle loop on the same noise
           all-zero and 90 %-sparse contexts                           -> test_v1_ddim50_vs_oracle, test_degenerate_contexts
 config 3  ensemble sharding at v1 size incl. VAE and the RCCL all-gather (world of one) -> test_v1_ensemble_rccl_world1
 config 4  knowledge-aligned ancestral step at v1 size, t in {99, 0}, fp32 and bf16 vs the reference golden -> test_v1_aligned_step
+config 5  full-resolution geometry (latent 25 x 48 x 48, axial cuboids 25 / 48 / 48 and 25 / 24 / 24): one denoiser forward vs the
+          oracle, fp32 and bf16 operands (the fp8 operand path of that config is not built)         -> test_fullres_forward
 """
 import json
 import os
@@ -17,7 +19,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import _templates as TP  # noqa: E402
-from _cases import NBODY_LDM_KW, NBODY_UNET_CFG, NBODY_VAE_CFG, V1_ALIGN_ARGS, V1_LDM_KW, V1_UNET_CFG, V1_VAE_CFG  # noqa: E402
+from _cases import (FULLRES_UNET_CFG, NBODY_LDM_KW, NBODY_UNET_CFG, NBODY_VAE_CFG, V1_ALIGN_ARGS, V1_LDM_KW, V1_UNET_CFG,  # noqa: E402
+                    V1_VAE_CFG)
 from _weights import seeded_input, seeded_state_dict  # noqa: E402
 from oracle import diffusion as OD  # noqa: E402
 from oracle import unet as OU  # noqa: E402
@@ -207,3 +210,35 @@ def test_v1_aligned_step(golden, precision):
     b = ldm.sample(cond=zc, batch_size=B, timesteps=2, use_alignment=True, alignment_kwargs={"avg_x_gt": avg}, return_decoded=False,
                    noise_tape=tape)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ config 5 (geometry; bf16 / fp32 operands)
+def test_fullres_forward():
+    """The v1 denoiser on the full-resolution latent grid (13 + 12 frames of 48 x 48 x 64: SURVEY.md §8(d) row 5): cuboid volumes
+    25 and 48 at level 0 (beyond the fused block kernel's 16: LayerNorm -> QKV GEMM -> generic attention core -> proj GEMM),
+    25 / 24 / 24 at level 1 (head_dim 128).  One forward of one trajectory against the oracle (11.4 TFLOP on the CPU)."""
+    # checkpoint schema of this geometry from the module itself (position tables / relative-position tables and index buffers grow
+    # with the grid; the index buffers are the ones pinned against the reference's at the v1 and tiny shapes)
+    sd = seeded_state_dict(CuboidTransformerUNet(**FULLRES_UNET_CFG).state_dict(), 1234)
+    x = seeded_input("frx", (1, 12, 48, 48, 64), 41)
+    zc = seeded_input("frc", (1, 13, 48, 48, 64), 42)
+    t = torch.tensor([500])
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 64))
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            ref = OU.unet_forward(sd, FULLRES_UNET_CFG, x, t, zc)
+    finally:
+        torch.set_num_threads(nthr)
+    t_cpu = time.time() - t0
+    for precision, tol in (("fp32", 1e-4), ("bf16", 2e-2)):
+        net = CuboidTransformerUNet(**FULLRES_UNET_CFG, precision=precision)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda()
+        out = net(x.cuda(), t.cuda(), zc.cuda())
+        e = rel_l2(out, ref)
+        print(f"[fullres {precision}] one forward rel-L2 vs oracle {e:.3e} (oracle {t_cpu:.0f} s on CPU)")
+        _report("fullres_forward", precision=precision, rel_l2=e, oracle_cpu_s=round(t_cpu, 1))
+        assert out.shape == (1, 12, 48, 48, 64) and e < tol
+        del net
