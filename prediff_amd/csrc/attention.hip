@@ -6,94 +6,241 @@
 // token id of every slot (or -1 for a padded slot), q/k/v rows are gathered straight from the (B, ntok, 3C) QKV GEMM
 // output and the result is scattered back to natural token order -- "shift/pad done as coalesced HBM gathers".
 //
-//  * MFMA path (vol <= 16, bf16 qkv, hd % 32 == 0): one wave per (sample, cuboid, head).
+//  * MFMA path (vol <= 64, bf16 qkv, hd % 32 == 0): one wave per (sample, cuboid, head, 16-query tile), 1-4 key tiles of 16.
 //      S^T = K Q^T   with v_mfma_f32_16x16x32_bf16   (A = K rows, B = Q rows: both 16 B/lane row loads from HBM/L2)
 //      softmax over keys: every lane owns one query column and 4 key rows -> 4-register + 2-shuffle reduction
 //      O^T = V^T P^T with v_mfma_f32_16x16x16_bf16   (P^T is already in B-operand layout: no LDS, no transpose)
 //    Per work item: 3*vol*hd*2 B in, vol*hd*2 B out, 4*vol^2*hd flop (~8 flop/B): HBM/latency bound by construction.
-//  * generic path (vol <= 64, any hd <= 128, bf16 or fp32 qkv): LDS-staged fp32 VALU kernel; used for the non-axial
-//    patterns (video_swin / spatial_lg / dilated / default cuboids) and for the fp32-accurate mode.
+//  * large cuboids (vol > 64, bf16 qkv, hd 32 / 64 / 128): online-softmax MFMA kernel, one wave per 16 queries.
+//  * generic path (vol <= 64, any hd <= 128, bf16 or fp32 qkv): LDS-staged fp32 VALU kernel; used for the fp32-accurate mode and
+//    odd head sizes.
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------- MFMA path
+// combine over the four 16-lane rows of the wave (v_permlane16_swap / v_permlane32_swap: one VALU instruction per exchange)
+__device__ __forceinline__ float attn_rows4_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float attn_rows4_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// One wave per (sample, cuboid, head, tile of 16 queries); KT = key tiles of 16 (cuboid volume <= 16 KT: the axial cuboids of the
+// SEVIR-LR grid need 1, those of the 48 x 48 full-resolution grid -- volumes 25 / 48 / 24 -- need 2 or 3).  All KT x 4 scores of a
+// lane stay in registers, so the softmax is exact (no online rescaling).
+template <int KT>
 __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_attn_args p) {
   const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // ((b * nc) + c) * heads + h
-  const int64_t nitems = (int64_t)p.B * p.nc * p.heads;
+  const int QT = (p.vol + 15) >> 4;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (((b * nc) + c) * heads + h) * QT + qt
+  const int64_t nitems = (int64_t)p.B * p.nc * p.heads * QT;
   if (item >= nitems) return;
-  const int h = (int)(item % p.heads);
-  const int c = (int)((item / p.heads) % p.nc);
-  const int b = (int)(item / ((int64_t)p.heads * p.nc));
+  const int qt = (int)(item % QT);
+  const int64_t it2 = item / QT;
+  const int h = (int)(it2 % p.heads);
+  const int c = (int)((it2 / p.heads) % p.nc);
+  const int b = (int)(it2 / ((int64_t)p.heads * p.nc));
   const int hd = p.C / p.heads;
-  const int q = lane & 15, g = lane >> 4;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int vol = p.vol;
+  const int query = qt * 16 + l16;                                       // this lane's query column
 
-  const int tok = q < p.vol ? p.tok_index[c * p.vol + q] : -1;   // token of row/column (lane & 15)
-  const pd_bf16* row = p.qkv_bf16 + ((int64_t)b * p.ntok + (tok >= 0 ? tok : 0)) * p.ld_qkv + h * hd;
+  const int qtok = query < vol ? p.tok_index[c * vol + query] : -1;
+  const pd_bf16* base = p.qkv_bf16 + (int64_t)b * p.ntok * p.ld_qkv + h * hd;
+  const pd_bf16* qrow = base + (int64_t)(qtok >= 0 ? qtok : 0) * p.ld_qkv;
 
-  // ---- S^T[key][query] ----
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int d0 = 0; d0 < hd; d0 += 32) {
-    bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0}, qf = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (tok >= 0) {
-      qf = *(const bf16x8*)(row + d0 + 8 * g);
-      kf = *(const bf16x8*)(row + p.C + d0 + 8 * g);
-    }
-    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s, 0, 0, 0);
+  // ---- S^T[key][query], one 16 x 16 tile per key tile ----
+  f32x4 s[KT];
+  int ktok[KT];                                                          // token of key row kt*16 + l16 (A operand rows)
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = kt * 16 + l16;
+    ktok[kt] = key < vol ? p.tok_index[c * vol + key] : -1;
+    s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // lane: query q, keys 4g..4g+3
-  float sc[4];
+  for (int d0 = 0; d0 < hd; d0 += 32) {
+    bf16x8 qf = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qtok >= 0) qf = *(const bf16x8*)(qrow + d0 + 8 * g);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ktok[kt] >= 0) kf = *(const bf16x8*)(base + (int64_t)ktok[kt] * p.ld_qkv + p.C + d0 + 8 * g);
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s[kt], 0, 0, 0);
+    }
+  }
+  // lane: query `query`, keys kt*16 + 4g .. +3
+  float sc[KT][4];
   float mx = -3.0e38f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int key = 4 * g + r;
-    float v = -INFINITY;
-    if (key < p.vol && q < p.vol) {
-      v = s[r] * p.scale + p.bias[((int64_t)h * p.vol + q) * p.vol + key];
-      if (p.mask && !p.mask[((int64_t)c * p.vol + q) * p.vol + key]) v = -1e18f;
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      float v = -INFINITY;
+      if (key < vol && query < vol) {
+        v = s[kt][r] * p.scale + p.bias[((int64_t)h * vol + query) * vol + key];
+        if (p.mask && !p.mask[((int64_t)c * vol + query) * vol + key]) v = -1e18f;
+      }
+      sc[kt][r] = v;
+      mx = fmaxf(mx, v);
     }
-    sc[r] = v;
-    mx = fmaxf(mx, v);
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float pr[4], sum = 0.f;
+  mx = attn_rows4_max(mx);
+  float sum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    pr[r] = expf(sc[r] - mx);   // exp(-inf) = 0 for non-existent keys
-    sum += pr[r];
-  }
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = expf(sc[kt][r] - mx);   // exp(-inf) = 0 for non-existent keys
+      sum += e;
+      s[kt][r] = e;
+    }
+  sum = attn_rows4_sum(sum);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
-  s16x4 pf;
+  s16x4 pf[KT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float v = pr[r] * inv;
-    if (sc[r] <= -1e18f) v = 0.f;   // masked_softmax multiplies by the mask after the softmax
-    pf[r] = (short)f2bf(v);
-  }
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = s[kt][r] * inv;
+      if (sc[kt][r] <= -1e18f) v = 0.f;   // masked_softmax multiplies by the mask after the softmax
+      pf[kt][r] = (short)f2bf(v);
+    }
 
   // ---- O^T[d][query] = sum_key V[key][d] P[query][key] ----
-  // A = V^T: lane holds V[key = 4g + jj][d0 + (lane & 15)], jj = 0..3;  B = P^T: pf.
-  int vtok[4];
+  // A = V^T: lane holds V[key = kt*16 + 4g + jj][d0 + l16], jj = 0..3;  B = P^T: pf[kt].
+  int vtok[KT][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) vtok[r] = (4 * g + r) < p.vol ? p.tok_index[c * p.vol + 4 * g + r] : -1;
-  const pd_bf16* vbase = p.qkv_bf16 + (int64_t)b * p.ntok * p.ld_qkv + 2 * p.C + h * hd + q;
-  pd_bf16* orow = (tok >= 0) ? p.out_bf16 + ((int64_t)b * p.ntok + tok) * p.ld_out + h * hd + 4 * g : nullptr;
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      vtok[kt][r] = key < vol ? p.tok_index[c * vol + key] : -1;
+    }
+  const pd_bf16* vbase = base + 2 * p.C + l16;
+  pd_bf16* orow = (qtok >= 0) ? p.out_bf16 + ((int64_t)b * p.ntok + qtok) * p.ld_out + h * hd + 4 * g : nullptr;
   for (int d0 = 0; d0 < hd; d0 += 16) {
-    s16x4 vf;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) vf[r] = vtok[r] >= 0 ? (short)vbase[(int64_t)vtok[r] * p.ld_qkv + d0] : (short)0;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o, 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      s16x4 vf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vf[r] = vtok[kt][r] >= 0 ? (short)vbase[(int64_t)vtok[kt][r] * p.ld_qkv + d0] : (short)0;
+      o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf[kt], o, 0, 0, 0);
+    }
     // the result feeds inline asm (v_cvt_pk_bf16_f32) directly: hipcc does not insert the XDL-write -> VALU-read wait states for asm
     asm volatile("s_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-    // lane: query q, d = d0 + 4g + r
+    // lane: query, d = d0 + 4g + r
     if (orow) {
       const uint32_t lo = pack_bf16x2(o[0], o[1]);
       const uint32_t hi = pack_bf16x2(o[2], o[3]);
       *(uint2*)(orow + d0) = make_uint2(lo, hi);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- large cuboids (volume > 64)
+// Patterns whose cuboids span the whole grid or a whole frame ("full": 13 x 16 x 16 = 3328 slots; "divided_st": 1 x 16 x 16 = 256;
+// cuboid_transformer_patterns.py:11-16,53-58).  One wave per (sample, cuboid, head, tile of 16 queries) walks the key tiles of 16
+// with an online softmax (running max m, running denominator l, accumulators rescaled by exp(m_old - m_new)): the score matrix
+// never exists.  Same MFMA operand layouts as the kernel above; unnormalised bf16 probabilities, fp32 normalisation at the end.
+// Masked entries (-1e18, cuboid_transformer.py:553-557) keep the reference's semantics: they take part in the running max and
+// denominator exactly as in a whole-row softmax (a fully masked row ends as zeros), their probabilities are zeroed afterwards.
+template <int NDT>   // head_dim / 16
+__global__ void __launch_bounds__(256) cuboid_attn_flash_kernel(const pd_cuboid_attn_args p) {
+  const int lane = threadIdx.x & 63;
+  const int vol = p.vol;
+  const int QT = (vol + 15) >> 4;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (((b * nc) + c) * heads + h) * QT + qt
+  const int64_t nitems = (int64_t)p.B * p.nc * p.heads * QT;
+  if (item >= nitems) return;
+  const int qt = (int)(item % QT);
+  const int64_t it2 = item / QT;
+  const int h = (int)(it2 % p.heads);
+  const int c = (int)((it2 / p.heads) % p.nc);
+  const int b = (int)(it2 / ((int64_t)p.heads * p.nc));
+  constexpr int hd = NDT * 16;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int query = qt * 16 + l16;
+  const int* tokc = p.tok_index + (int64_t)c * vol;
+  const int qtok = query < vol ? tokc[query] : -1;
+  const pd_bf16* base = p.qkv_bf16 + (int64_t)b * p.ntok * p.ld_qkv + h * hd;
+  bf16x8 qf[hd / 32];
+#pragma unroll
+  for (int i = 0; i < hd / 32; ++i) {
+    qf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (qtok >= 0) qf[i] = *(const bf16x8*)(base + (int64_t)qtok * p.ld_qkv + 32 * i + 8 * g);
+  }
+  f32x4 o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -3.0e38f, l = 0.f;
+  const float* brow = p.bias + ((int64_t)h * vol + (query < vol ? query : 0)) * vol;
+  const uint8_t* mrow = p.mask ? p.mask + ((int64_t)c * vol + (query < vol ? query : 0)) * vol : nullptr;
+  const pd_bf16* vbase = base + 2 * p.C + l16;
+  for (int kt = 0; kt < QT; ++kt) {
+    const int krow = kt * 16 + l16;
+    const int ktok = krow < vol ? tokc[krow] : -1;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < hd / 32; ++i) {
+      bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ktok >= 0) kf = *(const bf16x8*)(base + (int64_t)ktok * p.ld_qkv + p.C + 32 * i + 8 * g);
+      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i], s, 0, 0, 0);
+    }
+    float sc[4], tmax = -3.0e38f;
+    int vtok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      float v = -INFINITY;
+      vtok[r] = -1;
+      if (key < vol) {
+        vtok[r] = tokc[key];
+        if (query < vol) {
+          v = s[r] * p.scale + brow[key];
+          if (mrow && !mrow[key]) v = -1e18f;
+        }
+      }
+      sc[r] = v;
+      tmax = fmaxf(tmax, v);
+    }
+    tmax = attn_rows4_max(tmax);
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = expf(m - m_new);
+    float tsum = 0.f;
+    s16x4 pf;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = expf(sc[r] - m_new);          // exp(-inf) = 0 for non-existent keys
+      tsum += e;
+      pf[r] = (short)f2bf(sc[r] <= -1e18f ? 0.f : e);
+    }
+    l = l * alpha + attn_rows4_sum(tsum);
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) {
+      s16x4 vf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vf[r] = vtok[r] >= 0 ? (short)vbase[(int64_t)vtok[r] * p.ld_qkv + 16 * i] : (short)0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[i][r] *= alpha;
+      o[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o[i], 0, 0, 0);
+    }
+  }
+  if (qtok < 0) return;
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  pd_bf16* orow = p.out_bf16 + ((int64_t)b * p.ntok + qtok) * p.ld_out + h * hd + 4 * g;
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) {
+    // lane: query, d = 16 i + 4g + r  (the accumulators are read by ordinary VALU code here: hipcc pads the MFMA hazard itself)
+    const float v0 = o[i][0] * inv, v1 = o[i][1] * inv, v2 = o[i][2] * inv, v3 = o[i][3] * inv;
+    *(uint2*)(orow + 16 * i) = make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
   }
 }
 
@@ -184,16 +331,35 @@ extern "C" int pd_cuboid_attention(const pd_cuboid_attn_args* pa, pd_stream_t st
   const int hd = a.C / a.heads;
   hipStream_t s = (hipStream_t)stream;
   const int64_t nitems = (int64_t)a.B * a.nc * a.heads;
-  const bool mfma_ok = a.qkv_bf16 && a.vol <= 16 && (hd % 32) == 0 && a.out_bf16 && !a.out_f32 && !a.out_bf16_lo &&
+  const bool mfma_ok = a.qkv_bf16 && a.vol <= 64 && (hd % 32) == 0 && a.out_bf16 && !a.out_f32 && !a.out_bf16_lo &&
                        (a.ld_qkv % 8) == 0 && (a.ld_out % 4) == 0 && !a.force_generic;
   if (mfma_ok) {
-    hipLaunchKernelGGL(cuboid_attn_mfma_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a);
+    const int kt = (a.vol + 15) / 16;
+    const int64_t nwaves = nitems * kt;                  // one wave per 16-query tile
+    const dim3 grid((unsigned)((nwaves + 3) / 4));
+    switch (kt) {
+      case 1: hipLaunchKernelGGL(cuboid_attn_mfma_kernel<1>, grid, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(cuboid_attn_mfma_kernel<2>, grid, dim3(256), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(cuboid_attn_mfma_kernel<3>, grid, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(cuboid_attn_mfma_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
+    PD_CHECK_LAUNCH();
+    return PD_OK;
+  }
+  if (a.vol > GA_MAXVOL && a.qkv_bf16 && (hd == 32 || hd == 64 || hd == 128) && a.out_bf16 && !a.out_f32 && !a.out_bf16_lo && (a.ld_qkv % 8) == 0 &&
+      (a.ld_out % 4) == 0) {
+    // large cuboids ("full", "divided_st"): online-softmax MFMA kernel
+    const int qt = (a.vol + 15) / 16;
+    const dim3 grid((unsigned)((nitems * qt + 3) / 4));
+    if (hd == 32) hipLaunchKernelGGL(cuboid_attn_flash_kernel<2>, grid, dim3(256), 0, s, a);
+    else if (hd == 64) hipLaunchKernelGGL(cuboid_attn_flash_kernel<4>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(cuboid_attn_flash_kernel<8>, grid, dim3(256), 0, s, a);
     PD_CHECK_LAUNCH();
     return PD_OK;
   }
   if (a.vol > GA_MAXVOL || hd > 128) {
-    pd_set_error("pd_cuboid_attention: cuboid volume %d (max %d) / head_dim %d (max 128) not supported by the HIP path", a.vol,
-                 GA_MAXVOL, hd);
+    pd_set_error("pd_cuboid_attention: cuboid volume %d > %d needs bf16 q/k/v with head_dim 32 / 64 / 128 (precision=\"bf16\"); "
+                 "head_dim %d (max 128)", a.vol, GA_MAXVOL, hd);
     return PD_ERR_UNSUPPORTED;
   }
   const size_t lds = sizeof(float) * ((size_t)a.vol * hd * 2 + (size_t)a.vol * (hd + 1) + (size_t)a.vol * (a.vol + 1));

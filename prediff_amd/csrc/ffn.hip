@@ -260,6 +260,230 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
 #endif
 }
 
+// ================================================================================================================================
+// 64-row variant for units = 256 (the SEVIR-LR level-0 blocks): 512 threads, 64 rows, 76 KB of LDS, <= 128 VGPRs -> TWO workgroups
+// = 16 waves per CU (four per SIMD).  Same reasoning as csrc/attn_block.hip: the 128-row kernel above keeps one 144 KB workgroup per
+// CU whose waves are latency chains (fragment round trips, MFMA -> activation -> LDS, a barrier per slot) with the MFMA pipe
+// about a third busy, and its HBM phases (LayerNorm rows in, residual in, rows out: 55 of 235 us) overlap nothing.  Here a wave
+// holds the A fragments of 16 rows and 32 accumulator registers; W1_j / W2_j ([64 x 256] / [256 x 64], 32 KB each) alternate
+// through two LDS slots (slot 0 = the A-tile region), each requested one step ahead.
+//   chunk j:  step A  H_j^T[64 hidden x 64 rows] = W1_j A^T + b1 (wave: 32 hidden x 16 rows, accumulator starts from the bias),
+//                     activation, bf16 -> H tile (8 B stores: 4 consecutive hidden units of one token)
+//             step B  acc[64 x 256] += H_j W2_j^T (wave: 32 rows x 32 columns of each 128-column half)
+//   one workgroup barrier per step; the DMA of the next step's weights is in flight during the current one.
+#define FFN64_WLD(dst, base_vgpr, ks, dt)                                                                               \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(((ks) & 1) ? ((base_vgpr) ^ 64u) : (base_vgpr)),     \
+               "n"(((ks) >> 1) * 8192 + (dt) * 2048))
+
+template <int ACT>
+__global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = 256, BM = 64, HC = 64, KS = C / 64;
+  constexpr int SLOT = 32768;                      // one weight chunk: W1_j [64 hidden][256 k] or W2_j [256 out][64 hidden]
+  constexpr int PF = 2;                            // W1-fragment prefetch distance, k-steps of 32
+  constexpr int NSTEP = 2 * KS;                    // k-steps of 32 over K = C
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sS0 = smem;                                // A tile, then weight slot 0
+  char* sS1 = smem + SLOT;                         // weight slot 1
+  char* sH = smem + 2 * SLOT;                      // H tile [64 rows][64 hidden] bf16, 16 B chunk XOR (row >> 1) & 7
+  float* sB1 = (float*)(sH + BM * HC * 2);         // whole b1 (Hd floats)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * BM;
+  const int NJ = p.Hd / HC;
+  const int NCHUNK = 2 * NJ;                       // chunk s: even = W1_{s/2}, odd = W2_{s/2}; chunk s lives in slot (s + 1) & 1
+
+  const auto rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, 0, p.w1_bytes, 0x00020000);
+  const auto rW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2, 0, p.w2_bytes, 0x00020000);
+  // DMA lane mapping: one 512-thread instruction fills one [64 rows][64 k] slab (8 KB), lane-linear, source-side swizzle
+  const int drow = tid >> 3, dpos = tid & 7;
+  const int dchunk = dpos ^ ((drow >> 1) & 7);
+  const uint32_t w1_voff = ((uint32_t)drow * C + dchunk * 8) * 2u;                       // + (j*64*C + i*64)*2: K slab i of W1_j
+  const uint32_t w2_voff = ((uint32_t)drow * (uint32_t)p.Hd + dchunk * 8) * 2u;          // + (i*64*Hd + j*64)*2: output slab i of W2_j
+  auto issue = [&](int s) {
+    char* d = ((s + 1) & 1 ? sS1 : sS0) + wave * 1024;
+    const int j = s >> 1;
+    if (!(s & 1)) {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) BLDS16(rW1, d + i * 8192, w1_voff, (j * HC * C + i * 64) * 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) BLDS16(rW2, d + i * 8192, w2_voff, (i * 64 * p.Hd + j * HC) * 2);
+    }
+  };
+  issue(0);                                        // W1_0 -> slot 1
+
+  // ---- phase 0: LayerNorm -> bf16 A tile (KS slabs of [64][64]); b1 -> LDS while the row loads are in flight ----
+  ln_block_to_tile<C, BM, 8>(p.x, p.gamma, p.beta, p.eps, sS0, wave, lane, (p.dbg & 16) != 0,
+                             [&](int r) { const int m = m0 + r; return m < p.M ? m : -1; },
+                             [&]() { for (int i = tid; i < p.Hd; i += 512) sB1[i] = p.b1[i]; });
+
+  // ---- wave roles ----
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int swz16 = (l16 >> 1) & 7;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int swz = (lrow >> 1) & 7;
+  const int tn = wave & 1, tq = wave >> 1;         // GEMM-1: 32-hidden half tn x 16-row tile tq
+  const int wm = wave >> 2, wn = wave & 3;         // GEMM-2: 32-row tile wm x 32-column tile wn of every 128-column half
+  f32x16 acc2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                 // A tile written by all waves; W1_0 landed
+  bf16x8 areg[NSTEP];                              // this wave's 16 token rows, all of K, for the whole kernel
+#pragma unroll
+  for (int ks = 0; ks < NSTEP; ++ks)
+    areg[ks] = *(const bf16x8*)(sS0 + (ks >> 1) * (BM * 128) + (tq * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+  __syncthreads();                                 // the A-tile region is free: weight slot 0
+  issue(1);                                        // W2_0 -> slot 0
+
+  const uint32_t w_lane = (uint32_t)(uintptr_t)sS1 + (uint32_t)((tn * 32 + l16) * 128 + ((lg ^ swz16) << 4));
+  const uint32_t h_lds = (uint32_t)(uintptr_t)sH, b1_lds = (uint32_t)(uintptr_t)sB1;
+  const int g2_a = (wm * 32 + lrow) * 128;                               // H row of GEMM-2's A operand
+  const int g2_b = (wn >> 1) * 8192 + ((wn & 1) * 32 + lrow) * 128;      // W2 chunk: slab (64 output channels), row in it; + oh * 16384
+  // end of a step: the next step's weights have landed (the only DMA in flight), everyone is done with this step's slot and H
+  auto step_end = [&](int s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < NCHUNK && !(p.dbg & 1)) issue(s + 2);
+  };
+
+  for (int j = 0; j < NJ; ++j) {
+    // ---------------- step A: H_j^T = W1_j A^T + b1, activation -> H tile ----------------
+    {
+      // lane: token row tq*16 + l16 (column of the tile), hidden units tn*32 + 16 dt + 4 lg + (0..3)
+      f32x4 acc1[2], bb[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bb[dt]) : "v"(b1_lds + (uint32_t)((j * HC + tn * 32 + dt * 16 + 4 * lg) * 4)));
+      bf16x8 w[PF + 1][2];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        FFN64_WLD(w[i][0], w_lane, i, 0);
+        FFN64_WLD(w[i][1], w_lane, i, 1);
+      }
+      if (!(p.dbg & 2)) {
+#pragma unroll
+        for (int ks = 0; ks < NSTEP; ++ks) {
+          if (ks + PF < NSTEP) {
+            FFN64_WLD(w[(ks + PF) % (PF + 1)][0], w_lane, ks + PF, 0);
+            FFN64_WLD(w[(ks + PF) % (PF + 1)][1], w_lane, ks + PF, 1);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PF) : "memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NSTEP - 1 - ks)) : "memory");
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks == 0) { acc1[0] = bb[0]; acc1[1] = bb[1]; }      // (the bias reads are older than every fragment read: landed)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks % (PF + 1)][dt], areg[ks], acc1[dt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc1[0] = bb[0]; acc1[1] = bb[1];
+      }
+      if (!(p.dbg & 4)) {
+        const int trow = tq * 16 + l16;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int d = tn * 32 + dt * 16 + 4 * lg;
+          const float h0 = act_apply(acc1[dt][0], ACT), h1 = act_apply(acc1[dt][1], ACT);
+          const float h2 = act_apply(acc1[dt][2], ACT), h3 = act_apply(acc1[dt][3], ACT);
+          const uint64_t pk = (uint64_t)(pack_bf16x2(h0, h1)) | ((uint64_t)(pack_bf16x2(h2, h3)) << 32);
+          const int off = trow * 128 + (((d >> 3) ^ ((trow >> 1) & 7)) << 4) + ((d & 7) << 1);
+          // opaque ds_write: a visible LDS store would make hipcc drain the in-flight weight DMA first
+          asm volatile("ds_write_b64 %0, %1" ::"v"(h_lds + (uint32_t)off), "v"(pk) : "memory");
+        }
+      }
+      step_end(2 * j);                             // W2_j landed, H_j visible, slot 1 free -> W1_{j+1}
+    }
+    // ---------------- step B: acc += H_j W2_j^T ----------------
+    {
+      if (!(p.dbg & 8)) {
+        bf16x8 fa[2], fb[2][2];                                         // [pipeline slot][output half]: two k-sub-steps in flight
+        const uint32_t xs = (uint32_t)((lhalf ^ swz) << 4);              // 16 B slot of k-sub-step 0; sub-step kk: ^ (kk << 5)
+        const uint32_t a2 = h_lds + (uint32_t)g2_a + xs;
+        const uint32_t b2 = (uint32_t)(uintptr_t)sS0 + (uint32_t)g2_b + xs;
+        auto ld2 = [&](int kk, int slot) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(fa[slot]) : "v"(a2 ^ (uint32_t)(kk << 5)));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(fb[slot][0]) : "v"(b2 ^ (uint32_t)(kk << 5)));
+          asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(fb[slot][1]) : "v"(b2 ^ (uint32_t)(kk << 5)));
+        };
+        ld2(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (kk + 1 < 4) {
+            ld2(kk + 1, (kk + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][0], acc2[0], 0, 0, 0);
+          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][1], acc2[1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      step_end(2 * j + 1);                         // W1_{j+1} landed, slot 0 and H free -> W2_{j+1}
+    }
+  }
+
+  // ---- epilogue: acc2 -> per-wave LDS slab [32][64] fp32 -> + b2 + x -> out ----
+  constexpr int WN = 64;                           // columns per wave: 2 pieces of 32
+  constexpr int LPR = WN / 4, RPP = 64 / LPR, NPASS = 32 / RPP;
+  const int c0 = (lane % LPR) * 4;                 // slab column; output column = 128 (c0 / 32) + 32 wn + c0 % 32
+  const int n = (c0 >> 5) * 128 + wn * 32 + (c0 & 31);
+  float* sC = (float*)smem + wave * (32 * WN);     // (the last step_end left every wave past its weight / H reads)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sC[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * WN + t * 32 + lrow] = acc2[t][r];
+  const int mrow0 = m0 + wm * 32 + lane / LPR;
+  float4 xr[NPASS];
+#pragma unroll
+  for (int u = 0; u < NPASS; ++u) {
+    const int m = mrow0 + u * RPP;
+    xr[u] = make_float4(0, 0, 0, 0);
+    if (m < p.M && !(p.dbg & 32)) xr[u] = *(const float4*)(p.x + (int64_t)m * C + n);
+  }
+  const float4 bias = *(const float4*)(p.b2 + n);
+  // (no workgroup barrier: the slab is private to the wave)
+#pragma unroll
+  for (int u = 0; u < NPASS; ++u) {
+    const int m = mrow0 + u * RPP;
+    if (m >= p.M || (p.dbg & 64)) continue;
+    const float4 a4 = *(const float4*)(sC + (u * RPP + lane / LPR) * WN + c0);
+    *(float4*)(p.out + (int64_t)m * C + n) =
+        make_float4(a4.x + bias.x + xr[u].x, a4.y + bias.y + xr[u].y, a4.z + bias.z + xr[u].z, a4.w + bias.w + xr[u].w);
+  }
+#endif
+}
+
+template <int ACT>
+static int launch_ffn64(const pd_ffn_args_k& a, hipStream_t s) {
+  const int bytes = 2 * 32768 + 64 * 64 * 2 + a.Hd * 4;          // two weight slots (the epilogue slab re-uses them) + H tile + b1
+  static int attr_set = 0;
+  if (attr_set < bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)ffn64_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      pd_set_error("pd_ffn_fused: hipFuncSetAttribute(%d) failed: %s", bytes, hipGetErrorString(e));
+      return PD_ERR_LAUNCH;
+    }
+    attr_set = bytes;
+  }
+  hipLaunchKernelGGL((ffn64_kernel<ACT>), dim3((a.M + 63) / 64), dim3(512), bytes, s, a);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
 template <int C, int ACT>
 static int launch_ffn(const pd_ffn_args_k& a, hipStream_t s) {
   const int lds = 128 * C * 2 + 128 * 64 * 2 + 64 * C * 2 + C * 64 * 2 + a.Hd * 4;
@@ -279,6 +503,7 @@ static int launch_ffn(const pd_ffn_args_k& a, hipStream_t s) {
   return PD_OK;
 }
 
+extern "C" int pd_ffn_use_64 = 1;   // units = 256: the 64-row, two-workgroups-per-CU kernel (0: the 128-row kernel; A/B switch)
 extern "C" int pd_ffn_debug_flags = 0;
 extern "C" unsigned long long* pd_ffn_trace = nullptr;   // profiling ablations only (scripts/bench_ffn.py)
 
@@ -300,6 +525,7 @@ extern "C" int pd_ffn_fused(const float* x, float* out, const float* gamma, cons
   a.trace = pd_ffn_trace;
   hipStream_t s = (hipStream_t)stream;
 #define PD_FFN(ACT)                                  \
+  if (C == 256 && pd_ffn_use_64 && Hd * 4 + 2 * 32768 + 8192 <= 80 * 1024) return launch_ffn64<ACT>(a, s);   \
   if (C == 256) return launch_ffn<256, ACT>(a, s);   \
   if (C == 128) return launch_ffn<128, ACT>(a, s);   \
   return launch_ffn<64, ACT>(a, s);

@@ -5,7 +5,10 @@ from prediff_amd.packing import pack_linear
 import ctypes
 dbg = ctypes.c_int.in_dll(L.lib(), "pd_ffn_debug_flags")
 dbg.value = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-for B in (16, 32):
+use64 = ctypes.c_int.in_dll(L.lib(), "pd_ffn_use_64")
+if len(sys.argv) > 2:
+    use64.value = int(sys.argv[2])     # 1: 64-row kernel, two workgroups per CU (default); 0: 128-row kernel
+for B in (4, 16, 32):
     M, C, Hd = B * 3328, 256, 1024
     x = torch.randn(M, C, device="cuda")
     g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
@@ -20,9 +23,11 @@ for B in (16, 32):
     for _ in range(20): L.ffn_fused(x, out, g, b, w1, b1, w2, b2, M, C, Hd)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
-    print(f"[dbg {dbg.value}] ffn_fused L0 B={B}: {us:.1f} us  {4.0 * M * C * Hd / us / 1e6:.1f} TFLOP/s")
+    print(f"[dbg {dbg.value} use64 {use64.value}] ffn_fused L0 B={B}: {us:.1f} us  {4.0 * M * C * Hd / us / 1e6:.1f} TFLOP/s")
 
-# per-slot clock stamps (waves 0 and 4 of workgroup 300): work time and barrier wait of every slot
+if use64.value:
+    sys.exit(0)
+# per-slot clock stamps of the 128-row kernel (waves 0 and 4 of workgroup 300): work time and barrier wait of every slot
 tr = torch.zeros(512, dtype=torch.int64, device="cuda")
 ctypes.c_void_p.in_dll(L.lib(), "pd_ffn_trace").value = tr.data_ptr()
 L.ffn_fused(x, out, g, b, w1, b1, w2, b2, M, C, Hd)

@@ -77,6 +77,9 @@ TINY_UNET_CFGS = {
     "spatial_lg_4": _unet("spatial_lg_4", padding_type="ignore"),
     "axial_depth2": _unet("axial", depth=[2, 2], ffn_activation="leaky"),
     "default_cuboids": _unet(None, padding_type="ignore", use_inter_ffn=False),   # ctor-default (4,4,4) l / d
+    # cuboids larger than 64 slots: one cuboid = the whole grid (5 x 8 x 8 = 320, level 1: 80) / one frame (16 x 16 = 256, level 1: 64)
+    "full": _unet("full"),
+    "divided_st_16": _unet("divided_st", input_shape=[3, 16, 16, 4], target_shape=[2, 16, 16, 4]),
 }
 
 TINY_VAE_CFG = dict(in_channels=1, out_channels=1, down_block_types=["DownEncoderBlock2D"] * 3,

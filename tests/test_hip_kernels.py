@@ -289,6 +289,33 @@ def test_attention_axial_bf16(shape, cuboid, Cn, heads, force_generic):
     assert rel_l2(out, ref) < 6e-3
 
 
+# cuboid volumes 17..64: 2-4 key tiles of the MFMA core (full-resolution axial cuboids 25 / 48 / 24; non-axial patterns: 32 / 64 / 16)
+MULTI_TILE = [((25, 12, 12), (25, 1, 1), (0, 0, 0), LLL, "zeros", 256, 4), ((5, 48, 6), (1, 48, 1), (0, 0, 0), LLL, "zeros", 256, 4),
+              ((25, 24, 4), (1, 24, 1), (0, 0, 0), LLL, "zeros", 512, 4), ((5, 8, 8), (2, 4, 4), (1, 2, 2), LLL, "ignore", 64, 2),
+              ((5, 7, 6), (2, 4, 4), (1, 2, 2), LLL, "ignore", 64, 2), ((5, 8, 8), (4, 4, 4), (0, 0, 0), DDD, "ignore", 64, 2),
+              ((3, 8, 8), (4, 16, 2), (2, 1, 1), LLL, "ignore", 64, 2)]
+
+
+@pytest.mark.parametrize("shape,cuboid,shift,strategy,padding_type,Cn,heads", MULTI_TILE)
+def test_attention_mfma_multi_tile_bf16(shape, cuboid, shift, strategy, padding_type, Cn, heads):
+    out, ref = _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, 2, "bf16", False)
+    assert rel_l2(out, ref) < 6e-3
+    out_g, _ = _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, 2, "bf16", True)
+    assert rel_l2(out, out_g) < 6e-3          # MFMA core (bf16 probabilities) vs the fp32 VALU kernel on the same bf16 q/k/v
+
+
+# cuboids of more than 64 slots ("full" / "divided_st" patterns): online-softmax kernel, incl. a shifted + masked and a padded case
+LARGE = [((5, 8, 8), (5, 8, 8), (0, 0, 0), LLL, "zeros", 64, 2), ((13, 16, 16), (1, 16, 16), (0, 0, 0), LLL, "zeros", 256, 4),
+         ((3, 16, 8), (1, 16, 8), (0, 0, 0), LLL, "zeros", 512, 4), ((5, 12, 12), (2, 8, 8), (1, 4, 4), LLL, "ignore", 64, 2),
+         ((5, 11, 10), (3, 6, 6), (0, 0, 0), LLL, "ignore", 128, 4)]
+
+
+@pytest.mark.parametrize("shape,cuboid,shift,strategy,padding_type,Cn,heads", LARGE)
+def test_attention_large_cuboids_bf16(shape, cuboid, shift, strategy, padding_type, Cn, heads):
+    out, ref = _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, 2, "bf16", False)
+    assert rel_l2(out, ref) < 6e-3
+
+
 GENERIC = [((5, 8, 8), (2, 4, 4), (0, 0, 0), LLL, "zeros"), ((5, 8, 8), (2, 4, 4), (1, 2, 2), LLL, "zeros"),
            ((5, 8, 8), (2, 4, 4), (1, 2, 2), LLL, "ignore"), ((5, 7, 6), (2, 4, 4), (1, 2, 2), LLL, "ignore"),
            ((5, 8, 8), (1, 4, 4), (0, 0, 0), DDD, "zeros"), ((3, 8, 8), (4, 16, 2), (2, 1, 1), LLL, "ignore"),

@@ -37,6 +37,12 @@ def test_tiny_unet_vs_oracle_and_golden(golden, name, precision):
     x = seeded_input(name + "x", (2,) + tuple(cfg["target_shape"]), 2)
     cond = seeded_input(name + "c", (2,) + tuple(cfg["input_shape"]), 3)
     t = torch.tensor([7, 431])
+    if precision == "fp32" and name in ("full", "divided_st_16"):
+        # cuboids of more than 64 slots run on the online-softmax MFMA core, which takes bf16 q/k/v: the fp32-class engine says so
+        from prediff_amd._lib import PrediffHipError
+        with pytest.raises(PrediffHipError, match="cuboid volume"):
+            net(x.cuda(), t.cuda(), cond.cuda())
+        return
     out = net(x.cuda(), t.cuda(), cond.cuda())
     ref = OU.unet_forward(sd, cfg, x, t, cond)
     e_or, e_gold = rel_l2(out, ref), rel_l2(out, golden("tiny_unet")[f"{name}_out"])
