@@ -2,9 +2,9 @@
 context encode (VAE encoder, 7 frames / trajectory) | DDIM-50 loop | decode (VAE decoder, 6 frames / trajectory)."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from _cases import V1_UNET_CFG, V1_VAE_CFG
-from _weights import seeded_state_dict
+sys.path.insert(0, ROOT)
+from prediff_amd.presets import V1_UNET_CFG, V1_VAE_CFG
+from prediff_amd.seeding import seeded_state_dict
 from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
 from prediff_amd.autoencoder_kl import AutoencoderKL
 from prediff_amd.latent_diffusion import LatentDiffusion
