@@ -209,7 +209,14 @@ def test_v1_aligned_step(golden, precision):
     ldm.use_hip_graph = False
     b = ldm.sample(cond=zc, batch_size=B, timesteps=2, use_alignment=True, alignment_kwargs={"avg_x_gt": avg}, return_decoded=False,
                    noise_tape=tape)
-    assert torch.equal(a, b)
+    if precision == "fp32":
+        assert torch.equal(a, b)
+    else:
+        # bf16 engine, fewer than 17 trajectories per launch: the lanes (1 trajectory each here) and the eager batch of 2 use
+        # different K-slicings of the split-K Conv3d (csrc/igemm256.hip) -> fp32 summation order differs -> equal to bf16 noise
+        e = rel_l2(a, b)
+        print(f"[v1 aligned bf16] lanes of 1 vs eager batch of 2: rel-L2 {e:.3e}")
+        assert e < 1e-2
 
 
 # ------------------------------------------------------------------------------------------------ config 5 (geometry; bf16 / fp32 operands)
