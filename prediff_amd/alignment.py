@@ -48,19 +48,75 @@ def timestep_embedding(t, dim, max_period=10000):
     return emb
 
 
+class _HipConv3d(torch.autograd.Function):
+    """3x3x3, stride-1, pad-1 Conv3d of the guidance network on the engine's implicit-GEMM kernel, inside PyTorch autograd.
+
+    The guidance gradient is only ever taken w.r.t. the noisy latent (the network is frozen), so the backward is data-gradient
+    only: a convolution of grad_out with the spatially flipped, channel-transposed filter -- the same `pd_igemm` launch with a
+    second weight pack.  Both directions run the hi/lo-split bf16 MFMA form (fp32-class accuracy, tests/test_hip_kernels.py:
+    2e-5 per GEMM), so the guidance keeps the reference's fp32 numerics to ~1e-5; PyTorch's own fp32 Conv3d (MIOpen) spent
+    ~70 % of the 25 ms guidance gradient at 32 trajectories in these six convolutions."""
+
+    @staticmethod
+    def _packs(conv: nn.Conv3d, device):
+        from . import _lib as L
+        from .packing import pack_conv
+        key = (str(device), conv.weight.data_ptr(), conv.weight._version)
+        cached = getattr(conv, "_hip_packs", None)
+        if cached is None or cached[0] != key:
+            w = conv.weight.detach().to(device)
+            fwd = pack_conv(w, True)                                              # (27, Cout, Cin_p) hi, lo
+            bwd = pack_conv(w.flip(2, 3, 4).transpose(0, 1).contiguous(), True)   # (27, Cin, Cout_p): dgrad filter
+            bias = conv.bias.detach().float().contiguous().to(device) if conv.bias is not None else None
+            cached = (key, fwd, bwd, bias)
+            conv._hip_packs = cached
+        return cached[1], cached[2], cached[3]
+
+    @staticmethod
+    def _run(x_ncthw, w_hi, w_lo, bias, n_out):
+        from . import _lib as L
+        from .packing import pad64, split_bf16
+        B, Cn, T, H, W = x_ncthw.shape
+        M = B * T * H * W
+        Cp = pad64(Cn)
+        rows = x_ncthw.permute(0, 2, 3, 4, 1).reshape(M, Cn)
+        a = rows if Cp == Cn else F.pad(rows, (0, Cp - Cn))
+        a_hi, a_lo = split_bf16(a.float(), True)
+        out = torch.empty((M, n_out), dtype=torch.float32, device=x_ncthw.device)
+        with L.on_device(x_ncthw):
+            L.igemm(a_hi, w_hi, A_lo=a_lo, W_lo=w_lo, M=M, N=n_out, Cin=Cp, taps=27, w_tap_stride=n_out * Cp,
+                    geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias, out_f32=out)
+        return out.reshape(B, T, H, W, n_out).permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def forward(ctx, x, conv):
+        fwd, bwd, bias = _HipConv3d._packs(conv, x.device)
+        ctx.bwd, ctx.n_in = bwd, x.shape[1]
+        return _HipConv3d._run(x, fwd[0], fwd[1], bias, conv.out_channels)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return _HipConv3d._run(grad_out, ctx.bwd[0], ctx.bwd[1], None, ctx.n_in), None
+
+
+USE_HIP_CONV = True      # engine switch: False = nn.Conv3d (MIOpen) for the guidance network's convolutions
+# (the token-level nn.Linear layers were tried on pd_igemm the same way: slower -- 16.6 ms against 15.1 ms per gradient at 32
+#  trajectories; hipBLASLt's fp32 GEMM is fast enough that the fp32 -> bf16 hi/lo operand passes cost more than they save)
+
+
 def resblock_forward(m: TimeEmbedResBlock, x, emb=None):
     """models/time_embed.py:134-169 on channels-last input."""
     xc = x.permute(0, 4, 1, 2, 3)
-    h = m.in_layers[2](F.silu(m.in_layers[0](xc)))
+    h = _conv3d(m.in_layers[2], F.silu(m.in_layers[0](xc)))
     if m.use_embed:
         e = m.emb_layers[1](F.silu(emb)).type(h.dtype)[:, :, None, None, None]
         if m.use_scale_shift_norm:
             scale, shift = torch.chunk(e, 2, dim=1)
-            h = m.out_layers[3](F.silu(m.out_layers[0](h) * (1 + scale) + shift))
+            h = _conv3d(m.out_layers[3], F.silu(m.out_layers[0](h) * (1 + scale) + shift))
         else:
-            h = m.out_layers[3](F.silu(m.out_layers[0](h + e)))
+            h = _conv3d(m.out_layers[3], F.silu(m.out_layers[0](h + e)))
     else:
-        h = m.out_layers[3](F.silu(m.out_layers[0](h)))
+        h = _conv3d(m.out_layers[3], F.silu(m.out_layers[0](h)))
     return (m.skip_connection(xc) + h).permute(0, 2, 3, 4, 1)
 
 

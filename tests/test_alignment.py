@@ -110,3 +110,28 @@ def test_aligned_sampling_on_gpu(golden, precision):
         outs.append(ldm.sample(cond={"y": y}, batch_size=B, timesteps=3, use_alignment=True, alignment_kwargs={"avg_x_gt": avg},
                                return_decoded=False, noise_tape=torch.as_tensor(g["tape"])))
     assert torch.equal(outs[0], lat) and torch.equal(outs[1], lat) and torch.equal(outs[2], lat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,shape", [(65, 128, (6, 16, 16)), (128, 128, (6, 16, 16)), (256, 256, (6, 8, 8)), (32, 48, (3, 5, 7))])
+def test_hip_conv3d_autograd_function(cin, cout, shape):
+    """The guidance network's 3x3x3 convolutions run on pd_igemm inside autograd (hi/lo-split: fp32-class accuracy): forward and
+    the data gradient (the only gradient the guidance needs) against PyTorch's fp32 Conv3d."""
+    from prediff_amd import alignment as AL
+    g = torch.Generator().manual_seed(cin + cout)
+    conv = torch.nn.Conv3d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (27 * cin) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    conv = conv.cuda().requires_grad_(False)
+    x = torch.randn((2, cin) + shape, generator=g).cuda()
+    gout = torch.randn((2, cout) + shape, generator=g).cuda()
+    xa = x.clone().requires_grad_(True)
+    ya = AL._conv3d(conv, xa)
+    (ga,) = torch.autograd.grad(ya, xa, gout)
+    xb = x.clone().requires_grad_(True)
+    yb = conv(xb)
+    (gb,) = torch.autograd.grad(yb, xb, gout)
+    assert ya.shape == yb.shape and rel_l2(ya.detach(), yb.detach()) < 3e-5 and rel_l2(ga, gb) < 3e-5
+    # the frozen weights are packed once per weight version
+    assert conv._hip_packs[0][2] == conv.weight._version
