@@ -104,6 +104,14 @@ USE_HIP_CONV = True      # engine switch: False = nn.Conv3d (MIOpen) for the gui
 #  trajectories; hipBLASLt's fp32 GEMM is fast enough that the fp32 -> bf16 hi/lo operand passes cost more than they save)
 
 
+def _conv3d(conv: nn.Conv3d, x):
+    """conv(x) on NCTHW x; on a HIP device the 3x3x3 convolutions go through _HipConv3d."""
+    if (USE_HIP_CONV and x.is_cuda and conv.kernel_size == (3, 3, 3) and conv.stride == (1, 1, 1) and conv.padding == (1, 1, 1)
+            and conv.dilation == (1, 1, 1) and conv.groups == 1 and x.dtype == torch.float32):
+        return _HipConv3d.apply(x, conv)
+    return conv(x)
+
+
 def resblock_forward(m: TimeEmbedResBlock, x, emb=None):
     """models/time_embed.py:134-169 on channels-last input."""
     xc = x.permute(0, 4, 1, 2, 3)
