@@ -120,6 +120,14 @@ typedef struct pd_cuboid_attn_args {
 } pd_cuboid_attn_args;
 int pd_cuboid_attention(const pd_cuboid_attn_args* a, pd_stream_t stream);
 
+/* Data gradient of pd_cuboid_attention (fp32): given qkv (B, ntok, 3C) and d_out (B, ntok, C), both in natural token order, writes
+ * d_qkv (B, ntok, 3C).  The probabilities are recomputed from qkv + bias; bias table and weights get no gradient (sampling-time
+ * guidance only).  Replaces what torch.autograd derives for cuboid_transformer.py:852-861,947-949 when the knowledge-alignment
+ * gradient is taken (prediff/knowledge_alignment/alignment.py:60-66 through models.py:459-528).  vol <= 64, head_dim <= 128. */
+int pd_cuboid_attention_bwd(const float* qkv, const float* d_out, const int32_t* tok_index, const float* bias,
+                            const uint8_t* mask, float* d_qkv, int B, int ntok, int C, int heads, int nc, int vol,
+                            int ld_qkv, int ld_dout, int ld_dqkv, float scale, pd_stream_t stream);
+
 /* Row softmax of fp32 scores (rows, n) -> bf16 probabilities (taming/attention.py:176, computed in fp32). */
 int pd_softmax_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t rows, int n, int ld_in, int ld_out,
                     pd_stream_t stream);

@@ -56,6 +56,7 @@ _PROTOS = {
                           [C.c_float, C.c_int, C.c_void_p]),
     "pd_cast_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 6 + [C.c_void_p]),
     "pd_cuboid_attention": (C.c_int, [C.POINTER(CuboidAttnArgs), C.c_void_p]),
+    "pd_cuboid_attention_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 9 + [C.c_float, C.c_void_p]),
     "pd_softmax_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 3 + [C.c_void_p]),
     "pd_unet_build_input": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]),
     "pd_timestep_embedding": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
@@ -222,6 +223,11 @@ def cuboid_attention(*, qkv_bf16=None, qkv_f32=None, tok_index, bias, mask, out_
     a.scale = scale
     a.force_generic = 1 if force_generic else 0
     _check(lib().pd_cuboid_attention(C.byref(a), stream_ptr()), "pd_cuboid_attention")
+
+
+def cuboid_attention_bwd(*, qkv, d_out, tok_index, bias, mask, d_qkv, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_dout, ld_dqkv, scale):
+    _check(lib().pd_cuboid_attention_bwd(ptr(qkv), ptr(d_out), ptr(tok_index), ptr(bias), ptr(mask), ptr(d_qkv), B, ntok, Cn, heads, nc,
+                                         vol, ld_qkv, ld_dout, ld_dqkv, scale, stream_ptr()), "pd_cuboid_attention_bwd")
 
 
 def softmax_rows(x, out, out_lo, rows, n, ld_in, ld_out):

@@ -128,6 +128,69 @@ def resblock_forward(m: TimeEmbedResBlock, x, emb=None):
     return (m.skip_connection(xc) + h).permute(0, 2, 3, 4, 1)
 
 
+class _HipCuboidAttention(torch.autograd.Function):
+    """softmax(scale q k^T + bias [masked]) v over the cuboids of one layer, forward (pd_cuboid_attention, fp32 path) and data
+    gradient (pd_cuboid_attention_bwd), both on q/k/v in NATURAL token order: the cuboid gather / scatter (cuboid_transformer.py:
+    388-467) happens inside the kernels, so the ~30 reorder / bmm / softmax / index_copy launches per layer and direction that
+    torch.autograd issues for cuboid_transformer.py:839-861,947-962 become one kernel each.  Only qkv is kept for the backward
+    (the probabilities are recomputed).  The relative-position table gets no gradient (sampling-time guidance only)."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, tok32, mask_u8, heads, scale):
+        from . import _lib as L
+        B, S, C3 = qkv.shape
+        Cn = C3 // 3
+        nc, vol = tok32.shape
+        qkv = qkv.contiguous()
+        out = torch.empty(B, S, Cn, dtype=torch.float32, device=qkv.device)
+        with L.on_device(qkv):
+            L.cuboid_attention(qkv_f32=qkv, tok_index=tok32, bias=bias, mask=mask_u8, out_f32=out, B=B, ntok=S, Cn=Cn, heads=heads,
+                               nc=nc, vol=vol, ld_qkv=C3, ld_out=Cn, scale=scale, force_generic=True)
+        ctx.save_for_backward(qkv, bias, tok32, mask_u8 if mask_u8 is not None else tok32.new_empty(0))
+        ctx.geom = (heads, scale, mask_u8 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from . import _lib as L
+        qkv, bias, tok32, mask_u8 = ctx.saved_tensors
+        heads, scale, has_mask = ctx.geom
+        B, S, C3 = qkv.shape
+        nc, vol = tok32.shape
+        d_out = d_out.contiguous()
+        d_qkv = torch.empty_like(qkv)
+        with L.on_device(qkv):
+            L.cuboid_attention_bwd(qkv=qkv, d_out=d_out, tok_index=tok32, bias=bias, mask=mask_u8 if has_mask else None, d_qkv=d_qkv,
+                                   B=B, ntok=S, Cn=C3 // 3, heads=heads, nc=nc, vol=vol, ld_qkv=C3, ld_dout=C3 // 3, ld_dqkv=C3,
+                                   scale=scale)
+        return d_qkv, None, None, None, None, None
+
+
+def _attn_bias(at, vol, device):
+    """(heads, vol, vol) fp32 bias of one layer (cuboid_transformer.py:856-859), zeros without relative positions; cached per
+    table version."""
+    tab = at.relative_position_bias_table if at.use_relative_pos else None
+    key = (str(device), vol) + ((tab.data_ptr(), tab._version) if tab is not None else ())
+    hit = getattr(at, "_hip_bias", None)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            if tab is not None:
+                idx = at.relative_position_index[:vol, :vol].reshape(-1)
+                b = tab[idx].reshape(vol, vol, -1).permute(2, 0, 1).float().contiguous()
+            else:
+                b = torch.zeros(at.num_heads, vol, vol, dtype=torch.float32, device=device)
+        at._hip_bias = hit = (key, b)
+    return hit[1]
+
+
+USE_HIP_ATTN = True    # the guidance network's cuboid attention (forward + data gradient) on the HIP kernels when x is on a GPU
+
+
+def _hip_attention_ok(at, x, vol):
+    return (USE_HIP_ATTN and x.is_cuda and x.dtype == torch.float32 and at.qkv.bias is None and vol <= 64
+            and x.shape[-1] // at.num_heads <= 128)
+
+
 def attention_forward(at: CuboidSelfAttentionLayer, x, tables):
     """cuboid_transformer.py:812-966 (no global vectors): returns the layer output (no residual)."""
     B, T, H, W, C = x.shape
@@ -136,10 +199,20 @@ def attention_forward(at: CuboidSelfAttentionLayer, x, tables):
     if dk not in tables:    # device copies of the static index / mask tables, made once per device
         tok = tables["tok_index"].to(x.device).long()
         tables[dk] = dict(tok=tok, gather=torch.where(tok >= 0, tok, torch.full_like(tok, S)).reshape(-1),
-                          mask=tables["mask"].to(x.device).bool() if tables["mask"] is not None else None)
+                          mask=tables["mask"].to(x.device).bool() if tables["mask"] is not None else None,
+                          tok32=tok.to(torch.int32).contiguous(),
+                          mask_u8=tables["mask"].to(x.device).to(torch.uint8).contiguous() if tables["mask"] is not None else None)
     dev_t = tables[dk]
     tok, gather = dev_t["tok"], dev_t["gather"]
     nc, vol = tok.shape
+    if _hip_attention_ok(at, x, vol):
+        # natural token order end to end: the qkv Linear commutes with the cuboid gather, and a padded slot's q/k/v are zero rows
+        # either way (no qkv bias)
+        qkv = at.qkv(at.norm(x).reshape(B, S, C))
+        y = _HipCuboidAttention.apply(qkv, _attn_bias(at, vol, x.device), dev_t["tok32"], dev_t["mask_u8"], at.num_heads, float(at.scale))
+        if at.use_final_proj:
+            y = at.proj(y)
+        return y.reshape(B, T, H, W, C)
     h = at.norm(x).reshape(B, S, C)
     h = torch.cat([h, h.new_zeros(B, 1, C)], dim=1)                  # row S = the zero padding token
     xr = h[:, gather].reshape(B, nc, vol, C)

@@ -377,6 +377,115 @@ extern "C" int pd_cuboid_attention(const pd_cuboid_attn_args* pa, pd_stream_t st
   return PD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------- data gradient (guidance network)
+// d(loss)/d(q, k, v) of the cuboid attention above, fp32 throughout, one workgroup per (sample, cuboid, head).  The probabilities are
+// recomputed from q, k and the bias (nothing but qkv is kept from the forward); with P = softmax(s q k^T + bias) (masked entries 0):
+//   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - rowsum(P o dP)),   dQ = s dS K,   dK = s dS^T Q.
+// This is what autograd derives for cuboid_transformer.py:852-861,947-949 inside the reference's knowledge-alignment gradient
+// (alignment.py:60-66 -> models.py:459-528); the relative-position table and the weights get no gradient here (sampling only).
+__global__ void __launch_bounds__(256) cuboid_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_out,
+                                                              const int32_t* __restrict__ tok_index, const float* __restrict__ bias,
+                                                              const uint8_t* __restrict__ mask, float* __restrict__ d_qkv, int B, int ntok,
+                                                              int C, int heads, int nc, int vol, int ld_qkv, int ld_dout, int ld_dqkv,
+                                                              float scale) {
+  extern __shared__ float sm[];
+  const int hd = C / heads;
+  float* sq = sm;                        // [vol][hd]    q * scale
+  float* sk = sq + vol * hd;             // [vol][hd+1]
+  float* sv = sk + vol * (hd + 1);       // [vol][hd+1]
+  float* sdo = sv + vol * (hd + 1);      // [vol][hd]
+  float* sp = sdo + vol * hd;            // [vol][vol+1] P
+  float* sds = sp + vol * (vol + 1);     // [vol][vol+1] dP, then dS
+  __shared__ int stok[GA_MAXVOL];
+  const int64_t item = blockIdx.x;
+  const int h = (int)(item % heads);
+  const int c = (int)((item / heads) % nc);
+  const int b = (int)(item / ((int64_t)heads * nc));
+  const int tid = threadIdx.x;
+  if (tid < vol) stok[tid] = tok_index[c * vol + tid];
+  __syncthreads();
+  for (int i = tid; i < vol * hd; i += 256) {
+    const int r = i / hd, d = i - r * hd;
+    const int tok = stok[r];
+    float qv = 0.f, kv = 0.f, vv = 0.f, gv = 0.f;
+    if (tok >= 0) {
+      const float* row = qkv + ((int64_t)b * ntok + tok) * ld_qkv + h * hd + d;
+      qv = row[0]; kv = row[C]; vv = row[2 * C];
+      gv = d_out[((int64_t)b * ntok + tok) * ld_dout + h * hd + d];
+    }
+    sq[r * hd + d] = qv * scale;
+    sk[r * (hd + 1) + d] = kv;
+    sv[r * (hd + 1) + d] = vv;
+    sdo[r * hd + d] = gv;
+  }
+  __syncthreads();
+  for (int i = tid; i < vol * vol; i += 256) {
+    const int qi = i / vol, kj = i - qi * vol;
+    float a = 0.f, g = 0.f;
+    for (int d = 0; d < hd; ++d) {
+      a += sq[qi * hd + d] * sk[kj * (hd + 1) + d];
+      g += sdo[qi * hd + d] * sv[kj * (hd + 1) + d];
+    }
+    a += bias[((int64_t)h * vol + qi) * vol + kj];
+    if (mask && !mask[((int64_t)c * vol + qi) * vol + kj]) a = -1e18f;
+    sp[qi * (vol + 1) + kj] = a;
+    sds[qi * (vol + 1) + kj] = g;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int qi = wv; qi < vol; qi += 4) {
+    const float v = lane < vol ? sp[qi * (vol + 1) + lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float e = lane < vol ? expf(v - mx) : 0.f;
+    const float sum = wave_sum(e);
+    const float pr = (lane < vol && v > -1e18f) ? e / sum : 0.f;
+    const float g = lane < vol ? sds[qi * (vol + 1) + lane] : 0.f;
+    const float delta = wave_sum(pr * g);
+    if (lane < vol) {
+      sp[qi * (vol + 1) + lane] = pr;
+      sds[qi * (vol + 1) + lane] = pr * (g - delta);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < vol * hd; i += 256) {
+    const int r = i / hd, d = i - r * hd;
+    const int tok = stok[r];
+    if (tok < 0) continue;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < vol; ++j) {
+      dq += sds[r * (vol + 1) + j] * sk[j * (hd + 1) + d];
+      dk += sds[j * (vol + 1) + r] * sq[j * hd + d];      // sq already carries the scale
+      dv += sp[j * (vol + 1) + r] * sdo[j * hd + d];
+    }
+    float* row = d_qkv + ((int64_t)b * ntok + tok) * ld_dqkv + h * hd + d;
+    row[0] = dq * scale; row[C] = dk; row[2 * C] = dv;
+  }
+}
+
+extern "C" int pd_cuboid_attention_bwd(const float* qkv, const float* d_out, const int32_t* tok_index, const float* bias,
+                                       const uint8_t* mask, float* d_qkv, int B, int ntok, int C, int heads, int nc, int vol,
+                                       int ld_qkv, int ld_dout, int ld_dqkv, float scale, pd_stream_t stream) {
+  PD_CHECK_ARG(qkv && d_out && tok_index && bias && d_qkv, "pd_cuboid_attention_bwd: null pointer");
+  PD_CHECK_ARG(heads > 0 && C % heads == 0 && vol > 0 && nc > 0 && B >= 0, "pd_cuboid_attention_bwd: bad geometry");
+  const int hd = C / heads;
+  if (vol > GA_MAXVOL || hd > 128) {
+    pd_set_error("pd_cuboid_attention_bwd: cuboid volume %d (max %d) / head_dim %d (max 128) not supported", vol, GA_MAXVOL, hd);
+    return PD_ERR_UNSUPPORTED;
+  }
+  if (B == 0) return PD_OK;
+  const size_t lds = sizeof(float) * ((size_t)vol * hd * 2 + (size_t)vol * (hd + 1) * 2 + (size_t)vol * (vol + 1) * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)cuboid_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    attr_set = true;
+  }
+  const int64_t nitems = (int64_t)B * nc * heads;
+  hipLaunchKernelGGL(cuboid_attn_bwd_kernel, dim3((unsigned)nitems), dim3(256), lds, (hipStream_t)stream, qkv, d_out, tok_index, bias, mask,
+                     d_qkv, B, ntok, C, heads, nc, vol, ld_qkv, ld_dout, ld_dqkv, scale);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------- row softmax (VAE mid attention)
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ x, pd_bf16* __restrict__ out,
                                                            pd_bf16* __restrict__ out_lo, int64_t rows, int n, int ld_in, int ld_out) {

@@ -135,3 +135,43 @@ def test_hip_conv3d_autograd_function(cin, cout, shape):
     assert ya.shape == yb.shape and rel_l2(ya.detach(), yb.detach()) < 3e-5 and rel_l2(ga, gb) < 3e-5
     # the frozen weights are packed once per weight version
     assert conv._hip_packs[0][2] == conv.weight._version
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dim,heads,cuboid,shift,strategy,padding", [
+    ((6, 16, 16), 128, 4, (6, 1, 1), (0, 0, 0), ("l", "l", "l"), "zeros"),
+    ((6, 16, 16), 128, 4, (1, 16, 1), (0, 0, 0), ("l", "l", "l"), "zeros"),
+    ((6, 8, 8), 256, 4, (1, 1, 8), (0, 0, 0), ("l", "l", "l"), "zeros"),
+    ((5, 7, 6), 64, 2, (2, 4, 4), (1, 2, 2), ("l", "l", "l"), "zeros"),       # padded, shifted, masked
+    ((4, 8, 8), 64, 2, (2, 4, 4), (0, 0, 0), ("d", "d", "d"), "ignore"),      # dilated
+    ((3, 6, 5), 32, 1, (3, 4, 4), (0, 2, 2), ("l", "l", "l"), "ignore"),      # padding masked out ("ignore")
+])
+def test_hip_cuboid_attention_autograd_function(shape, dim, heads, cuboid, shift, strategy, padding):
+    """The guidance network's cuboid attention on pd_cuboid_attention / pd_cuboid_attention_bwd inside autograd, against the
+    PyTorch statement of the same layer: output and the data gradient."""
+    from prediff_amd import alignment as AL
+    from prediff_amd.cuboid_geometry import attention_tables
+    from prediff_amd.cuboid_transformer_unet import CuboidSelfAttentionLayer
+    torch.manual_seed(dim + heads + sum(cuboid))
+    at = CuboidSelfAttentionLayer(dim, heads, cuboid_size=cuboid, shift_size=shift, strategy=strategy, padding_type=padding)
+    with torch.no_grad():
+        for p in at.parameters():
+            p.copy_(torch.randn(p.shape) * (0.5 if p.ndim == 2 and p.shape[-1] == heads else 1.0 / p.shape[-1] ** 0.5 if p.ndim == 2 else 1.0))
+        at.norm.weight.add_(1.0)
+    at = at.cuda().requires_grad_(False)
+    x = torch.randn((2,) + shape + (dim,)).cuda()
+    gout = torch.randn((2,) + shape + (dim,)).cuda()
+    res = []
+    for use in (True, False):
+        AL.USE_HIP_ATTN = use
+        try:
+            tables = attention_tables(shape, cuboid, shift, strategy, padding)
+            xa = x.clone().requires_grad_(True)
+            y = AL.attention_forward(at, xa, tables)
+            (g,) = torch.autograd.grad(y, xa, gout)
+            res.append((y.detach(), g))
+        finally:
+            AL.USE_HIP_ATTN = True
+    ey, eg = rel_l2(res[0][0], res[1][0]), rel_l2(res[0][1], res[1][1])
+    print(f"[hip cuboid attention autograd {shape} {cuboid}] out {ey:.2e} grad {eg:.2e}")
+    assert ey < 2e-5 and eg < 2e-5
