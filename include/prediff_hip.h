@@ -94,6 +94,14 @@ int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, con
                       const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo,
                       int B, int S, int C, int G, int ld_out, float eps, int silu, pd_stream_t stream);
 
+/* Data gradient of pd_groupnorm_silu on contiguous channels-last rows (ld = C): dx (B, S, C) from x, dy and the forward's
+ * partial sums (mean / rstd are re-derived from them); bwd_partials: B * pd_groupnorm_nchunk(S, C) * G * 2 doubles of scratch.
+ * gamma / beta get no gradient (frozen guidance network).  C must divide 256.  What autograd derives for
+ * models/time_embed.py:89-120,134-169 (GroupNorm32 -> SiLU) inside the knowledge-alignment gradient (alignment.py:60-66). */
+int pd_groupnorm_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
+                          const double* fwd_partials, double* bwd_partials, float* dx, int B, int S, int C, int G,
+                          float eps, int silu, pd_stream_t stream);
+
 /* fp32 rows -> bf16 (hi[, lo]) rows with optional row gather (rows_per_sample_out rows taken from offset row_off inside
  * each rows_per_sample_in block) and zero padded columns.  Used for un-normalised GEMM inputs
  * (cuboid_transformer_unet.py:492 x[:, in_len:], time_embed.py:169 skip_connection input, cuboid_transformer.py:373). */

@@ -54,6 +54,7 @@ _PROTOS = {
     "pd_groupnorm_nchunk": (C.c_int, [C.c_int, C.c_int]),
     "pd_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 +
                           [C.c_float, C.c_int, C.c_void_p]),
+    "pd_groupnorm_silu_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
     "pd_cast_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 6 + [C.c_void_p]),
     "pd_cuboid_attention": (C.c_int, [C.POINTER(CuboidAttnArgs), C.c_void_p]),
     "pd_cuboid_attention_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 9 + [C.c_float, C.c_void_p]),
@@ -207,6 +208,11 @@ def groupnorm_silu(x, gamma, beta, partials, out, out_lo, B, S, Cn, G, ld_out, e
     _check(lib().pd_groupnorm_silu(ptr(x), ptr(gamma), ptr(beta), ptr(ss_scale), ptr(ss_shift), ld_ss, ptr(partials),
                                    ptr(out), ptr(out_lo), B, S, Cn, G, ld_out, eps, 1 if silu else 0, stream_ptr()),
            "pd_groupnorm_silu")
+
+
+def groupnorm_silu_bwd(x, dy, gamma, beta, fwd_partials, bwd_partials, dx, B, S, Cn, G, eps=1e-5, silu=True):
+    _check(lib().pd_groupnorm_silu_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(fwd_partials), ptr(bwd_partials), ptr(dx), B, S, Cn, G,
+                                       eps, 1 if silu else 0, stream_ptr()), "pd_groupnorm_silu_bwd")
 
 
 def cast_rows(x, out, out_lo, n_samples, rows_in, row_off, rows_out, Cn, ld_in, ld_out):

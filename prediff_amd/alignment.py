@@ -75,15 +75,16 @@ class _HipConv3d(torch.autograd.Function):
     @staticmethod
     def _run(x_ncthw, w_hi, w_lo, bias, n_out):
         from . import _lib as L
-        from .packing import pad64, split_bf16
+        from .packing import pad64
         B, Cn, T, H, W = x_ncthw.shape
         M = B * T * H * W
         Cp = pad64(Cn)
-        rows = x_ncthw.permute(0, 2, 3, 4, 1).reshape(M, Cn)
-        a = rows if Cp == Cn else F.pad(rows, (0, Cp - Cn))
-        a_hi, a_lo = split_bf16(a.float(), True)
-        out = torch.empty((M, n_out), dtype=torch.float32, device=x_ncthw.device)
-        with L.on_device(x_ncthw):
+        rows = x_ncthw.permute(0, 2, 3, 4, 1).reshape(M, Cn).float().contiguous()
+        a_hi = torch.empty((M, Cp), dtype=torch.bfloat16, device=rows.device)
+        a_lo = torch.empty_like(a_hi)
+        out = torch.empty((M, n_out), dtype=torch.float32, device=rows.device)
+        with L.on_device(rows):
+            L.cast_rows(rows, a_hi, a_lo, 1, M, 0, M, Cn, Cn, Cp)          # fp32 -> bf16 hi + lo, zero-padded columns, one pass
             L.igemm(a_hi, w_hi, A_lo=a_lo, W_lo=w_lo, M=M, N=n_out, Cin=Cp, taps=27, w_tap_stride=n_out * Cp,
                     geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias, out_f32=out)
         return out.reshape(B, T, H, W, n_out).permute(0, 4, 1, 2, 3)
@@ -112,8 +113,84 @@ def _conv3d(conv: nn.Conv3d, x):
     return conv(x)
 
 
+class _HipGnSiluConv3d(torch.autograd.Function):
+    """conv3x3x3(SiLU(GroupNorm(x))) [+ per-sample vector] [+ residual] on channels-last rows (B, T, H, W, C), forward and data
+    gradient, without leaving the row layout: pd_groupnorm_silu writes the convolution's bf16 hi/lo operand directly, pd_igemm
+    adds bias / embedding vector / residual in its epilogue; backward = dgrad pd_igemm (flipped, transposed filter) then
+    pd_groupnorm_silu_bwd.  Replaces, per convolution and direction, PyTorch's GroupNorm + SiLU + two layout copies + the operand
+    split (models/time_embed.py:89-120,134-169).  Frozen network: only x (and the residual) get a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gn, conv, rowvec, residual):
+        from . import _lib as L
+        B, T, H, W, Cn = x.shape
+        S, M, N, G = T * H * W, B * T * H * W, conv.out_channels, gn.num_groups
+        fwd, bwd, bias = _HipConv3d._packs(conv, x.device)
+        x = x.contiguous()
+        dev = x.device
+        part = torch.empty(B * L.groupnorm_nchunk(S, Cn) * G * 2, dtype=torch.float64, device=dev)
+        a_hi = torch.empty((M, Cn), dtype=torch.bfloat16, device=dev)
+        a_lo = torch.empty_like(a_hi)
+        out = torch.empty((B, T, H, W, N), dtype=torch.float32, device=dev)
+        with L.on_device(x):
+            L.groupnorm_silu(x, gn.weight, gn.bias, part, a_hi, a_lo, B, S, Cn, G, Cn, gn.eps, silu=True)
+            L.igemm(a_hi, fwd[0], A_lo=a_lo, W_lo=fwd[1], M=M, N=N, Cin=Cn, taps=27, w_tap_stride=N * Cn,
+                    geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias, rowvec=rowvec, rows_per_sample=S if rowvec is not None else 0,
+                    residual=residual, out_f32=out)
+        ctx.save_for_backward(x, part, gn.weight, gn.bias)
+        ctx.bwd, ctx.geom, ctx.has_res = bwd, (B, T, H, W, Cn, N, G, gn.eps), residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from . import _lib as L
+        x, part, gamma, beta = ctx.saved_tensors
+        B, T, H, W, Cn, N, G, eps = ctx.geom
+        S, M = T * H * W, B * T * H * W
+        d_out = d_out.contiguous()
+        dev = x.device
+        g_hi = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        g_lo = torch.empty_like(g_hi)
+        da = torch.empty((M, Cn), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        part_b = torch.empty_like(part)
+        with L.on_device(x):
+            L.cast_rows(d_out, g_hi, g_lo, 1, M, 0, M, N, N, N)
+            L.igemm(g_hi, ctx.bwd[0], A_lo=g_lo, W_lo=ctx.bwd[1], M=M, N=Cn, Cin=N, taps=27, w_tap_stride=Cn * N,
+                    geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), out_f32=da)
+            L.groupnorm_silu_bwd(x, da, gamma, beta, part, part_b, dx, B, S, Cn, G, eps, silu=True)
+        return dx, None, None, None, (d_out if ctx.has_res else None)
+
+
+USE_HIP_RESBLOCK = True   # the guidance network's GroupNorm -> SiLU -> Conv3d pairs as one row-layout autograd node each
+
+
+def _hip_resblock_ok(m, x):
+    if not (USE_HIP_RESBLOCK and USE_HIP_CONV and x.is_cuda and x.dtype == torch.float32 and not m.use_scale_shift_norm):
+        return False
+    for gn, conv in ((m.in_layers[0], m.in_layers[2]), (m.out_layers[0], m.out_layers[3])):
+        Cn = conv.in_channels
+        if not (conv.kernel_size == (3, 3, 3) and conv.stride == (1, 1, 1) and conv.padding == (1, 1, 1) and conv.dilation == (1, 1, 1)
+                and conv.groups == 1 and Cn % 64 == 0 and Cn <= 256 and 256 % Cn == 0 and conv.out_channels % 64 == 0
+                and gn.num_groups <= 256 and gn.affine):
+            return False
+    sk = m.skip_connection
+    return isinstance(sk, nn.Identity) or (isinstance(sk, nn.Conv3d) and sk.kernel_size == (1, 1, 1))
+
+
 def resblock_forward(m: TimeEmbedResBlock, x, emb=None):
     """models/time_embed.py:134-169 on channels-last input."""
+    if _hip_resblock_ok(m, x):
+        e = None
+        if m.use_embed:
+            e = m.emb_layers[1](F.silu(emb)).float().contiguous()                   # (B, C_out): depends on t only, no gradient path
+            if e.requires_grad:
+                e = None
+        if e is not None or not m.use_embed:
+            sk = m.skip_connection
+            res = x if isinstance(sk, nn.Identity) else F.linear(x, sk.weight.reshape(sk.out_channels, sk.in_channels), sk.bias)
+            h = _HipGnSiluConv3d.apply(x, m.in_layers[0], m.in_layers[2], e, None)
+            return _HipGnSiluConv3d.apply(h, m.out_layers[0], m.out_layers[3], None, res.contiguous())
     xc = x.permute(0, 4, 1, 2, 3)
     h = _conv3d(m.in_layers[2], F.silu(m.in_layers[0](xc)))
     if m.use_embed:

@@ -397,6 +397,114 @@ extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float
 }
 
 // -------------------------------------------------------------------------------------------------
+// Data gradient of y = SiLU(GroupNorm(x)) on channels-last rows (guidance network, frozen affine): with xh = (x - mean) rstd,
+// n = gamma xh + beta, dn = dy SiLU'(n), dxh = dn gamma and N = S * C/G elements per (sample, group):
+//   dx = rstd (dxh - mean_N(dxh) - xh mean_N(dxh xh)).
+// Two passes like the forward: per-chunk fp64 partial sums of (dxh, dxh xh), then the apply pass reduces them in a fixed order
+// (deterministic).  mean / rstd are re-derived from the forward's partial sums.  A thread owns one channel; C divides 256.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gn_reduce_partials(const double* __restrict__ pb, int nchunk, int G, double* spart, double* sout) {
+  // pb: this sample's (nchunk, G, 2) partial sums -> sout[2 g], sout[2 g + 1]; 256 / G threads per group stride the chunks
+  const int tid = threadIdx.x, LP = 256 / G;
+  if (tid < LP * G) {
+    const int g = tid % G, j = tid / G;
+    double a = 0, b = 0;
+    for (int k = j; k < nchunk; k += LP) { a += pb[((int64_t)k * G + g) * 2]; b += pb[((int64_t)k * G + g) * 2 + 1]; }
+    spart[tid * 2] = a;
+    spart[tid * 2 + 1] = b;
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0, b = 0;
+    for (int j = 0; j < LP; ++j) { a += spart[(j * G + tid) * 2]; b += spart[(j * G + tid) * 2 + 1]; }
+    sout[tid * 2] = a;
+    sout[tid * 2 + 1] = b;
+  }
+  __syncthreads();
+}
+
+template <bool APPLY>
+__global__ void __launch_bounds__(256) gn_silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const double* __restrict__ fwd_partials, double* __restrict__ bwd_partials,
+                                                          float* __restrict__ dx, int S, int C, int G, float eps, int silu, int nchunk) {
+  __shared__ double spart[2 * 256];
+  __shared__ double sfwd[2 * 256];
+  __shared__ double sbwd[2 * 256];
+  __shared__ float sred[2 * 256];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / G;
+  const double cnt = (double)S * cpg;
+  gn_reduce_partials(fwd_partials + (int64_t)b * nchunk * G * 2, nchunk, G, spart, sfwd);
+  if (APPLY) gn_reduce_partials(bwd_partials + (int64_t)b * nchunk * G * 2, nchunk, G, spart, sbwd);
+  const int c = tid % C, rr = tid / C, RP = 256 / C, g = c / cpg;
+  const double mean_d = sfwd[g * 2] / cnt;
+  double var = sfwd[g * 2 + 1] / cnt - mean_d * mean_d;
+  if (var < 0) var = 0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float ga = gamma[c], a = rstd * ga, d = beta[c] - mean * a;
+  const float m1 = APPLY ? (float)(sbwd[g * 2] / cnt) : 0.f, m2 = APPLY ? (float)(sbwd[g * 2 + 1] / cnt) : 0.f;
+  const int r0 = chunk * GN_ROWS, r1 = min(S, r0 + GN_ROWS);
+  const int64_t base = ((int64_t)b * S + r0) * C + c;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+  for (int r = rr; r < r1 - r0; r += RP) {
+    const float xv = x[base + (int64_t)r * C], gy = dy[base + (int64_t)r * C];
+    const float n = xv * a + d;
+    float dn = gy;
+    if (silu) {
+      const float sig = 1.f / (1.f + __expf(-n));
+      dn = gy * sig * (1.f + n * (1.f - sig));
+    }
+    const float dxh = dn * ga, xh = (xv - mean) * rstd;
+    if (APPLY) {
+      dx[base + (int64_t)r * C] = rstd * (dxh - m1 - xh * m2);
+    } else {
+      s1 += dxh;
+      s2 += dxh * xh;
+    }
+  }
+  if (!APPLY) {
+    sred[tid * 2] = s1;
+    sred[tid * 2 + 1] = s2;
+    __syncthreads();
+    if (tid < G) {
+      double a1 = 0, a2 = 0;
+      for (int r = 0; r < RP; ++r)
+        for (int k = 0; k < cpg; ++k) {
+          const int t = r * C + tid * cpg + k;
+          a1 += sred[t * 2];
+          a2 += sred[t * 2 + 1];
+        }
+      double* out = bwd_partials + ((int64_t)b * nchunk + chunk) * G * 2;
+      out[tid * 2] = a1;
+      out[tid * 2 + 1] = a2;
+    }
+  }
+}
+
+extern "C" int pd_groupnorm_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
+                                     const double* fwd_partials, double* bwd_partials, float* dx, int B, int S, int C, int G,
+                                     float eps, int silu, pd_stream_t stream) {
+  PD_CHECK_ARG(x && dy && gamma && beta && fwd_partials && bwd_partials && dx, "pd_groupnorm_silu_bwd: null pointer");
+  PD_CHECK_ARG(G > 0 && C % G == 0, "pd_groupnorm_silu_bwd: bad C/G (%d,%d)", C, G);
+  if (C > 256 || 256 % C != 0 || G > 256) {
+    pd_set_error("pd_groupnorm_silu_bwd: C = %d must divide 256 (G = %d <= 256)", C, G);
+    return PD_ERR_UNSUPPORTED;
+  }
+  if (B <= 0 || S <= 0) return PD_OK;
+  const int nchunk = pd_groupnorm_nchunk(S, C);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_silu_bwd_kernel<false>, dim3(nchunk, B), dim3(256), 0, s, x, dy, gamma, beta, fwd_partials, bwd_partials, dx, S, C, G,
+                     eps, silu, nchunk);
+  PD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_silu_bwd_kernel<true>, dim3(nchunk, B), dim3(256), 0, s, x, dy, gamma, beta, fwd_partials, bwd_partials, dx, S, C, G,
+                     eps, silu, nchunk);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
 // fp32 -> bf16 row cast with row-slice gather and zero column padding
 // -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cast_rows_kernel(const float* __restrict__ x, pd_bf16* __restrict__ out,

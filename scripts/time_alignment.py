@@ -41,9 +41,15 @@ def loop(graph, n=6):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-print(f"aligned DDPM loop, ms/step: eager {loop(False):.1f}; denoiser graphs on lane streams overlapped with the guidance {loop(True):.1f}")
-# (tried in round 2: the guidance network under torch.autocast(bfloat16) -- 26.8 ms against 24.9 ms in fp32: MIOpen has no fast bf16
-#  Conv3d for these shapes on this stack, so the option was dropped; the guidance stays fp32 PyTorch autograd)
+print(f"aligned DDPM loop, ms/step: eager {loop(False):.1f}")
+for ns in (1, 2, 4):
+    if B % ns == 0:
+        ldm.num_streams = ns
+        print(f"aligned DDPM loop, ms/step: denoiser graphs on {ns} lane stream(s) overlapped with the guidance {loop(True):.1f}")
+ldm.num_streams = 2
+# history of the guidance gradient at 32 trajectories: 24.9 ms all-PyTorch fp32 (MIOpen Conv3d ~70 %; autocast(bf16) was slower, 26.8 ms)
+# -> 15.1 ms with the 3x3x3 convolutions on pd_igemm (_HipConv3d) -> 9.0 ms with the cuboid attention on pd_cuboid_attention(_bwd)
+# -> 7.6 ms with GroupNorm -> SiLU -> Conv3d as one row-layout node (pd_groupnorm_silu(_bwd)); all at fp32-class accuracy
 
 
 # experiment: the guidance gradient (autograd forward + backward) captured in a HIP graph

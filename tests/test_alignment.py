@@ -175,3 +175,37 @@ def test_hip_cuboid_attention_autograd_function(shape, dim, heads, cuboid, shift
     ey, eg = rel_l2(res[0][0], res[1][0]), rel_l2(res[0][1], res[1][1])
     print(f"[hip cuboid attention autograd {shape} {cuboid}] out {ey:.2e} grad {eg:.2e}")
     assert ey < 2e-5 and eg < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,emb,shape", [(64, 128, False, (6, 16, 16)), (128, 128, True, (6, 16, 16)), (256, 256, True, (6, 8, 8)),
+                                                (64, 64, True, (3, 5, 7))])
+def test_hip_resblock_autograd_nodes(cin, cout, emb, shape):
+    """TimeEmbedResBlock of the guidance network as two row-layout GroupNorm -> SiLU -> Conv3d nodes (pd_groupnorm_silu + pd_igemm,
+    backward pd_igemm dgrad + pd_groupnorm_silu_bwd) against the PyTorch statement: output and data gradient."""
+    from prediff_amd import alignment as AL
+    from prediff_amd.cuboid_transformer_unet import TimeEmbedResBlock
+    torch.manual_seed(cin + cout)
+    m = TimeEmbedResBlock(channels=cin, emb_channels=96 if emb else None, dropout=0.0, out_channels=cout, use_embed=emb, dims=3)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape) * (1.0 / (27 * p.shape[1]) ** 0.5 if p.ndim == 5 else 0.3))
+        for gn in (m.in_layers[0], m.out_layers[0]):
+            gn.weight.add_(1.0)
+    m = m.cuda().requires_grad_(False)
+    x = (torch.randn((2,) + shape + (cin,)) * 1.5 + 0.3).cuda()
+    e = torch.randn(2, 96).cuda() if emb else None
+    gout = torch.randn((2,) + shape + (cout,)).cuda()
+    res = []
+    for use in (True, False):
+        AL.USE_HIP_RESBLOCK = use
+        try:
+            xa = x.clone().requires_grad_(True)
+            y = AL.resblock_forward(m, xa, e)
+            (g,) = torch.autograd.grad(y, xa, gout)
+            res.append((y.detach(), g))
+        finally:
+            AL.USE_HIP_RESBLOCK = True
+    ey, eg = rel_l2(res[0][0], res[1][0]), rel_l2(res[0][1], res[1][1])
+    print(f"[hip resblock autograd {cin}->{cout} {shape}] out {ey:.2e} grad {eg:.2e}")
+    assert ey < 3e-5 and eg < 3e-5
