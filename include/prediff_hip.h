@@ -72,6 +72,10 @@ typedef struct pd_igemm_args {
                               is never split.  Used for small grids (few trajectories per launch): the K loop of a long-K launch is cut
                               into slices that run as separate workgroups, then summed in slice order (deterministic) with the epilogue */
   int64_t splitk_ws_elems;
+  int32_t fp8;             /* != 0: A and W hold OCP e4m3 bytes (lda / ldw / strides count elements = bytes; Cin % 128 == 0, lda/ldw % 16 == 0);
+                              the tensor scales go in alpha.  Long-K row-wise linear and stride-1 convolution launches only (the 256 x 256
+                              kernel, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales); no split, no batch */
+  int32_t reserved0;
 } pd_igemm_args;
 int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
 
@@ -93,6 +97,12 @@ int pd_groupnorm_nchunk(int S, int C);
 int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, const float* ss_scale,
                       const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo,
                       int B, int S, int C, int G, int ld_out, float eps, int silu, pd_stream_t stream);
+
+/* pd_groupnorm_silu with an OCP e4m3 output (the A operand of an fp8 pd_igemm launch): out[b, s, c] = e4m3(y * fp8_scale),
+ * round to nearest even, saturating at +-448; rows of C bytes.  C % 4 == 0, C/4 divides 256, 4 | C/G. */
+int pd_groupnorm_silu_fp8(const float* x, const float* gamma, const float* beta, const float* ss_scale,
+                          const float* ss_shift, int ld_ss, double* partials, uint8_t* out, int B, int S, int C, int G,
+                          float eps, int silu, float fp8_scale, pd_stream_t stream);
 
 /* Data gradient of pd_groupnorm_silu on contiguous channels-last rows (ld = C): dx (B, S, C) from x, dy and the forward's
  * partial sums (mean / rstd are re-derived from them); bwd_partials: B * pd_groupnorm_nchunk(S, C) * G * 2 doubles of scratch.

@@ -31,7 +31,7 @@ class IgemmArgs(C.Structure):
                  "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw", "ut", "uh", "uw", "vT", "vH", "vW",
                  "rows_per_sample", "ld_rowvec", "ld_res", "res_period", "ld_mul", "act", "ld_out", "ld_outb", "split")] + \
                [("alpha", C.c_float), ("tile", C.c_int32), ("vec_epilogue", C.c_int32), ("a_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("debug_flags", C.c_int32), ("ksplit", C.c_int32),
-                ("splitk_ws", C.c_void_p), ("splitk_ws_elems", C.c_int64)]
+                ("splitk_ws", C.c_void_p), ("splitk_ws_elems", C.c_int64), ("fp8", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class CuboidAttnArgs(C.Structure):
@@ -54,6 +54,7 @@ _PROTOS = {
     "pd_groupnorm_nchunk": (C.c_int, [C.c_int, C.c_int]),
     "pd_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 +
                           [C.c_float, C.c_int, C.c_void_p]),
+    "pd_groupnorm_silu_fp8": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "pd_groupnorm_silu_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
     "pd_cast_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 6 + [C.c_void_p]),
     "pd_cuboid_attention": (C.c_int, [C.POINTER(CuboidAttnArgs), C.c_void_p]),
@@ -141,7 +142,7 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
           A_lo=None, W_lo=None, bias=None, rowvec=None, rows_per_sample=0, residual=None, res_period=0,
           ld_res=None, mul=None, act="none", alpha=1.0, out_f32=None, out_bf16=None, out_bf16_lo=None,
           ld_out=None, ld_outb=None, nbatch=1, a_batch_stride=0, w_batch_stride=0, out_batch_stride=0,
-          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None):
+          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None, fp8=False):
     """Thin wrapper around pd_igemm.  `geom` = dict(B,Ti,Hi,Wi,To,Ho,Wo,KT,KH,KW,st,sh,sw,pt,ph,pw,ut,uh,uw) or None
     for a plain linear layer."""
     a = IgemmArgs()
@@ -171,6 +172,7 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
     a.alpha = alpha
     a.tile = tile
     a.debug_flags = debug_flags
+    a.fp8 = 1 if fp8 else 0           # A / W are e4m3 bytes (torch.float8_e4m3fn); tensor scales in alpha
     if splitk_ws is not None:       # fp32 workspace: lets the library split the K loop of small-grid, long-K launches
         a.splitk_ws, a.splitk_ws_elems = ptr(splitk_ws), splitk_ws.numel()
     _check(lib().pd_igemm(C.byref(a), stream_ptr()), "pd_igemm")
@@ -208,6 +210,11 @@ def groupnorm_silu(x, gamma, beta, partials, out, out_lo, B, S, Cn, G, ld_out, e
     _check(lib().pd_groupnorm_silu(ptr(x), ptr(gamma), ptr(beta), ptr(ss_scale), ptr(ss_shift), ld_ss, ptr(partials),
                                    ptr(out), ptr(out_lo), B, S, Cn, G, ld_out, eps, 1 if silu else 0, stream_ptr()),
            "pd_groupnorm_silu")
+
+
+def groupnorm_silu_fp8(x, gamma, beta, partials, out, B, S, Cn, G, eps, fp8_scale, silu=True, ss_scale=None, ss_shift=None, ld_ss=0):
+    _check(lib().pd_groupnorm_silu_fp8(ptr(x), ptr(gamma), ptr(beta), ptr(ss_scale), ptr(ss_shift), ld_ss, ptr(partials), ptr(out),
+                                       B, S, Cn, G, eps, 1 if silu else 0, fp8_scale, stream_ptr()), "pd_groupnorm_silu_fp8")
 
 
 def groupnorm_silu_bwd(x, dy, gamma, beta, fwd_partials, bwd_partials, dx, B, S, Cn, G, eps=1e-5, silu=True):

@@ -291,9 +291,14 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(a.taps == a.KT * a.KH * a.KW, "pd_igemm: taps != KT*KH*KW");
   PD_CHECK_ARG((int64_t)a.B * a.To * a.Ho * a.Wo == a.M, "pd_igemm: M != B*To*Ho*Wo");
   PD_CHECK_ARG((a.ut == 1 || a.ut == 2) && (a.uh == 1 || a.uh == 2) && (a.uw == 1 || a.uw == 2), "pd_igemm: bad upsample");
+  if (a.fp8) {
+    PD_CHECK_ARG((a.Cin & 127) == 0 && (a.lda & 15) == 0 && (a.ldw & 15) == 0, "pd_igemm: fp8 operands need Cin %% 128 == 0 and lda/ldw %% 16 == 0");
+    PD_CHECK_ARG(!a.split && a.nbatch <= 1, "pd_igemm: fp8 operands: no hi/lo split, no batch");
+  }
   {
-    const int64_t abytes = (int64_t)a.B * a.Ti * a.Hi * a.Wi * (int64_t)a.lda * 2;
-    const int64_t wbytes = ((int64_t)(a.taps - 1) * a.w_tap_stride + (int64_t)a.N * a.ldw) * 2;
+    const int eb = a.fp8 ? 1 : 2;
+    const int64_t abytes = (int64_t)a.B * a.Ti * a.Hi * a.Wi * (int64_t)a.lda * eb;
+    const int64_t wbytes = ((int64_t)(a.taps - 1) * a.w_tap_stride + (int64_t)a.N * a.ldw) * eb;
     PD_CHECK_ARG(abytes < 0xfffffe00ll && wbytes < 0xfffffe00ll, "pd_igemm: operand larger than a 4 GiB buffer descriptor");
     a.a_bytes = (uint32_t)abytes;
     a.w_bytes = (uint32_t)wbytes;
@@ -316,6 +321,13 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
                          a.uh == 1 && a.uw == 1 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && a.vT <= 0 && a.vH <= 0 && a.vW <= 0;
   const int kind = pointwise ? 0 : ((a.KT == 1 && a.Ti == 1 && a.To == 1) ? 1 : 2);
   a.ksplit = 1;
+  if (a.fp8) {
+    if (!pd_igemm256_supported(a, kind) || kind == 1) {
+      pd_set_error("pd_igemm: fp8 operands are built for row-wise linear layers and stride-1, un-upsampled Conv3d launches only");
+      return PD_ERR_UNSUPPORTED;
+    }
+    return pd_igemm256_launch(a, kind, s);
+  }
   if (tile == 0 && !pd_igemm_disable_256) {
     // small grids (few trajectories per launch) with a long K loop: 256 x 256 tiles x K-slices fill the CUs (igemm256.hip)
     const int ks = pd_igemm256_ksplit(a, kind);

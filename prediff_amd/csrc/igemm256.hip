@@ -44,7 +44,37 @@
   __builtin_amdgcn_s_barrier();        \
   __builtin_amdgcn_sched_barrier(0)
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
 namespace {
+// one lane's operand fragments of a 16-row tile for a whole K-tile: two 16 B LDS slots, (0*4 + lg) ^ swz and (1*4 + lg) ^ swz.
+// bf16: the operands of the two k-steps; fp8: together the 32 B operand of one scaled MFMA (loaded straight into the halves of an
+// 8-register tuple so that no copies are needed)
+template <bool F8>
+struct Frag256 {
+  bf16x8 v[2];
+  __device__ __forceinline__ void load(const char* base, int lg, int swz) {
+    v[0] = *(const bf16x8*)(base + ((lg ^ swz) * 16));
+    v[1] = *(const bf16x8*)(base + (((4 + lg) ^ swz) * 16));
+  }
+};
+template <>
+struct Frag256<true> {
+  i32x8 v;
+  __device__ __forceinline__ void load(const char* base, int lg, int swz) {
+    const i32x4v l = *(const i32x4v*)(base + ((lg ^ swz) * 16)), h = *(const i32x4v*)(base + (((4 + lg) ^ swz) * 16));
+    v = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+};
+__device__ __forceinline__ f32x4 mfma_f8(const Frag256<true>& a, const Frag256<true>& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a.v, b.v, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);   // e4m3 x e4m3, block scales 2^0
+}
+__device__ __forceinline__ f32x4 mfma_f8(const Frag256<false>&, const Frag256<false>&, f32x4 c) { return c; }
+__device__ __forceinline__ f32x4 mfma_bf16(const Frag256<false>& a, const Frag256<false>& b, int ks, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[ks], b.v[ks], c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const Frag256<true>&, const Frag256<true>&, int, f32x4 c) { return c; }
 constexpr int HT = 128 * 128;   // bytes of one half tile: 128 rows x 64 bf16
 constexpr int KBUF = 4 * HT;    // one K-tile buffer: A half 0, A half 1, W half 0, W half 1
 
@@ -57,8 +87,15 @@ constexpr int KBUF = 4 * HT;    // one K-tile buffer: A half 0, A half 1, W half
 // SK: split-K launch (small grids).  blockIdx.y = K-slice; the slice's K-tiles [kt0, kt1) run through the unchanged main loop and
 // the raw fp32 accumulators go to slab `slice` of p.splitk_ws ([ksplit][M][N]); igemm_splitk_reduce_kernel sums the slabs in slice
 // order (deterministic) and applies the epilogue.
-template <int KIND, int RT, bool SK = false>
+// F8: OCP e4m3 operands (one byte per element).  A K-tile is still 128 B of every row -- 128 elements instead of 64 -- so the
+// staging, swizzle, DMA schedule and LDS fragment reads are byte for byte those of the bf16 kernel; the two 16 B fragments a lane
+// reads per 16 x 16 tile become the 32 B operand of ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit E8M0 block scales; the tensor
+// scales ride in p.alpha) where bf16 issues two 16x16x32 MFMAs: the same MFMA cycles per K-tile for twice the K.  Both operands
+// use the same (lane, byte) -> k assignment, which is all a dot product needs.
+template <int KIND, int RT, bool SK = false, bool F8 = false>
 __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
+  constexpr uint32_t EB = F8 ? 1u : 2u;           // bytes per operand element
+  constexpr int KSH = F8 ? 7 : 6;                 // log2(elements per 128 B K-tile row)
   constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
   constexpr int ROW1 = BM - 16 * RT;              // first tile row of wave row 1 (128 for RT = 8, 96 for RT = 7)
   constexpr int RA0 = 4, RA1 = RT - 4;            // row tiles of the two A sub-halves
@@ -82,8 +119,8 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   const int n0 = (t % tiles_n) << 8;
   const int bz = blockIdx.z;
 
-  const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)bz * p.a_batch_stride), 0, p.a_bytes, 0x00020000);
-  const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)bz * p.w_batch_stride), 0, p.w_bytes, 0x00020000);
+  const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (int64_t)bz * p.a_batch_stride * EB), 0, p.a_bytes, 0x00020000);
+  const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + (int64_t)bz * p.w_batch_stride * EB), 0, p.w_bytes, 0x00020000);
 
   // ---- staging: one DMA instruction covers 64 rows x 128 B; thread -> (row tid/8, 16 B slot tid%8), swizzled source chunk ----
   const int srow = tid >> 3, spos = tid & 7;
@@ -99,7 +136,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
       const int m = m0 + hh * ROW1 + rloc;
       const bool ok = m < p.M && rloc < 16 * RT && m < m0 + BM;
       if (KIND == 0) {
-        aoff[hh][i] = ok ? ((uint32_t)m * (uint32_t)p.lda + schunk * 8) * 2u : PD_OOB;
+        aoff[hh][i] = ok ? ((uint32_t)m * (uint32_t)p.lda) * EB + schunk * 16 : PD_OOB;
       } else {
         const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
         const int mm = ok ? m : 0;
@@ -117,9 +154,9 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int n = n0 + hh * 128 + i * 64 + srow;
-      woff[hh][i] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldw + schunk * 8) * 2u : PD_OOB;
+      woff[hh][i] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldw) * EB + schunk * 16 : PD_OOB;
     }
-  const int kchunks = p.Cin >> 6;
+  const int kchunks = p.Cin >> KSH;
   const int nk_all = p.taps * kchunks;
   const int kslice = SK ? (int)blockIdx.y : 0;
   const int kt0 = SK ? (int)((int64_t)nk_all * kslice / p.ksplit) : 0;
@@ -135,11 +172,11 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
       const uint32_t c = acoord[hh][i];
       const int vt = (int)(c & 1023u) - p.pt + kt, vh = (int)((c >> 10) & 1023u) - p.ph + kh, vw = (int)((c >> 20) & 1023u) - p.pw + kw;
       const bool ok = !(c >> 31) && (unsigned)vt < (unsigned)p.Ti && (unsigned)vh < (unsigned)p.Hi && (unsigned)vw < (unsigned)p.Wi;
-      aoff[hh][i] = ok ? ((abase[hh][i] + (uint32_t)((vt * p.Hi + vh) * p.Wi + vw)) * (uint32_t)p.lda + schunk * 8) * 2u : PD_OOB;
+      aoff[hh][i] = ok ? ((abase[hh][i] + (uint32_t)((vt * p.Hi + vh) * p.Wi + vw)) * (uint32_t)p.lda) * EB + schunk * 16 : PD_OOB;
     }
   };
   // K-tile counters of the DMA streams (A runs one K-tile ahead of the MFMAs, W two); all wave-uniform scalars
-  const uint32_t w_tap_stride_b = (uint32_t)p.w_tap_stride * 2u;
+  const uint32_t w_tap_stride_b = (uint32_t)p.w_tap_stride * EB;
   int a_tap = SK ? kt0 / kchunks : 0;
   int a_kc = SK ? kt0 - a_tap * kchunks : 0, w_kc = a_kc;
   uint32_t w_tap_b = (uint32_t)a_tap * w_tap_stride_b;     // byte offset of the current W tap
@@ -196,13 +233,19 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
   __builtin_amdgcn_sched_barrier(0);
 
-  bf16x8 a[4][2], b0[2][2], b1[2][2];
+  Frag256<F8> a[4], b0[2], b1[2];
   // one quadrant: NR row tiles x 2 column tiles x K = 64 (two k-steps); consecutive MFMAs hit different accumulators
 #define QUAD16(NR, R0, C0, bfrag)                                                                                         \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                        \
+  if constexpr (F8) {                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < (NR); ++i)                                                                      \
       _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                       \
-        acc[(R0) + i][(C0) + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bfrag[c][ks], acc[(R0) + i][(C0) + c], 0, 0, 0);
+        acc[(R0) + i][(C0) + c] = mfma_f8(a[i], bfrag[c], acc[(R0) + i][(C0) + c]);                                       \
+  } else {                                                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                      \
+      _Pragma("unroll") for (int i = 0; i < (NR); ++i)                                                                    \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                     \
+          acc[(R0) + i][(C0) + c] = mfma_bf16(a[i], bfrag[c], ks, acc[(R0) + i][(C0) + c]);                               \
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const char* sA = smem + cur * KBUF + a_rd;
@@ -211,13 +254,9 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 
     // ---------- phase 0: W column tiles 0-1, A row tiles 0-3; quadrant (A0, W0) ----------
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < 2; ++c) b0[c].load(sB + c * (16 * 128), lg, swz);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) b0[c][ks] = *(const bf16x8*)(sB + c * (16 * 128) + (((ks * 4 + lg) ^ swz) * 16));
-#pragma unroll
-    for (int i = 0; i < RA0; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) a[i][ks] = *(const bf16x8*)(sA + i * (16 * 128) + (((ks * 4 + lg) ^ swz) * 16));
+    for (int i = 0; i < RA0; ++i) a[i].load(sA + i * (16 * 128), lg, swz);
     if (more1) issue_a(0, cur ^ 1);
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
@@ -227,9 +266,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 
     // ---------- phase 1: W column tiles 2-3; quadrant (A0, W1) ----------
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) b1[c][ks] = *(const bf16x8*)(sB + (2 + c) * (16 * 128) + (((ks * 4 + lg) ^ swz) * 16));
+    for (int c = 0; c < 2; ++c) b1[c].load(sB + (2 + c) * (16 * 128), lg, swz);
     if (more1) { issue_a(1, cur ^ 1); next_a(); }
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
@@ -239,9 +276,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 
     // ---------- phase 2: A row tiles 4 .. RT-1; quadrant (A1, W1) ----------
 #pragma unroll
-    for (int i = 0; i < RA1; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) a[i][ks] = *(const bf16x8*)(sA + (RA0 + i) * (16 * 128) + (((ks * 4 + lg) ^ swz) * 16));
+    for (int i = 0; i < RA1; ++i) a[i].load(sA + (RA0 + i) * (16 * 128), lg, swz);
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
     QUAD16(RA1, RA0, 2, b1)
@@ -376,7 +411,7 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind);
 // tiles cover at most half of the CUs, into as many slices as fit one round, each at least 8 K-tiles long, within the workspace.
 int pd_igemm256_ksplit(const pd_igemm_args& a, int kind) {
   extern int pd_igemm_splitk_max_tiles;
-  if (!a.splitk_ws || a.split || (a.N & 3) || (a.nbatch > 1) || !pd_igemm256_supported(a, kind)) return 0;
+  if (!a.splitk_ws || a.split || a.fp8 || (a.N & 3) || (a.nbatch > 1) || !pd_igemm256_supported(a, kind)) return 0;
   const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int nk = a.taps * (a.Cin >> 6);
   if (tiles > pd_igemm_splitk_max_tiles || nk < 32) return 0;
@@ -389,13 +424,13 @@ int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s) {
   return kind == 0 ? launch256_splitk<0>(a, s) : launch256_splitk<2>(a, s);
 }
 
-template <int KIND, int RT>
+template <int KIND, int RT, bool F8 = false>
 static int launch256(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
   constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT, false, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -404,7 +439,7 @@ static int launch256(const pd_igemm_args& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + 255) / 256);
   dim3 grid(tiles, 1, a.nbatch > 0 ? a.nbatch : 1);
-  hipLaunchKernelGGL((igemm256_kernel<KIND, RT>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((igemm256_kernel<KIND, RT, false, F8>), grid, dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -418,5 +453,6 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind) {
 }
 
 int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s) {
+  if (a.fp8) return kind == 0 ? launch256<0, 8, true>(a, s) : launch256<2, 8, true>(a, s);
   return kind == 0 ? launch256<0, 8>(a, s) : launch256<2, 8>(a, s);
 }

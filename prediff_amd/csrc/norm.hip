@@ -296,12 +296,14 @@ __global__ void __launch_bounds__(256) gn_stats_vec_kernel(const float* __restri
   }
 }
 
+// F8: the output is OCP e4m3, value * fp8_scale, saturating (v_cvt_pk_fp8_f32 rounds to nearest even), one byte per channel
+template <bool F8>
 __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ss_scale,
                                                            const float* __restrict__ ss_shift, int ld_ss,
                                                            const double* __restrict__ partials, pd_bf16* __restrict__ out,
                                                            pd_bf16* __restrict__ out_lo, int S, int C, int G, float eps, int silu,
-                                                           int nchunk) {
+                                                           int nchunk, float fp8_scale) {
   __shared__ float smr[2 * 256];
   __shared__ double spart[2 * 256];
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -347,6 +349,7 @@ __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restri
   const float4* xb = (const float4*)(x + ((int64_t)b * S + r0) * C) + cv;
   uint2* ob = (uint2*)(out + ((int64_t)b * S + r0) * C) + cv;
   uint2* obl = out_lo ? (uint2*)(out_lo + ((int64_t)b * S + r0) * C) + cv : nullptr;
+  uint32_t* ob8 = (uint32_t*)((uint8_t*)out + ((int64_t)b * S + r0) * C) + cv;
 #pragma unroll 4
   for (int r = rr; r < r1 - r0; r += RP) {
     const float4 v = xb[(int64_t)r * CV];
@@ -355,7 +358,13 @@ __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restri
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.f + __expf(-y[k]));
     }
-    if (obl) {
+    if (F8) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = fminf(fmaxf(y[k] * fp8_scale, -448.f), 448.f);
+      int w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
+      ob8[(int64_t)r * CV] = (uint32_t)w;
+    } else if (obl) {
       uint16_t hi[4], lo[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) f2bf_split(y[k], hi[k], lo[k]);
@@ -383,8 +392,8 @@ extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float
   if (vec) {
     hipLaunchKernelGGL(gn_stats_vec_kernel, dim3(nchunk, B), dim3(256), 0, s, x, partials, S, C, G);
     PD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_apply_vec_kernel, dim3(nchunk, B), dim3(256), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, partials, out,
-                       out_lo, S, C, G, eps, silu, nchunk);
+    hipLaunchKernelGGL(gn_apply_vec_kernel<false>, dim3(nchunk, B), dim3(256), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, partials,
+                       out, out_lo, S, C, G, eps, silu, nchunk, 1.f);
     PD_CHECK_LAUNCH();
     return PD_OK;
   }
@@ -392,6 +401,31 @@ extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float
   PD_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), 2 * G * sizeof(float), s, x, gamma, beta, ss_scale, ss_shift,
                      ld_ss, partials, out, out_lo, S, C, G, ld_out, eps, silu, nchunk);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+// GroupNorm [-> SiLU] -> e4m3 rows (the operand of an fp8 pd_igemm launch): out[b, s, c] = e4m3(y * fp8_scale), ld_out == C
+extern "C" int pd_groupnorm_silu_fp8(const float* x, const float* gamma, const float* beta, const float* ss_scale,
+                                     const float* ss_shift, int ld_ss, double* partials, uint8_t* out, int B, int S, int C, int G,
+                                     float eps, int silu, float fp8_scale, pd_stream_t stream) {
+  PD_CHECK_ARG(x && gamma && beta && partials && out, "pd_groupnorm_silu_fp8: null pointer");
+  PD_CHECK_ARG(G > 0 && C % G == 0 && fp8_scale > 0.f, "pd_groupnorm_silu_fp8: bad C/G/scale (%d,%d,%g)", C, G, (double)fp8_scale);
+  PD_CHECK_ARG((ss_scale == nullptr) == (ss_shift == nullptr), "pd_groupnorm_silu_fp8: scale/shift must come together");
+  const int nchunk = pd_groupnorm_nchunk(S, C);
+  const int CV = C / 4, cpg = C / G;
+  const bool vec = (C % 4 == 0) && CV <= 256 && (256 % CV == 0) && (cpg % 4 == 0) && G <= 256 &&
+                   (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && ((uintptr_t)out & 3) == 0 &&
+                   (!ss_scale || ((ld_ss % 4 == 0) && (((uintptr_t)ss_scale | (uintptr_t)ss_shift) & 15) == 0));
+  if (!vec) {
+    pd_set_error("pd_groupnorm_silu_fp8: needs C %% 4 == 0, C/4 dividing 256 and 4 | C/G (C = %d, G = %d)", C, G);
+    return PD_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_vec_kernel, dim3(nchunk, B), dim3(256), 0, s, x, partials, S, C, G);
+  PD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_apply_vec_kernel<true>, dim3(nchunk, B), dim3(256), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, partials,
+                     (pd_bf16*)out, (pd_bf16*)nullptr, S, C, G, eps, silu, nchunk, fp8_scale);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }

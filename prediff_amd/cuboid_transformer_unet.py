@@ -26,7 +26,7 @@ from torch import nn
 
 from . import _lib as L
 from .cuboid_geometry import attention_tables, relative_position_bias, relative_position_index
-from .packing import pack_conv, pack_linear, pad64
+from .packing import pack_conv, pack_conv_fp8, pack_linear, pad64
 from .patterns import CuboidSelfAttentionPatterns
 
 
@@ -327,9 +327,13 @@ class CuboidTransformerUNet(nn.Module):
             raise NotImplementedError(f"norm_layer={norm_layer!r}")
         if downsample_type != "patch_merge" or upsample_type != "upsample":
             raise NotImplementedError
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' (throughput) or 'fp32' (hi/lo split, fp32-class accuracy)")
-        self.precision = precision
+        if precision not in ("bf16", "fp32", "fp8"):
+            raise ValueError("precision must be 'bf16' (throughput), 'fp32' (hi/lo split, fp32-class accuracy) or 'fp8' "
+                             "(bf16 engine with e4m3 operands for the 3x3x3 convolutions)")
+        # "fp8": the bf16 engine with the TimeEmbedResBlock convolutions (45 % of the FLOPs, the long-K launches) on OCP e4m3
+        # operands through the scaled K = 128 MFMA; everything else as in "bf16".  Accuracy is report-only (BASELINE config 5).
+        self.fp8_conv = precision == "fp8"
+        self.precision = "bf16" if self.fp8_conv else precision
         self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
         self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 16)
         self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
@@ -491,7 +495,7 @@ class CuboidTransformerUNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ packing
     def _params_key(self, device):
-        return (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (str(device), self.precision, self.fp8_conv) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self, device):
         """fp32 checkpoint tensors -> K-contiguous bf16 (hi[/lo]) operands + fp32 epilogue vectors (once per weight version)."""
@@ -515,6 +519,10 @@ class CuboidTransformerUNet(nn.Module):
         def resblock(name, m: TimeEmbedResBlock):
             norm(name + ".gn1", m.in_layers[0]); conv(name + ".conv1", m.in_layers[2])
             norm(name + ".gn2", m.out_layers[0]); conv(name + ".conv2", m.out_layers[3])
+            if self.fp8_conv:
+                for cn, cm in ((".conv1", m.in_layers[2]), (".conv2", m.out_layers[3])):
+                    if cm.in_channels % 128 == 0 and (cm.in_channels // 4) <= 256 and 256 % (cm.in_channels // 4) == 0:
+                        P[name + cn + ".w8"] = pack_conv_fp8(cm.weight.to(device))      # (e4m3 (27, N, C), scale)
             if m.use_embed:
                 P[name + ".emb.w"], P[name + ".emb.b"] = f32(m.emb_layers[1].weight), f32(m.emb_layers[1].bias)
             if not isinstance(m.skip_connection, nn.Identity):
@@ -593,6 +601,18 @@ class CuboidTransformerUNet(nn.Module):
         return hi, lo
 
     # ------------------------------------------------------------------------------------------------ building blocks
+    FP8_ACT_SCALE = 16.0      # GroupNorm -> SiLU outputs are O(1): x16 keeps |y| < 28 in range and 1e-3 above the subnormals
+
+    def _gn_fp8(self, x, g, beta, B, S, C, G, name, dev, ss=None):
+        """GroupNorm -> SiLU -> e4m3 rows (value * FP8_ACT_SCALE), the A operand of an fp8 convolution launch."""
+        a8 = self._buf(name + ".f8", (B * S, C), torch.float8_e4m3fn, dev)
+        part = self._buf("gn.part", (B * L.groupnorm_nchunk(S, C) * G * 2,), torch.float64, dev)
+        kw = {}
+        if ss is not None:
+            kw = dict(ss_scale=ss, ss_shift=ss[:, C:], ld_ss=2 * C)
+        L.groupnorm_silu_fp8(x, g, beta, part, a8, B, S, C, G, 1e-5, self.FP8_ACT_SCALE, silu=True, **kw)
+        return a8
+
     def _gn(self, x, g, beta, B, S, C, G, name, dev, silu=True, ss=None):
         ld = pad64(C)
         hi, lo = self._bf(name, B * S, ld, dev)
@@ -620,17 +640,30 @@ class CuboidTransformerUNet(nn.Module):
         ws = self._splitk_ws(B, dev)
         Cin, Cout = m.channels, m.out_channels
         geom = L.conv_geom(B, thw, (3, 3, 3))
-        a1, a1lo, ld1 = self._gn(x, P[name + ".gn1.g"], P[name + ".gn1.beta"], B, S, Cin, m.in_groups, "gn.a", dev)
         h = self._buf("res.h", (B * S, Cout), torch.float32, dev)
-        w1, w1lo = P[name + ".conv1.w"]
         ssn = m.use_embed and m.use_scale_shift_norm
-        L.igemm(a1, w1, A_lo=a1lo, W_lo=w1lo, M=B * S, N=Cout, Cin=ld1, taps=27, w_tap_stride=Cout * ld1, geom=geom,
-                bias=P[name + ".conv1.b"], rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h,
-                splitk_ws=ws)
+        ld1 = pad64(Cin)
+        if (name + ".conv1.w8") in P:       # precision="fp8": e4m3 operands, tensor scales folded into alpha
+            a8 = self._gn_fp8(x, P[name + ".gn1.g"], P[name + ".gn1.beta"], B, S, Cin, m.in_groups, "gn.a", dev)
+            w8, sw = P[name + ".conv1.w8"]
+            L.igemm(a8, w8, M=B * S, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, bias=P[name + ".conv1.b"],
+                    rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h,
+                    alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True)
+        else:
+            a1, a1lo, ld1 = self._gn(x, P[name + ".gn1.g"], P[name + ".gn1.beta"], B, S, Cin, m.in_groups, "gn.a", dev)
+            w1, w1lo = P[name + ".conv1.w"]
+            L.igemm(a1, w1, A_lo=a1lo, W_lo=w1lo, M=B * S, N=Cout, Cin=ld1, taps=27, w_tap_stride=Cout * ld1, geom=geom,
+                    bias=P[name + ".conv1.b"], rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h,
+                    splitk_ws=ws)
         ldo = pad64(Cout)
-        a2, a2lo, _ = self._gn(h, P[name + ".gn2.g"], P[name + ".gn2.beta"], B, S, Cout, m.out_groups, "gn.a", dev,
+        fp8_2 = (name + ".conv2.w8") in P
+        if fp8_2:
+            a28 = self._gn_fp8(h, P[name + ".gn2.g"], P[name + ".gn2.beta"], B, S, Cout, m.out_groups, "gn.a", dev,
                                ss=(emb if ssn else None))
-        w2, w2lo = P[name + ".conv2.w"]
+        else:
+            a2, a2lo, _ = self._gn(h, P[name + ".gn2.g"], P[name + ".gn2.beta"], B, S, Cout, m.out_groups, "gn.a", dev,
+                                   ss=(emb if ssn else None))
+            w2, w2lo = P[name + ".conv2.w"]
         if out is None:
             out = x if Cin == Cout else self._buf("res.out", (B * S, Cout), torch.float32, dev)
         if isinstance(m.skip_connection, nn.Identity):
@@ -639,13 +672,18 @@ class CuboidTransformerUNet(nn.Module):
             # 1x1x1 (or 3x3x3 when use_conv) skip on the raw input, written to `out`, then accumulated into by conv2
             xa, xalo = self._bf("skip.a", B * S, ld1, dev)
             L.cast_rows(x, xa, xalo, B, S, 0, S, Cin, Cin, ld1)
-            ws, wslo = P[name + ".skip.w"]
+            wsk, wsklo = P[name + ".skip.w"]
             k = m.skip_connection.kernel_size[0]
-            L.igemm(xa, ws, A_lo=xalo, W_lo=wslo, M=B * S, N=Cout, Cin=ld1, taps=k ** 3, w_tap_stride=Cout * ld1,
+            L.igemm(xa, wsk, A_lo=xalo, W_lo=wsklo, M=B * S, N=Cout, Cin=ld1, taps=k ** 3, w_tap_stride=Cout * ld1,
                     geom=L.conv_geom(B, thw, (k, k, k), pad=(k // 2,) * 3), bias=P[name + ".skip.b"], out_f32=out)
             res = out
-        L.igemm(a2, w2, A_lo=a2lo, W_lo=w2lo, M=B * S, N=Cout, Cin=ldo, taps=27, w_tap_stride=Cout * ldo, geom=geom,
-                bias=P[name + ".conv2.b"], residual=res, out_f32=out, splitk_ws=ws)
+        if fp8_2:
+            w8, sw = P[name + ".conv2.w8"]
+            L.igemm(a28, w8, M=B * S, N=Cout, Cin=Cout, taps=27, w_tap_stride=Cout * Cout, geom=geom, bias=P[name + ".conv2.b"],
+                    residual=res, out_f32=out, alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True)
+        else:
+            L.igemm(a2, w2, A_lo=a2lo, W_lo=w2lo, M=B * S, N=Cout, Cin=ldo, taps=27, w_tap_stride=Cout * ldo, geom=geom,
+                    bias=P[name + ".conv2.b"], residual=res, out_f32=out, splitk_ws=ws)
         return out
 
     def _attention(self, P, name, at: CuboidSelfAttentionLayer, x, B, S, C, tabs, geo, dev):

@@ -239,7 +239,9 @@ def test_fullres_forward():
     finally:
         torch.set_num_threads(nthr)
     t_cpu = time.time() - t0
-    for precision, tol in (("fp32", 1e-4), ("bf16", 2e-2)):
+    # "fp8": e4m3 operands for the 3x3x3 convolutions (3 mantissa bits: report-only accuracy, BASELINE config 5); the bound below only
+    # catches a broken kernel, the number to read is the printed one
+    for precision, tol in (("fp32", 1e-4), ("bf16", 2e-2), ("fp8", 0.25)):
         net = CuboidTransformerUNet(**FULLRES_UNET_CFG, precision=precision)
         net.load_state_dict(sd, strict=True)
         net = net.cuda()
@@ -249,3 +251,24 @@ def test_fullres_forward():
         _report("fullres_forward", precision=precision, rel_l2=e, oracle_cpu_s=round(t_cpu, 1))
         assert out.shape == (1, 12, 48, 48, 64) and e < tol
         del net
+
+
+def test_v1_unet_fp8_conv(golden):
+    """precision="fp8" at the v1 size: GroupNorm -> SiLU -> e4m3 rows -> scaled-MFMA Conv3d for the 34 convolutions of a forward, the
+    rest of the bf16 engine unchanged.  Against the reference golden (fp32 slice) and against the bf16 engine; report-only accuracy."""
+    import _templates as TP
+    g = golden("v1_unet")
+    sd = seeded_state_dict(TP.unet_template(V1_UNET_CFG, "v1_unet_schema.json"), 1234)
+    x, cond, t = seeded_input("v1x", (1, 6, 16, 16, 64), 2).cuda(), seeded_input("v1c", (1, 7, 16, 16, 64), 3).cuda(), torch.tensor([500]).cuda()
+    outs = {}
+    for precision in ("bf16", "fp8"):
+        net = CuboidTransformerUNet(**V1_UNET_CFG, precision=precision)
+        net.load_state_dict(sd, strict=True)
+        outs[precision] = net.cuda()(x, t, cond)
+        e = rel_l2(outs[precision][0, :, ::4, ::4, ::8], g["out_slice"])
+        print(f"[v1 unet {precision}] rel-L2 vs the reference golden (fp32 slice) {e:.3e}")
+        _report("v1_unet_fp8_conv", precision=precision, rel_l2=e)
+    assert torch.isfinite(outs["fp8"]).all()
+    e8 = rel_l2(outs["fp8"], outs["bf16"])
+    print(f"[v1 unet fp8 conv] rel-L2 vs the bf16 engine {e8:.3e}")
+    assert 1e-4 < e8 < 0.25          # different arithmetic (not the bf16 path by accident), same function

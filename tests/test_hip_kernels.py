@@ -568,3 +568,75 @@ def test_igemm_linear_split_k_all_epilogue_operands():
     assert bool(torch.isfinite(ws[:M * N]).all())             # split
     ref = F.gelu(0.5 * (bf(x) @ bf(w).t()) + bias) * mul + res
     assert rel_l2(out, ref) < 3e-6 and rel_l2(outb.float(), ref) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (e4m3) operands, scaled MFMA
+@pytest.mark.parametrize("M,N,K", [(1000, 300, 256), (4096, 512, 2048), (77, 64, 128)])
+def test_igemm_linear_fp8(M, N, K):
+    """pd_igemm with e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales, tensor scales in alpha) against the fp32
+    product of the SAME quantised operands: only the fp32 summation order differs."""
+    from prediff_amd.packing import pack_linear_fp8, to_fp8
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(DEV)     # asymmetric operands
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.arange(N)[:, None] * 1e-3).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    a8, sa = to_fp8(x, 16.0), 16.0
+    w8, sw = pack_linear_fp8(w)
+    out = torch.empty(M, N, device=DEV)
+    L.igemm(a8, w8, M=M, N=N, Cin=K, bias=bias, alpha=1.0 / (sa * sw), out_f32=out, fp8=True)
+    ref = (a8.float() @ w8.float().T) / (sa * sw) + bias
+    assert rel_l2(out, ref) < 3e-5
+    e = rel_l2(out, x @ w.T + bias)
+    print(f"[igemm fp8 linear {M}x{N}x{K}] vs the unquantised fp32 product: rel-L2 {e:.3e}")
+    assert e < 6e-2
+
+
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 5, 8, 8, 128, 64), (1, 13, 16, 16, 256, 256), (2, 3, 6, 6, 5, 32), (1, 13, 8, 8, 512, 512)])
+def test_igemm_conv3d_fp8(B, T, H, W, Cin, Cout):
+    from prediff_amd.packing import pack_conv_fp8, pad128, to_fp8
+    g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
+    x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    emb = torch.randn(B, Cout, generator=g).to(DEV)
+    Cp, M = pad128(Cin), B * T * H * W
+    xp = torch.zeros(M, Cp, device=DEV)
+    xp[:, :Cin] = x.reshape(M, Cin)
+    sa = 16.0
+    a8 = to_fp8(xp, sa)
+    w8, sw = pack_conv_fp8(w)
+    out = torch.empty(M, Cout, device=DEV)
+    L.igemm(a8, w8, M=M, N=Cout, Cin=Cp, taps=27, w_tap_stride=Cout * Cp, geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias,
+            rowvec=emb, rows_per_sample=T * H * W, alpha=1.0 / (sa * sw), out_f32=out, fp8=True)
+    xq = a8.float()[:, :Cin].reshape(B, T, H, W, Cin) / sa
+    wq = w8.float()[:, :, :Cin].permute(1, 2, 0).reshape(Cout, Cin, 3, 3, 3) / sw
+    ref = F.conv3d(xq.permute(0, 4, 1, 2, 3), wq, bias, padding=1) + emb[:, :, None, None, None]
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(M, Cout)
+    assert rel_l2(out, ref) < 3e-5
+    full = (F.conv3d(x.permute(0, 4, 1, 2, 3), w, bias, padding=1) + emb[:, :, None, None, None]).permute(0, 2, 3, 4, 1).reshape(M, Cout)
+    e = rel_l2(out, full)
+    print(f"[igemm fp8 conv3d {Cin}->{Cout}] vs the unquantised fp32 convolution: rel-L2 {e:.3e}")
+    assert e < 6e-2
+
+
+@pytest.mark.parametrize("B,S,C,G,ss", [(2, 3328, 256, 32, False), (3, 832, 512, 32, True), (1, 100, 128, 32, False)])
+def test_groupnorm_silu_fp8(B, S, C, G, ss):
+    """GroupNorm -> SiLU with an e4m3 output (value * scale, RNE, saturating) against torch's cast of the fp32 statement."""
+    g = torch.Generator(device="cpu").manual_seed(B + S + C)
+    x = (torch.randn(B, S, C, generator=g) * 2 + 0.5).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+    emb = (0.3 * torch.randn(B, 2 * C, generator=g)).to(DEV) if ss else None
+    part = torch.empty(B * L.groupnorm_nchunk(S, C) * G * 2, dtype=torch.float64, device=DEV)
+    out = torch.empty(B * S, C, dtype=torch.float8_e4m3fn, device=DEV)
+    kw = dict(ss_scale=emb, ss_shift=emb[:, C:], ld_ss=2 * C) if ss else {}
+    L.groupnorm_silu_fp8(x, gamma, beta, part, out, B, S, C, G, 1e-5, 16.0, silu=True, **kw)
+    y = F.group_norm(x.permute(0, 2, 1), G, gamma, beta, 1e-5).permute(0, 2, 1)
+    if ss:
+        y = y * (1 + emb[:, None, :C]) + emb[:, None, C:]
+    y = F.silu(y).reshape(B * S, C)
+    ref = (y * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    same = float((out.view(torch.uint8) == ref.view(torch.uint8)).float().mean())
+    err = rel_l2(out.float(), ref.float())
+    print(f"[gn silu fp8 C={C}] identical bytes {same:.4f}, rel-L2 of the dequantised values {err:.2e}")
+    assert same > 0.99 and err < 1e-2
+    assert rel_l2(out.float() / 16.0, y) < 4e-2          # e4m3: 3 mantissa bits
