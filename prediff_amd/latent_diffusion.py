@@ -135,6 +135,7 @@ class LatentDiffusion(_module_base()):
         # workspace.  Trajectories are independent, so the sub-batches fill each other's idle CUs (tile-count quantisation, HBM-bound
         # phases of the fused kernels): +12...20 % throughput at 32-64 trajectories.  Results are identical to num_streams = 1.
         self.num_streams = 2
+        self.aligned_lanes = 1        # knowledge-aligned loop: denoiser lanes next to the guidance stream (see p_sample_loop)
         self._lane_streams: Dict = {}
 
     # ------------------------------------------------------------------------------------------------ schedule
@@ -472,8 +473,12 @@ class LatentDiffusion(_module_base()):
         # concurrently with the denoiser graphs of the lanes; the step epilogue joins them.  Same arithmetic as the eager path.
         eps_lanes = None
         if use_alignment and self.use_hip_graph and self.parameterization == "eps" and img.is_cuda and isinstance(cond, torch.Tensor):
+            # one denoiser graph on one side stream: the guidance is the concurrent second stream of work, and splitting the denoiser
+            # into lanes as well only makes the three compete (measured at 32 / 8 trajectories: 33.4 / 11.6 ms per step with one
+            # lane, 34.8 / 13.6 with two, 37.2 / 16.0 with four -- profiles/r02_j_time_alignment*.log).  `aligned_lanes` overrides.
             saved = self.num_streams
-            if B % max(1, int(saved)):
+            self.num_streams = max(1, int(self.aligned_lanes))
+            if B % max(1, self.num_streams):
                 self.num_streams = 1
             eps_lanes = self._lanes("eps", B, cond, device, True) if self.num_streams > 1 else None
             self.num_streams = saved

@@ -44,9 +44,9 @@ def loop(graph, n=6):
 print(f"aligned DDPM loop, ms/step: eager {loop(False):.1f}")
 for ns in (1, 2, 4):
     if B % ns == 0:
-        ldm.num_streams = ns
+        ldm.aligned_lanes = ns
         print(f"aligned DDPM loop, ms/step: denoiser graphs on {ns} lane stream(s) overlapped with the guidance {loop(True):.1f}")
-ldm.num_streams = 2
+ldm.aligned_lanes = 1
 # history of the guidance gradient at 32 trajectories: 24.9 ms all-PyTorch fp32 (MIOpen Conv3d ~70 %; autocast(bf16) was slower, 26.8 ms)
 # -> 15.1 ms with the 3x3x3 convolutions on pd_igemm (_HipConv3d) -> 9.0 ms with the cuboid attention on pd_cuboid_attention(_bwd)
 # -> 7.6 ms with GroupNorm -> SiLU -> Conv3d as one row-layout node (pd_groupnorm_silu(_bwd)); all at fp32-class accuracy

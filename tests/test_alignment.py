@@ -106,7 +106,7 @@ def test_aligned_sampling_on_gpu(golden, precision):
     # path (no graphs, one stream) must give the same latents bit for bit, whatever the number of lanes
     outs = []
     for streams, graph in ((2, True), (1, True), (2, False)):
-        ldm.num_streams, ldm.use_hip_graph = streams, graph
+        ldm.aligned_lanes, ldm.use_hip_graph = streams, graph
         outs.append(ldm.sample(cond={"y": y}, batch_size=B, timesteps=3, use_alignment=True, alignment_kwargs={"avg_x_gt": avg},
                                return_decoded=False, noise_tape=torch.as_tensor(g["tape"])))
     assert torch.equal(outs[0], lat) and torch.equal(outs[1], lat) and torch.equal(outs[2], lat)

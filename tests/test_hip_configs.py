@@ -204,6 +204,7 @@ def test_v1_aligned_step(golden, precision):
         assert e < tol and cs < tol
     # the looped form (sample(timesteps=2, use_alignment=True): denoiser graphs on the lane streams overlapping the autograd guidance)
     tape = [zt] + [seeded_input(f"v1an{tt}", (B, 6, 16, 16, 64), 14).cuda() for tt in (99, 0)]
+    ldm.aligned_lanes = 2
     a = ldm.sample(cond=zc, batch_size=B, timesteps=2, use_alignment=True, alignment_kwargs={"avg_x_gt": avg}, return_decoded=False,
                    noise_tape=tape)
     ldm.use_hip_graph = False
