@@ -17,7 +17,13 @@ from oracle import diffusion as OD
 from oracle import unet as OU
 from oracle import vae as OV
 
-torch.set_grad_enabled(False)
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    """the oracle runs without autograd -- per test, not process-wide (other modules of the same pytest process take gradients)"""
+    with torch.no_grad():
+        yield
 
 
 def rel_l2(a, b):
