@@ -300,7 +300,7 @@ def main():
         achieved = flops_per_launch / ker_s / 1e12
         traffic = None
         tp = os.path.join(ROOT, "profiles", "conv3d_hbm_traffic.json")
-        if os.path.exists(tp) and args.config == "v1":
+        if os.path.exists(tp) and args.config == "v1" and args.precision == "bf16":
             try:
                 traffic = json.load(open(tp)).get(f"B{Bl}")
             except Exception:
