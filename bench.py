@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--no-fused-ffn", action="store_true")
     ap.add_argument("--no-fused-attn", action="store_true")
     ap.add_argument("--igemm-debug", type=int, default=0, help="A/B: OR-ed into every pd_igemm launch's debug_flags")
+    ap.add_argument("--min-k-256", type=int, default=-1, help="A/B: shortest K (taps * Cin) the auto tile choice gives to the 256x256 kernel")
     ap.add_argument("--splitk-max-tiles", type=int, default=-1, help="A/B: split-K Conv3d only for launches of at most this many 256x256 tiles (0 = off)")
     ap.add_argument("--no-tile256", action="store_true", help="A/B: keep pd_igemm on the 128x128 kernel for the long-K launches")
     args = ap.parse_args()
@@ -185,6 +186,9 @@ def main():
     if args.igemm_debug:
         import ctypes
         ctypes.c_int.in_dll(L.lib(), "pd_igemm_debug_or").value = args.igemm_debug
+    if args.min_k_256 >= 0:
+        import ctypes
+        ctypes.c_int.in_dll(L.lib(), "pd_igemm_256_min_k").value = args.min_k_256
     if args.splitk_max_tiles >= 0:
         import ctypes
         ctypes.c_int.in_dll(L.lib(), "pd_igemm_splitk_max_tiles").value = args.splitk_max_tiles

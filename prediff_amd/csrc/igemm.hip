@@ -276,6 +276,7 @@ int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s);
 extern "C" int pd_igemm_default_tile = 0;   // bench / tuning override of the auto choice (0 = built-in heuristic)
 extern "C" int pd_igemm_debug_or = 0;       // bench A/B switch: OR-ed into every launch's debug_flags
 extern "C" int pd_igemm_disable_256 = 0;    // bench A/B switch: keep the auto choice away from the 256 x 256 kernel
+extern "C" int pd_igemm_256_min_k = 1024;   // shortest K (taps * Cin) the auto choice gives to the 256 x 256 kernel (bench A/B switch: 512 wins 25 % on stand-alone full-resolution level-1 launches and nothing end to end, two lanes running)
 extern "C" int pd_igemm_splitk_max_tiles = 128;   // split-K only for launches of at most this many 256 x 256 tiles (0 disables it)
 int pd_igemm256_ksplit(const pd_igemm_args& a, int kind);
 int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s);
@@ -344,7 +345,7 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     // long K: the 256 x 256 eight-wave kernel does a round of 256 tiles (one per CU of the MI355X) in ~1.65x the time the
     // 128 x 128 kernel needs for a round of 512 (two per CU) inside the sampling loop -- twice the work; take it when its whole
     // rounds are the cheaper ones (Conv3d at 32 trajectories: 317 us in 2 rounds against 385 us in 4)
-    if (tile == PD_BIG_TILE_DEFAULT && !pd_igemm_disable_256 && !a.split && (int64_t)a.taps * a.Cin >= 1024 && pd_igemm256_supported(a, kind)) {
+    if (tile == PD_BIG_TILE_DEFAULT && !pd_igemm_disable_256 && !a.split && (int64_t)a.taps * a.Cin >= pd_igemm_256_min_k && pd_igemm256_supported(a, kind)) {
       const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.nbatch > 0 ? a.nbatch : 1);
       const int64_t r128 = (t128 + 511) / 512, r256 = (t256 + 255) / 256;
       if (r256 * 33 <= r128 * 20) tile = 7;

@@ -39,9 +39,11 @@ def linear(M, N, K):
     a8 = to_fp8(x, 16.0); w8, sw = pack_linear_fp8(w)
     out = torch.empty(M, N, device=dev)
     t16 = timed(lambda: L.igemm(a16, w16, M=M, N=N, Cin=K, out_f32=out, tile=7))
+    tauto = timed(lambda: L.igemm(a16, w16, M=M, N=N, Cin=K, out_f32=out))
     t8 = timed(lambda: L.igemm(a8, w8, M=M, N=N, Cin=K, out_f32=out, alpha=1 / (16 * sw), fp8=True))
     gf = 2.0 * M * N * K / 1e9
-    print(f"linear {M}x{N}x{K}: bf16 {t16:8.1f} us ({gf / t16:6.3f} PF/s)   fp8 {t8:8.1f} us ({gf / t8:6.3f} PF/s)   x{t16 / t8:.2f}", flush=True)
+    print(f"linear {M}x{N}x{K}: bf16 256-tile {t16:8.1f} us ({gf / t16:6.3f} PF/s), auto tile {tauto:8.1f} us   fp8 {t8:8.1f} us ({gf / t8:6.3f} PF/s)   "
+          f"x{min(t16, tauto) / t8:.2f} vs the better bf16", flush=True)
 
 
 conv(32, 13, 16, 16, 256, 256)     # v1 level 0 at 32 trajectories
@@ -51,3 +53,10 @@ conv(4, 25, 24, 24, 512, 512)      # full resolution level 1
 linear(8192, 8192, 8192)
 linear(106496, 512, 2048)
 linear(106496, 768, 256)
+
+print("level-1 linears, v1 at 32 trajectories (M = 26624) and full resolution at 4 (M = 57600); level-0 full resolution (M = 230400)")
+for M in (26624, 57600):
+    for N, K in ((1536, 512), (512, 512), (2048, 512), (512, 2048)):
+        linear(M, N, K)
+linear(230400, 768, 256)
+linear(230400, 256, 256)
