@@ -110,7 +110,7 @@ def test_v1_ddim50_vs_oracle():
     t_cpu = time.time() - t0
     ref = traj[-1]
     errs = {}
-    for precision in ("fp32", "bf16"):
+    for precision in ("fp32", "bf16", "fp8"):
         ldm = _v1_ldm(precision)
         out, inter = ldm.sample(cond=zc.cuda(), batch_size=B, sampler="ddim", ddim_steps=50, eta=0.0, x_T=xT.cuda(),
                                 return_decoded=False, return_intermediates=True)
@@ -120,11 +120,12 @@ def test_v1_ddim50_vs_oracle():
         out2 = ldm.sample(cond=zc.cuda(), batch_size=B, sampler="ddim", ddim_steps=50, eta=0.0, x_T=xT.cuda(), return_decoded=False)
         assert torch.equal(out2, out)
         del ldm
-    print(f"[v1 DDIM-50] rel-L2 vs oracle loop after 50 steps: fp32 {errs['fp32']:.3e}, bf16 {errs['bf16']:.3e}; "
-          f"by step (1,10,25,40,50): fp32 {errs['fp32_by_step']} bf16 {errs['bf16_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
+    print(f"[v1 DDIM-50] rel-L2 vs oracle loop after 50 steps: fp32 {errs['fp32']:.3e}, bf16 {errs['bf16']:.3e}, fp8 (e4m3 Conv3d) {errs['fp8']:.3e}; "
+          f"by step (1,10,25,40,50): fp32 {errs['fp32_by_step']} bf16 {errs['bf16_by_step']} fp8 {errs['fp8_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
     _report("v1_ddim50", oracle_cpu_s=round(t_cpu, 1), **errs)
     assert errs["fp32"] < 1e-3
     assert errs["bf16"] < 0.25 and np.isfinite(errs["bf16"])
+    assert errs["fp8"] < 0.5 and np.isfinite(errs["fp8"])          # report-only operand type (BASELINE config 5)
 
 
 @pytest.mark.parametrize("kind", ["zeros", "sparse90"])
