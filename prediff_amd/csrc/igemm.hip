@@ -327,6 +327,11 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
       pd_set_error("pd_igemm: fp8 operands are built for row-wise linear layers and stride-1, un-upsampled Conv3d launches only");
       return PD_ERR_UNSUPPORTED;
     }
+    const int ks = (a.tile == 0 && !pd_igemm_disable_256) ? pd_igemm256_ksplit(a, kind) : 0;     // small grids: K-slices as extra workgroups
+    if (ks >= 2) {
+      a.ksplit = ks;
+      return pd_igemm256_launch_splitk(a, kind, s);
+    }
     return pd_igemm256_launch(a, kind, s);
   }
   if (tile == 0 && !pd_igemm_disable_256) {

@@ -387,12 +387,12 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const pd_igemm
   }
 }
 
-template <int KIND>
+template <int KIND, bool F8 = false>
 static int launch256_splitk(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, 8, true, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -400,7 +400,7 @@ static int launch256_splitk(const pd_igemm_args& a, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL((igemm256_kernel<KIND, 8, true>), dim3(tiles, a.ksplit, 1), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((igemm256_kernel<KIND, 8, true, F8>), dim3(tiles, a.ksplit, 1), dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   const int64_t total = (int64_t)a.M * (a.N >> 2);
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
@@ -415,9 +415,9 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind);
 // tiles cover at most half of the CUs, into as many slices as fit one round, each at least 8 K-tiles long, within the workspace.
 int pd_igemm256_ksplit(const pd_igemm_args& a, int kind) {
   extern int pd_igemm_splitk_max_tiles;
-  if (!a.splitk_ws || a.split || a.fp8 || (a.N & 3) || (a.nbatch > 1) || !pd_igemm256_supported(a, kind)) return 0;
+  if (!a.splitk_ws || a.split || (a.N & 3) || (a.nbatch > 1) || !pd_igemm256_supported(a, kind)) return 0;
   const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int nk = a.taps * (a.Cin >> 6);
+  const int nk = a.taps * (a.Cin >> (a.fp8 ? 7 : 6));       // K-tiles of 128 B per row
   if (tiles > pd_igemm_splitk_max_tiles || nk < 32) return 0;
   int64_t ks = std::min<int64_t>(256 / tiles, nk / 8);
   ks = std::min<int64_t>(ks, a.splitk_ws_elems / ((int64_t)a.M * a.N));
@@ -425,6 +425,7 @@ int pd_igemm256_ksplit(const pd_igemm_args& a, int kind) {
 }
 
 int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s) {
+  if (a.fp8) return kind == 0 ? launch256_splitk<0, true>(a, s) : launch256_splitk<2, true>(a, s);
   return kind == 0 ? launch256_splitk<0>(a, s) : launch256_splitk<2>(a, s);
 }
 

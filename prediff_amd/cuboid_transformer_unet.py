@@ -648,7 +648,7 @@ class CuboidTransformerUNet(nn.Module):
             w8, sw = P[name + ".conv1.w8"]
             L.igemm(a8, w8, M=B * S, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, bias=P[name + ".conv1.b"],
                     rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h,
-                    alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True)
+                    alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True, splitk_ws=ws)
         else:
             a1, a1lo, ld1 = self._gn(x, P[name + ".gn1.g"], P[name + ".gn1.beta"], B, S, Cin, m.in_groups, "gn.a", dev)
             w1, w1lo = P[name + ".conv1.w"]
@@ -680,7 +680,7 @@ class CuboidTransformerUNet(nn.Module):
         if fp8_2:
             w8, sw = P[name + ".conv2.w8"]
             L.igemm(a28, w8, M=B * S, N=Cout, Cin=Cout, taps=27, w_tap_stride=Cout * Cout, geom=geom, bias=P[name + ".conv2.b"],
-                    residual=res, out_f32=out, alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True)
+                    residual=res, out_f32=out, alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True, splitk_ws=ws)
         else:
             L.igemm(a2, w2, A_lo=a2lo, W_lo=w2lo, M=B * S, N=Cout, Cin=ldo, taps=27, w_tap_stride=Cout * ldo, geom=geom,
                     bias=P[name + ".conv2.b"], residual=res, out_f32=out, splitk_ws=ws)

@@ -608,6 +608,14 @@ def test_igemm_conv3d_fp8(B, T, H, W, Cin, Cout):
     out = torch.empty(M, Cout, device=DEV)
     L.igemm(a8, w8, M=M, N=Cout, Cin=Cp, taps=27, w_tap_stride=Cout * Cp, geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias,
             rowvec=emb, rows_per_sample=T * H * W, alpha=1.0 / (sa * sw), out_f32=out, fp8=True)
+    # small grids: the same launch with a split-K workspace (K-slices as extra workgroups, slabs summed in slice order)
+    ws = torch.full((8 * 1024 * 1024,), float("nan"), device=DEV)
+    out_sk = torch.full((M, Cout), float("nan"), device=DEV)
+    L.igemm(a8, w8, M=M, N=Cout, Cin=Cp, taps=27, w_tap_stride=Cout * Cp, geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias,
+            rowvec=emb, rows_per_sample=T * H * W, alpha=1.0 / (sa * sw), out_f32=out_sk, fp8=True, splitk_ws=ws)
+    assert rel_l2(out_sk, out) < 3e-6
+    tiles = ((M + 255) // 256) * ((Cout + 255) // 256)
+    assert bool(torch.isfinite(ws[:M * Cout]).all()) == (tiles <= 128 and 27 * Cp // 128 >= 32 and Cout % 4 == 0)
     xq = a8.float()[:, :Cin].reshape(B, T, H, W, Cin) / sa
     wq = w8.float()[:, :, :Cin].permute(1, 2, 0).reshape(Cout, Cin, 3, 3, 3) / sw
     ref = F.conv3d(xq.permute(0, 4, 1, 2, 3), wq, bias, padding=1) + emb[:, :, None, None, None]
