@@ -96,10 +96,15 @@ struct pd_attn_block_args_k {
              // 16 no LN loads, 32 no residual loads, 64 no stores
 };
 
-template <int C>
+// KT = key tiles of 16 per cuboid: a workgroup's 64 rows are 4 / KT whole cuboids of up to 16 KT slots each (KT = 1: the axial
+// cuboids of the SEVIR-LR grid; KT = 2 / 4: cuboid volumes up to 32 / 64, e.g. 25 and 48 on the 48 x 48 full-resolution grid --
+// the slots beyond the volume are empty rows, 22-25 % of the tile there).
+template <int C, int KT = 1, int RPC_ = 16 * KT>
 __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 64, HD = 64, HEADS = C / HD;
+  constexpr int RPC = RPC_, CPW = 64 / RPC, QPC = RPC / 16;   // rows per cuboid (16 KT, or 64 for 3 key tiles: 33-48 slots), cuboids per
+                                                              // workgroup, query tiles per cuboid
   constexpr int KS = C / 64;                       // 64-wide K slabs of the A tile
   constexpr int KH = C / 128;                      // K halves of a head's Wq / Wk / Wv slice: chunks [64 d][128 k]
   constexpr int OH = C / 128;                      // output halves of a head's Wp slice: chunks [128 out][64 k]
@@ -134,6 +139,7 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
 
   const auto rWqkv = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wqkv, 0, p.wqkv_bytes, 0x00020000);
   const auto rWp = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, p.wp_bytes, 0x00020000);
+  const auto rBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, HEADS * p.vol * p.vol * 4, 0x00020000);
 
   // DMA lane mapping: one 512-thread instruction fills one slab = [64 rows][64 k] (8 KB), lane-linear, source-side swizzle.
   // Every chunk is 2 slabs: ONE per-lane offset serves all chunks, the rest is the instruction's scalar offset.
@@ -164,8 +170,8 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
 
   // ---- token table of the 4 cuboids, relative-position bias (padded to 16 x 16 per head) ----
   if (tid < BM) {
-    const int cl = tid >> 4, slot = tid & 15;
-    const int64_t gc = (int64_t)blockIdx.x * 4 + cl;
+    const int cl = tid / RPC, slot = tid % RPC;
+    const int64_t gc = (int64_t)blockIdx.x * CPW + cl;
     int row = -1;
     if (gc < (int64_t)p.B * p.nc && slot < vol) {
       const int b = (int)(gc / p.nc), c = (int)(gc - (int64_t)b * p.nc);
@@ -181,10 +187,11 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
   //      relative-position-bias tables are built while the row loads are in flight ----
   ln_block_to_tile<C, BM, 8>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, (p.dbg & 16) != 0, [&](int r) { return sTok[r]; }, [&]() {
     for (int i = tid; i < 3 * C; i += 512) sBq[i] = p.bqkv ? p.bqkv[i] : 0.f;
-    for (int i = tid; i < HEADS * 256; i += 512) {
-      const int h = i >> 8, q = (i >> 4) & 15, k = i & 15;
-      sBias[i] = (q < vol && k < vol) ? p.bias[((int64_t)h * vol + q) * vol + k] : 0.f;
-    }
+    if (KT == 1)           // (larger cuboids read their bias rows from L2 inside the core: the table would not fit next to a second workgroup)
+      for (int i = tid; i < HEADS * 256; i += 512) {
+        const int h = i >> 8, q = (i >> 4) & 15, k = i & 15;
+        sBias[i] = (q < vol && k < vol) ? p.bias[((int64_t)h * vol + q) * vol + k] : 0.f;
+      }
   });
 
   TRACE();
@@ -226,7 +233,7 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
   const uint32_t w_lane_off = (uint32_t)((tn * 32 + l16) * 128 + ((lg ^ swz16) << 4));
   const uint32_t q_lds = (uint32_t)(uintptr_t)sQ, k_lds = (uint32_t)(uintptr_t)sK, vt_lds = (uint32_t)(uintptr_t)sVT;
   const uint32_t bq_lds = (uint32_t)(uintptr_t)sBq, bias_lds = (uint32_t)(uintptr_t)sBias;
-  const int cub_of_wave = (int)(((int64_t)blockIdx.x * 4 + (wave & 3)) % p.nc);  // cuboid (mask table row) of this wave's core
+  const int cub_of_wave = (int)(((int64_t)blockIdx.x * CPW + (wave & 3) / QPC) % p.nc);  // cuboid (mask table row) of this wave's core
   // end of a weight-chunk step: chunk s+1 has landed (chunk s+2 may stay in flight), everyone is done with chunk s, refill its slot
   auto step_end = [&](int s) {
     if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
@@ -338,11 +345,127 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
           asm volatile("ds_write_b64 %0, %1" ::"v"(vt_lds + (uint32_t)off), "v"(pk) : "memory");
         }
       }
-      step_end(NCH * h + 3 * KH - 1);
+      if constexpr (KT == 1) step_end(NCH * h + 3 * KH - 1);
+    }
+    // larger cuboids: the core waves fetch their bias entries (query qi of the cuboid, keys kt*16 + 4g .. +3) from L2 BEFORE the
+    // next weight chunk is issued, so that the counted vmcnt in front of the core covers them without draining that chunk
+    float bkg[KT > 1 ? KT : 1][4];
+    if constexpr (KT > 1) {
+      const int s = NCH * h + 3 * KH - 1;
+      if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      {
+        // one per-lane offset + immediates; keys beyond the table's end read 0 through the descriptor's bounds check
+        const int qi = ((wave & 3) % QPC) * 16 + l16h;
+        const uint32_t boff = (uint32_t)((((h * vol) + (qi < vol ? qi : 0)) * vol + 4 * lgh) * 4);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            bkg[kt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, boff + (uint32_t)((kt * 16 + r) * 4), 0, 0));
+      }
+      if (s + 3 < NCHUNK && !(p.dbg & 1)) issue_chunk(s + 3);
     }
     TRACE();
+    if constexpr (KT > 1) {
+      // ---------------- attention core, cuboids of up to 16 KT slots: waves w and w + 4 = query tile w of the workgroup's 64 rows;
+      //                  both form the probabilities, each then takes half of the head's 64 output features ----------------
+      if (!(p.dbg & 4)) {
+        const int q = l16h, g = lgh;
+        const int wq = wave & 3, dhalf = wave >> 2;
+        const int row = wq * 16 + q;                      // this lane's query row
+        const int cbase = (wq / QPC) * RPC;               // first row of its cuboid
+        const int qi = (wq % QPC) * 16 + q;               // query index inside the cuboid
+        const int rswz = (row >> 1) & 7;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+          asm volatile("ds_read_b128 %0, %1" : "=v"(qf[st]) : "v"(q_lds + (uint32_t)(row * 128 + (((g + 4 * st) ^ rswz) << 4))));
+        // S^T[key][query] per key tile, turned into this lane's logits in place (query qi, keys kt*16 + 4g .. +3); masked entries are
+        // remembered as bits so that nothing but the 4 KT logits stays live (the core runs inside the kernel's 128-VGPR budget)
+        f32x4 sc4[KT];
+        uint32_t masked = 0;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const int krow = cbase + kt * 16 + q;
+          const int kswz = (krow >> 1) & 7;
+          bf16x8 kf[2];
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(kf[st]) : "v"(k_lds + (uint32_t)(krow * 128 + (((g + 4 * st) ^ kswz) << 4))));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], z, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[1], t, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            float v = -INFINITY;
+            if (key < vol && qi < vol) {
+              v = t[r] * p.scale + bkg[kt][r];
+              if (p.mask && !p.mask[((int64_t)cub_of_wave * vol + qi) * vol + key]) { v = -1e18f; masked |= 1u << (kt * 4 + r); }
+            }
+            sc4[kt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mx = rows4_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = expf(sc4[kt][r] - mx);   // exp(-inf) = 0 for non-existent keys
+            sum += e;
+            sc4[kt][r] = e;
+          }
+        sum = rows4_sum(sum);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        s16x4 pf[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = sc4[kt][r] * inv;
+            if (masked & (1u << (kt * 4 + r))) v = 0.f;       // masked_softmax multiplies by the mask after the softmax
+            pf[kt][r] = (short)f2bf(v);
+          }
+        // O^T[d][query] = sum over the key tiles of V^T (lane: d = 16 i + q, keys of 4-row group cbase/4 + 4 kt + g) x P^T
+        f32x4 o[2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int d = 16 * (2 * dhalf + ii) + q;
+          s16x4 vf[KT];
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+            asm volatile("ds_read_b64 %0, %1" : "=v"(vf[kt]) : "v"(vt_lds + (uint32_t)(d * 128 + ((((cbase >> 2) + 4 * kt + g) ^ (d & 15)) << 3))));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          o[ii] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) o[ii] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[kt], pf[kt], o[ii], 0, 0, 0);
+        }
+        // the waves of a pair read the same Q rows above and overwrite them with O below: everyone is past its Q reads first
+        asm volatile("s_nop 15" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[0][3]), "+v"(o[1][0]), "+v"(o[1][1]), "+v"(o[1][2]), "+v"(o[1][3]));
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int dd = 16 * (2 * dhalf + ii) + 4 * g;
+          const uint64_t pk = (uint64_t)(pack_bf16x2(o[ii][0], o[ii][1])) | ((uint64_t)(pack_bf16x2(o[ii][2], o[ii][3])) << 32);
+          const int off = row * 128 + (((dd >> 3) ^ rswz) << 4) + ((dd & 7) << 1);
+          asm volatile("ds_write_b64 %0, %1" ::"v"(q_lds + (uint32_t)off), "v"(pk) : "memory");
+        }
+      } else {
+        __builtin_amdgcn_s_barrier();     // (ablation flag: keep the barrier count of the core)
+      }
+    }
     // ---------------- attention core: waves 0-3, wave w = cuboid w of this workgroup ----------------
-    if (wave < 4 && !(p.dbg & 4)) {
+    if (KT == 1 && wave < 4 && !(p.dbg & 4)) {
       const int q = l16h, g = lgh;
       const int row = wave * 16 + q;
       const int rswz = (row >> 1) & 7;
@@ -495,7 +618,7 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
 #endif
 }
 
-template <int C>
+template <int C, int KT = 1, int RPC = 16 * KT>
 static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   constexpr int heads = C / 64;
   constexpr int work = 3 * 16384 + 3 * 64 * 64 * 2;                 // weight ring + Q, K, V^T tiles: re-used by the epilogue slab
@@ -505,7 +628,7 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_block_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_block_kernel<C, KT, RPC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_block_fused: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -513,7 +636,8 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
     attr_set = true;
   }
   const int64_t cuboids = (int64_t)a.B * a.nc;
-  hipLaunchKernelGGL((attn_block_kernel<C>), dim3((unsigned)((cuboids + 3) / 4)), dim3(512), lds, s, a);
+  constexpr int CPW = 64 / RPC;
+  hipLaunchKernelGGL((attn_block_kernel<C, KT, RPC>), dim3((unsigned)((cuboids + CPW - 1) / CPW)), dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -522,7 +646,7 @@ extern "C" int pd_attn_block_debug_flags = 0;
 extern "C" unsigned long long* pd_attn_block_trace = nullptr;   // profiling ablations only (scripts/bench_attn_block.py)
 
 extern "C" int pd_attn_block_fused_supported(int C, int heads, int vol) {
-  return (C == 256 || C == 128) && heads * 64 == C && vol >= 1 && vol <= 16;
+  return (C == 256 || C == 128) && heads * 64 == C && vol >= 1 && vol <= 64;
 }
 
 extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
@@ -531,7 +655,7 @@ extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamm
                                    pd_stream_t stream) {
   PD_CHECK_ARG(x && out && gamma && beta && Wqkv && Wp && tok_index && bias, "pd_attn_block_fused: null pointer");
   PD_CHECK_ARG(pd_attn_block_fused_supported(C, heads, vol), "pd_attn_block_fused: unsupported units=%d heads=%d cuboid volume=%d "
-               "(units in {128,256}, head_dim 64, volume <= 16)", C, heads, vol);
+               "(units in {128,256}, head_dim 64, volume <= 64)", C, heads, vol);
   PD_CHECK_ARG(B > 0 && ntok > 0 && nc > 0 && (int64_t)B * ntok < (1ll << 31), "pd_attn_block_fused: bad sizes");
   pd_attn_block_args_k a;
   a.x = x; a.out = out; a.gamma = gamma; a.beta = beta; a.Wqkv = Wqkv; a.bqkv = bqkv; a.Wp = Wp; a.bp = bp;
@@ -542,6 +666,13 @@ extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamm
   a.dbg = pd_attn_block_debug_flags;
   a.trace = pd_attn_block_trace;
   hipStream_t s = (hipStream_t)stream;
-  if (C == 256) return launch_attn_block<256>(a, s);
-  return launch_attn_block<128>(a, s);
+  const int kt = (vol + 15) / 16;     // key tiles of 16 per cuboid; 3 and 4 tiles: one cuboid per 64-row workgroup
+  if (C == 256) {
+    if (kt == 1) return launch_attn_block<256, 1>(a, s);
+    if (kt == 2) return launch_attn_block<256, 2>(a, s);
+    return kt == 3 ? launch_attn_block<256, 3, 64>(a, s) : launch_attn_block<256, 4>(a, s);
+  }
+  if (kt == 1) return launch_attn_block<128, 1>(a, s);
+  if (kt == 2) return launch_attn_block<128, 2>(a, s);
+  return kt == 3 ? launch_attn_block<128, 3, 64>(a, s) : launch_attn_block<128, 4>(a, s);
 }

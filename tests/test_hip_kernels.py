@@ -419,7 +419,12 @@ def test_ffn_fused(M, Cn, act):
 ATTN_BLOCK = [((13, 16, 16), (13, 1, 1), (0, 0, 0), "zeros", 256, 4, 2), ((13, 16, 16), (1, 16, 1), (0, 0, 0), "zeros", 256, 4, 3),
               ((13, 16, 16), (1, 1, 16), (0, 0, 0), "zeros", 256, 4, 1), ((5, 8, 8), (1, 8, 1), (0, 0, 0), "zeros", 128, 2, 3),
               ((3, 5, 6), (3, 1, 1), (0, 0, 0), "zeros", 128, 2, 1), ((5, 7, 6), (1, 4, 4), (0, 2, 2), "ignore", 128, 2, 2),
-              ((5, 7, 6), (1, 4, 4), (0, 2, 2), "zeros", 256, 4, 1)]
+              ((5, 7, 6), (1, 4, 4), (0, 2, 2), "zeros", 256, 4, 1),
+              # cuboid volumes 17 .. 64: 2 / 4 key tiles per cuboid, 2 / 1 cuboids per 64-row workgroup (full-resolution grid: 25, 48)
+              ((25, 12, 12), (25, 1, 1), (0, 0, 0), "zeros", 256, 4, 1), ((5, 48, 6), (1, 48, 1), (0, 0, 0), "zeros", 256, 4, 2),
+              ((4, 6, 48), (1, 1, 48), (0, 0, 0), "zeros", 128, 2, 1), ((4, 8, 8), (2, 4, 4), (1, 2, 2), "zeros", 256, 4, 2),
+              ((6, 9, 10), (2, 4, 8), (0, 2, 4), "ignore", 128, 2, 1), ((5, 7, 6), (2, 3, 3), (1, 1, 1), "ignore", 256, 4, 3),
+              ((3, 5, 17), (1, 1, 17), (0, 0, 0), "zeros", 128, 2, 2)]
 
 
 @pytest.mark.parametrize("shape,cuboid,shift,padding_type,Cn,heads,B", ATTN_BLOCK)
