@@ -197,7 +197,7 @@ int pd_ffn_fused(const float* x, float* out, const float* gamma, const float* be
                  const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, pd_stream_t stream);
 
 /* Fused cuboid self-attention block, bf16 engine:  out = x + proj(attention(qkv(LayerNorm(x))))  for head_dim 64 and cuboid volume
- * <= 16 (CuboidSelfAttentionLayer.forward cuboid_transformer.py:812-966 + the residual of :1151), in place allowed (out == x).
+ * <= 64 (CuboidSelfAttentionLayer.forward cuboid_transformer.py:812-966 + the residual of :1151), in place allowed (out == x).
  * x/out (B, ntok, C) fp32; Wqkv (3C, C) and Wp (C, C) bf16 row-major; bqkv (3C) / bp (C) fp32 or NULL; tok_index, bias, mask
  * as for pd_cuboid_attention.  Supported when pd_attn_block_fused_supported(C, heads, vol); otherwise use
  * pd_layernorm + pd_igemm + pd_cuboid_attention + pd_igemm. */

@@ -1,4 +1,4 @@
-// pd_attn_block_fused: x += proj(cuboid_attention(qkv(LayerNorm(x)))) in ONE kernel for head_dim 64, cuboid volume <= 16
+// pd_attn_block_fused: x += proj(cuboid_attention(qkv(LayerNorm(x)))) in ONE kernel for head_dim 64, cuboid volume <= 64
 // (CuboidSelfAttentionLayer.forward + the residual of StackCuboidSelfAttentionBlock, reference cuboid_transformer.py:812-966,
 // :1151) -- every axial pattern of the SEVIR-LR denoiser at level 0 (units 256, 4 heads).
 //
