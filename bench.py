@@ -43,10 +43,11 @@ CONV3D_GFLOP_PER_STEP = 376.9 + 14.9   # 32 TimeEmbedResBlock convs + first_proj
 WORKLOADS = {
     "v1": dict(unet="V1_UNET_CFG", ldm="V1_LDM_KW", cond=(7, 16, 16, 64), unet_gflop=653.4, conv3d_gflop=376.9 + 14.9, tokens=3328,
                label="SEVIR-LR 7->6 x128x128 (latent 13x16x16, C 256/512, depth [4,4], axial), DDIM-50 eta=0, "
-                     "no knowledge alignment (BASELINE.json configs[1])"),
+                     "no knowledge alignment (BASELINE.json configs[1])", precision="bf16"),
     "fullres": dict(unet="FULLRES_UNET_CFG", ldm="FULLRES_LDM_KW", cond=(13, 48, 48, 64), unet_gflop=11360.0, conv3d_gflop=6920.0, tokens=57600,
                     label="SEVIR full-res 13->12 x384x384 (latent 25x48x48, C 256/512, depth [4,4], axial cuboids 25/48/48), DDIM-50 "
-                          "eta=0, bf16 operands (BASELINE.json configs[4] geometry; its fp8 path is not built)"),
+                          "eta=0 (BASELINE.json configs[4]; fp8 = e4m3 operands for the Conv3d launches, the other GEMMs stay bf16)",
+                    precision="fp8"),
 }
 CONV3D_LAUNCHES_PER_STEP = 34
 CONV3D_KERNEL_LABEL = "igemm256_kernel<2,8> | igemm_kernel<128,128,64,2,false,2,2,1> per launch (Conv3d 3x3x3 implicit GEMM)"
@@ -148,7 +149,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="latent trajectories (ensemble members) per GPU")
     ap.add_argument("--streams", type=int, default=2, help="lanes: the batch advances as this many equal sub-batches on concurrent HIP streams")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32", "fp8"],
+                    help="operand type; default: the one BASELINE.json quotes the workload on (v1: bf16, fullres: fp8)")
     ap.add_argument("--config", default="v1", choices=sorted(WORKLOADS), help="v1 = BASELINE configs[1] (the metric); fullres = configs[4] geometry, bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ensemble", type=int, default=32, help="members of the ONE ensemble timed as the strong-scaling line (BASELINE config 3)")
@@ -179,6 +181,8 @@ def main():
     from prediff_amd import _lib as L
     from prediff_amd.schedule import make_ddim_sampling_parameters, make_ddim_timesteps
     WL = WORKLOADS[args.config]
+    if args.precision is None:
+        args.precision = WL["precision"]
     if args.config == "fullres" and args.batch == 64:
         args.batch = 8            # BASELINE config 5: ensemble 64 over 8 GPUs
     B = args.batch
