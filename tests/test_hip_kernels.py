@@ -478,7 +478,7 @@ def test_attn_block_fused(shape, cuboid, shift, padding_type, Cn, heads, B, qkv_
     assert torch.equal(xin, out)
 
 
-@pytest.mark.parametrize("case", [10, 11, "w"])
+@pytest.mark.parametrize("case", [10, 11, "w", "t25", "h48", "w48", "swin32"])
 def test_attn_block_fused_vs_oracle(golden, case):
     """pd_attn_block_fused directly against the oracle's CuboidSelfAttentionLayer statement (+x) and the reference goldens
     (tests/golden/attn_layer.npz cases 10 / 11 = the v1 level-0 axial-T / axial-H layers; the axial-W layer has no golden and is
@@ -488,8 +488,14 @@ def test_attn_block_fused_vs_oracle(golden, case):
     from _weights import seeded_input, seeded_state_dict
     from oracle import unet as OU
     from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
+    big = {   # cuboid volumes 25 / 48 / 32: the 2-, 3- and 2-key-tile variants (full-resolution axial layers; a shifted 3-D window)
+        "t25": dict(ATTN_CASES[11], shape=(25, 6, 6), cuboid=(25, 1, 1), B=1), "h48": dict(ATTN_CASES[11], shape=(3, 48, 5), cuboid=(1, 48, 1), B=2),
+        "w48": dict(ATTN_CASES[11], shape=(2, 5, 48), cuboid=(1, 1, 48), B=1),
+        "swin32": dict(ATTN_CASES[11], shape=(4, 8, 8), cuboid=(2, 4, 4), shift=(1, 2, 2), B=2)}
     if case == "w":
         c, seed, xname = dict(ATTN_CASES[11], cuboid=(1, 1, 16)), 190, "attnw"
+    elif case in big:
+        c, seed, xname = big[case], 191 + len(case), "attn" + case
     else:
         c, seed, xname = ATTN_CASES[case], 100 + case, f"attn{case}"
     Cn, heads, shape, cuboid = c["dim"], c["heads"], tuple(c["shape"]), tuple(c["cuboid"])
@@ -514,7 +520,7 @@ def test_attn_block_fused_vs_oracle(golden, case):
     print(f"[attn_block_fused case {case}] layer output rel-L2 vs oracle {e:.3e}")
     assert e < 6e-3
     assert rel_l2(out.reshape(x.shape).cpu(), x + y_ref) < 3e-3          # the block's result x + attn(x)
-    if case != "w":
+    if case in (10, 11):
         g = golden("attn_layer")
         assert rel_l2(y[:, :, ::2, ::2, ::4], g[f"y_{case}_slice"]) < 6e-3
         assert abs(float(y.double().abs().sum()) / float(g[f"y_{case}_abs_sum"][0]) - 1) < 6e-3
