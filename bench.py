@@ -308,9 +308,9 @@ def main():
         achieved = flops_per_launch / ker_s / 1e12
         traffic = None
         tp = os.path.join(ROOT, "profiles", "conv3d_hbm_traffic.json")
-        if os.path.exists(tp) and args.config == "v1" and args.precision == "bf16":
+        if os.path.exists(tp) and args.config == "v1" and args.precision in ("bf16", "fp8"):
             try:
-                traffic = json.load(open(tp)).get(f"B{Bl}")
+                traffic = json.load(open(tp)).get(f"B{Bl}" + ("" if args.precision == "bf16" else "_fp8"))
             except Exception:
                 traffic = None
         # --precision fp8: e4m3 operands for the Conv3d launches only (the dominant kernel, priced against the fp8 peak); every other
