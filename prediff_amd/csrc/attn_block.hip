@@ -34,6 +34,12 @@
 // Numerics are those of the un-fused bf16 path (bf16 LN output, bf16 q/k/v/P/O, fp32 accumulation, fp32 softmax).
 #include <algorithm>
 #include "common.h"
+// A/B switch (compile time): 1 runs the cuboid-volume <= 16 kernel through the multi-key-tile core as well (all 8 waves, bias from
+// L2, one more workgroup barrier per head).  Measured at the v1 level-0 shapes, 32 trajectories: 161 / 139 us against 154 / 130 us
+// for the 4-wave core with its LDS bias table (core phase 2.0 k -> 4.0 k clocks per head) -- so the tuned core stays the default.
+#ifndef PD_AB_GENERIC_CORE
+#define PD_AB_GENERIC_CORE 0
+#endif
 #include "ln_tile.h"
 
 #define BLDS16(rsrc, ldsptr, voff, soff) \
@@ -187,7 +193,7 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
   //      relative-position-bias tables are built while the row loads are in flight ----
   ln_block_to_tile<C, BM, 8>(p.x, p.gamma, p.beta, p.eps, sA, wave, lane, (p.dbg & 16) != 0, [&](int r) { return sTok[r]; }, [&]() {
     for (int i = tid; i < 3 * C; i += 512) sBq[i] = p.bqkv ? p.bqkv[i] : 0.f;
-    if (KT == 1)           // (larger cuboids read their bias rows from L2 inside the core: the table would not fit next to a second workgroup)
+    if (KT == 1 && !PD_AB_GENERIC_CORE)           // (larger cuboids read their bias rows from L2 inside the core: the table would not fit next to a second workgroup)
       for (int i = tid; i < HEADS * 256; i += 512) {
         const int h = i >> 8, q = (i >> 4) & 15, k = i & 15;
         sBias[i] = (q < vol && k < vol) ? p.bias[((int64_t)h * vol + q) * vol + k] : 0.f;
@@ -345,12 +351,12 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
           asm volatile("ds_write_b64 %0, %1" ::"v"(vt_lds + (uint32_t)off), "v"(pk) : "memory");
         }
       }
-      if constexpr (KT == 1) step_end(NCH * h + 3 * KH - 1);
+      if constexpr (KT == 1 && !PD_AB_GENERIC_CORE) step_end(NCH * h + 3 * KH - 1);
     }
     // larger cuboids: the core waves fetch their bias entries (query qi of the cuboid, keys kt*16 + 4g .. +3) from L2 BEFORE the
     // next weight chunk is issued, so that the counted vmcnt in front of the core covers them without draining that chunk
     float bkg[KT > 1 ? KT : 1][4];
-    if constexpr (KT > 1) {
+    if constexpr (KT > 1 || PD_AB_GENERIC_CORE) {
       const int s = NCH * h + 3 * KH - 1;
       if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -369,7 +375,7 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
       if (s + 3 < NCHUNK && !(p.dbg & 1)) issue_chunk(s + 3);
     }
     TRACE();
-    if constexpr (KT > 1) {
+    if constexpr (KT > 1 || PD_AB_GENERIC_CORE) {
       // ---------------- attention core, cuboids of up to 16 KT slots: waves w and w + 4 = query tile w of the workgroup's 64 rows;
       //                  both form the probabilities, each then takes half of the head's 64 output features ----------------
       if (!(p.dbg & 4)) {
@@ -465,7 +471,7 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
       }
     }
     // ---------------- attention core: waves 0-3, wave w = cuboid w of this workgroup ----------------
-    if (KT == 1 && wave < 4 && !(p.dbg & 4)) {
+    if (KT == 1 && !PD_AB_GENERIC_CORE && wave < 4 && !(p.dbg & 4)) {
       const int q = l16h, g = lgh;
       const int row = wave * 16 + q;
       const int rswz = (row >> 1) & 7;
