@@ -11,6 +11,9 @@
 //      softmax over keys: every lane owns one query column and 4 key rows -> 4-register + 2-shuffle reduction
 //      O^T = V^T P^T with v_mfma_f32_16x16x16_bf16   (P^T is already in B-operand layout: no LDS, no transpose)
 //    Per work item: 3*vol*hd*2 B in, vol*hd*2 B out, 4*vol^2*hd flop (~8 flop/B): HBM/latency bound by construction.
+//    (Tried in round 2: V rows staged through per-wave LDS with 16 B row loads instead of the 2-byte V^T gathers below -- no faster:
+//     24.7 / 29.4 us against 24.7 / 29.7 us at the v1 level-1 shapes, 10 % slower at head_dim 128 with 2 key tiles; the kernel already
+//     moves 3-4.4 TB/s of q, k, v, o bytes and the gathers hit lines the K loads just brought in.  scripts/bench_attn_core.py.)
 //  * large cuboids (vol > 64, bf16 qkv, hd 32 / 64 / 128): online-softmax MFMA kernel, one wave per 16 queries.
 //  * generic path (vol <= 64, any hd <= 128, bf16 or fp32 qkv): LDS-staged fp32 VALU kernel; used for the fp32-accurate mode and
 //    odd head sizes.
