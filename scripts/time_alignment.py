@@ -48,6 +48,10 @@ for ns in (1, 2, 4):
         ldm.aligned_lanes = ns
         print(f"aligned DDPM loop, ms/step: denoiser graphs on {ns} lane stream(s) overlapped with the guidance {loop(True):.1f}")
 ldm.aligned_lanes = 1
+ldm.guidance_high_priority = True
+print(f"aligned DDPM loop, ms/step: one denoiser lane, guidance on a HIGH-priority stream {loop(True):.1f} (second run {loop(True):.1f})")
+ldm.guidance_high_priority = False
+print(f"aligned DDPM loop, ms/step: one denoiser lane, guidance on the caller's stream (again) {loop(True):.1f}")
 # history of the guidance gradient at 32 trajectories: 24.9 ms all-PyTorch fp32 (MIOpen Conv3d ~70 %; autocast(bf16) was slower, 26.8 ms)
 # -> 15.1 ms with the 3x3x3 convolutions on pd_igemm (_HipConv3d) -> 9.0 ms with the cuboid attention on pd_cuboid_attention(_bwd)
 # -> 7.6 ms with GroupNorm -> SiLU -> Conv3d as one row-layout node (pd_groupnorm_silu(_bwd)); all at fp32-class accuracy
