@@ -61,12 +61,13 @@ class _HipConv3d(torch.autograd.Function):
     def _packs(conv: nn.Conv3d, device):
         from . import _lib as L
         from .packing import pack_conv
-        key = (str(device), conv.weight.data_ptr(), conv.weight._version)
+        split = not getattr(conv, "_hip_bf16", False)       # False: single-pass bf16 operands (SEVIRAvgIntensityAlignment(hip_precision="bf16"))
+        key = (str(device), conv.weight.data_ptr(), conv.weight._version, split)
         cached = getattr(conv, "_hip_packs", None)
         if cached is None or cached[0] != key:
             w = conv.weight.detach().to(device)
-            fwd = pack_conv(w, True)                                              # (27, Cout, Cin_p) hi, lo
-            bwd = pack_conv(w.flip(2, 3, 4).transpose(0, 1).contiguous(), True)   # (27, Cin, Cout_p): dgrad filter
+            fwd = pack_conv(w, split)                                             # (27, Cout, Cin_p) hi, lo (lo = None without the split)
+            bwd = pack_conv(w.flip(2, 3, 4).transpose(0, 1).contiguous(), split)  # (27, Cin, Cout_p): dgrad filter
             bias = conv.bias.detach().float().contiguous().to(device) if conv.bias is not None else None
             cached = (key, fwd, bwd, bias)
             conv._hip_packs = cached
@@ -81,10 +82,10 @@ class _HipConv3d(torch.autograd.Function):
         Cp = pad64(Cn)
         rows = x_ncthw.permute(0, 2, 3, 4, 1).reshape(M, Cn).float().contiguous()
         a_hi = torch.empty((M, Cp), dtype=torch.bfloat16, device=rows.device)
-        a_lo = torch.empty_like(a_hi)
+        a_lo = torch.empty_like(a_hi) if w_lo is not None else None       # the activation is split exactly when the filter is
         out = torch.empty((M, n_out), dtype=torch.float32, device=rows.device)
         with L.on_device(rows):
-            L.cast_rows(rows, a_hi, a_lo, 1, M, 0, M, Cn, Cn, Cp)          # fp32 -> bf16 hi + lo, zero-padded columns, one pass
+            L.cast_rows(rows, a_hi, a_lo, 1, M, 0, M, Cn, Cn, Cp)          # fp32 -> bf16 hi [+ lo], zero-padded columns, one pass
             L.igemm(a_hi, w_hi, A_lo=a_lo, W_lo=w_lo, M=M, N=n_out, Cin=Cp, taps=27, w_tap_stride=n_out * Cp,
                     geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias, out_f32=out)
         return out.reshape(B, T, H, W, n_out).permute(0, 4, 1, 2, 3)
@@ -130,7 +131,7 @@ class _HipGnSiluConv3d(torch.autograd.Function):
         dev = x.device
         part = torch.empty(B * L.groupnorm_nchunk(S, Cn) * G * 2, dtype=torch.float64, device=dev)
         a_hi = torch.empty((M, Cn), dtype=torch.bfloat16, device=dev)
-        a_lo = torch.empty_like(a_hi)
+        a_lo = torch.empty_like(a_hi) if fwd[1] is not None else None
         out = torch.empty((B, T, H, W, N), dtype=torch.float32, device=dev)
         with L.on_device(x):
             L.groupnorm_silu(x, gn.weight, gn.bias, part, a_hi, a_lo, B, S, Cn, G, Cn, gn.eps, silu=True)
@@ -150,7 +151,7 @@ class _HipGnSiluConv3d(torch.autograd.Function):
         d_out = d_out.contiguous()
         dev = x.device
         g_hi = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        g_lo = torch.empty_like(g_hi)
+        g_lo = torch.empty_like(g_hi) if ctx.bwd[1] is not None else None
         da = torch.empty((M, Cn), dtype=torch.float32, device=dev)
         dx = torch.empty_like(x)
         part_b = torch.empty_like(part)
@@ -519,8 +520,13 @@ class SEVIRAvgIntensityAlignment:
     """sevir.py:7-104"""
 
     def __init__(self, alignment_type: str = "avg_x", guide_scale: float = 1.0, model_type: str = "cuboid",
-                 model_args: Dict[str, Any] = None, model_ckpt_path: str = None):
+                 model_args: Dict[str, Any] = None, model_ckpt_path: str = None, hip_precision: str = "fp32"):
+        """`hip_precision` (engine option, not in the reference): operand form of the guidance network's 3x3x3 convolutions on a HIP
+        device -- "fp32": bf16 hi/lo split, fp32-class accuracy (the form the parity of the guided step is pinned with);
+        "bf16": single-pass bf16 operands, the accuracy class of a precision="bf16" / "fp8" denoiser next to it."""
         assert alignment_type in ["avg_x"], f"alignment_type {alignment_type} is not supported"
+        if hip_precision not in ("fp32", "bf16"):
+            raise ValueError("hip_precision must be 'fp32' or 'bf16'")
         self.alignment_type, self.guide_scale = alignment_type, guide_scale
         if model_type != "cuboid":
             raise NotImplementedError(f"model_type={model_type} is not implemented")
@@ -529,6 +535,10 @@ class SEVIRAvgIntensityAlignment:
             self.model.load_state_dict(torch.load(model_ckpt_path, map_location="cpu"))
         self.model.eval()
         self.model.requires_grad_(False)
+        self.hip_precision = hip_precision
+        for mod in self.model.modules():
+            if isinstance(mod, nn.Conv3d):
+                mod._hip_bf16 = hip_precision == "bf16"
 
     @classmethod
     def model_objective(cls, x, y=None, **kwargs):

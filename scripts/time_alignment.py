@@ -9,9 +9,10 @@ from prediff_amd.alignment import SEVIRAvgIntensityAlignment
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 PRECISION = sys.argv[2] if len(sys.argv) > 2 else "bf16"      # denoiser engine: bf16 | fp8 (e4m3 Conv3d operands) | fp32
+GUIDANCE = sys.argv[3] if len(sys.argv) > 3 else "fp32"       # operand form of the guidance network's convolutions: fp32 (hi/lo split) | bf16
 dev = torch.device("cuda")
 ldm = bench.v1_model(PRECISION, dev)
-align = SEVIRAvgIntensityAlignment(guide_scale=50.0, model_args=V1_ALIGN_ARGS)
+align = SEVIRAvgIntensityAlignment(guide_scale=50.0, model_args=V1_ALIGN_ARGS, hip_precision=GUIDANCE)
 align.model.to(dev)
 ldm.set_alignment(align.get_mean_shift)
 zc = torch.randn((B, 7, 16, 16, 64), device=dev)
@@ -27,7 +28,7 @@ def timed(fn, n=5):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
 
-print(f"B={B}, denoiser precision {PRECISION}: denoiser forward (eager) {timed(lambda: ldm.apply_model(zt, t, zc)):.1f} ms; "
+print(f"B={B}, denoiser precision {PRECISION}, guidance convolutions {GUIDANCE}: denoiser forward (eager) {timed(lambda: ldm.apply_model(zt, t, zc)):.1f} ms; "
       f"alignment gradient {timed(lambda: ldm.alignment_fn(zt, t, zc=zc, y=None, **kw)):.1f} ms; "
       f"p_sample(use_alignment=True) {timed(lambda: ldm.p_sample(zt=zt, zc=zc, t=t, use_alignment=True, alignment_kwargs=kw)):.1f} ms; "
       f"p_sample(no alignment, eager) {timed(lambda: ldm.p_sample(zt=zt, zc=zc, t=t)):.1f} ms")

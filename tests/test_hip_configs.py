@@ -181,12 +181,17 @@ def test_v1_ensemble_rccl_world1():
 
 
 # ------------------------------------------------------------------------------------------------ config 4
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16+bf16guidance"])
 def test_v1_aligned_step(golden, precision):
+    """precision "bf16+bf16guidance": the bf16 denoiser with the guidance network's convolutions on single-pass bf16 operands too
+    (SEVIRAvgIntensityAlignment(hip_precision="bf16")); the other two keep the guidance at fp32-class accuracy."""
     from prediff_amd.alignment import SEVIRAvgIntensityAlignment
     g = golden("v1_aligned")
+    guidance_precision = "bf16" if precision.endswith("guidance") else "fp32"
+    precision = precision.split("+")[0]
     ldm = _v1_ldm(precision)
-    al = SEVIRAvgIntensityAlignment(alignment_type="avg_x", guide_scale=50.0, model_type="cuboid", model_args=dict(V1_ALIGN_ARGS))
+    al = SEVIRAvgIntensityAlignment(alignment_type="avg_x", guide_scale=50.0, model_type="cuboid", model_args=dict(V1_ALIGN_ARGS),
+                                    hip_precision=guidance_precision)
     al.model.load_state_dict(seeded_state_dict(al.model.state_dict(), 701))
     al.model.cuda()
     ldm.set_alignment(al.get_mean_shift)
@@ -200,8 +205,8 @@ def test_v1_aligned_step(golden, precision):
         out = ldm.p_sample(zt=zt, zc=zc, t=t, y=None, use_alignment=True, alignment_kwargs={"avg_x_gt": avg}, noise=noise)
         e = rel_l2(out[:, :, ::2, ::2, ::4], g[f"out_{tt}_slice"])
         cs = abs(float(out.double().abs().sum()) / float(g[f"out_{tt}_abs_sum"][0]) - 1)
-        print(f"[v1 aligned {precision} t={tt}] rel-L2 vs reference {e:.3e}, |.|-sum deviation {cs:.2e}")
-        _report("v1_aligned_step", precision=precision, t=tt, rel_l2=e)
+        print(f"[v1 aligned {precision}, guidance convolutions {guidance_precision} t={tt}] rel-L2 vs reference {e:.3e}, |.|-sum deviation {cs:.2e}")
+        _report("v1_aligned_step", precision=precision, guidance=guidance_precision, t=tt, rel_l2=e)
         assert e < tol and cs < tol
     # the looped form (sample(timesteps=2, use_alignment=True): denoiser graphs on the lane streams overlapping the autograd guidance)
     tape = [zt] + [seeded_input(f"v1an{tt}", (B, 6, 16, 16, 64), 14).cuda() for tt in (99, 0)]
