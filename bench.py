@@ -2,6 +2,7 @@
 """Headline benchmark: denoising-steps/sec of the PreDiff sampling hot path on MI355X.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N ...      (outside a launcher: starts N ranks itself, one process per GPU; fewer than N devices = error)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -135,6 +136,28 @@ def cpu_baseline(budget_s=15.0):
             "sample": f"{n} oracle denoiser forwards (fp32, B=1, v1 config, torch CPU, {nthr} of {ncpu} threads) in {el:.1f} s"}
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script, one process per GPU, under torch.distributed.run
+    (RCCL rendezvous on 127.0.0.1) and return its exit status.  Fewer than N visible devices is an error, never a silent 1-GPU run
+    (the reference runs one process per GPU under DDP: scripts/prediff/sevirlr/train_sevirlr_prediff.py:648)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n_gpus and "--launch-check" not in sys.argv:
+        print(f"bench.py: --gpus {n_gpus} asked for, {ndev} HIP device(s) visible: refusing to report a smaller job as n_gpus={n_gpus}",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only form the host driver supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def lanes_for(batch, args):
     """Lanes for a small per-GPU batch: sub-batches of >= 2 trajectories on concurrent streams (measured, profiles/r02_*sweep*)."""
     if args.small_streams:
@@ -153,6 +176,8 @@ def main():
                     help="operand type; default: the one BASELINE.json quotes the workload on (v1: bf16, fullres: fp8)")
     ap.add_argument("--config", default="v1", choices=sorted(WORKLOADS), help="v1 = BASELINE configs[1] (the metric); fullres = configs[4] geometry, bf16")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher self-test without GPUs: every rank joins a gloo group, rank 0 prints the world it sees, nothing is timed")
     ap.add_argument("--ensemble", type=int, default=32, help="members of the ONE ensemble timed as the strong-scaling line (BASELINE config 3)")
     ap.add_argument("--small-streams", type=int, default=0, help="lanes for the small-batch / strong-scaling lines (0 = automatic)")
     ap.add_argument("--no-extra", action="store_true", help="skip the strong-scaling and small-batch lines")
@@ -169,7 +194,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    if args.gpus < 1:
+        sys.exit(f"bench.py: --gpus {args.gpus} is not a GPU count")
+    if args.gpus != world:
+        if "RANK" in os.environ or "LOCAL_RANK" in os.environ:
+            # launched by torch.distributed.run with a different process count than asked for: refuse instead of mis-reporting n_gpus
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (--nproc-per-node {args.gpus})")
+        sys.exit(self_launch(args.gpus))
+    if args.launch_check:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        seen = torch.ones(1)
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(seen.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device is visible (there is no CPU path)")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} wants device {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

@@ -169,6 +169,8 @@ USE_HIP_RESBLOCK = True   # the guidance network's GroupNorm -> SiLU -> Conv3d p
 def _hip_resblock_ok(m, x):
     if not (USE_HIP_RESBLOCK and USE_HIP_CONV and x.is_cuda and x.dtype == torch.float32 and not m.use_scale_shift_norm):
         return False
+    if m.training:           # the fused node has no Dropout (out_layers[2]): a network left in train mode keeps the torch path
+        return False
     for gn, conv in ((m.in_layers[0], m.in_layers[2]), (m.out_layers[0], m.out_layers[3])):
         Cn = conv.in_channels
         if not (conv.kernel_size == (3, 3, 3) and conv.stride == (1, 1, 1) and conv.padding == (1, 1, 1) and conv.dilation == (1, 1, 1)
@@ -265,8 +267,12 @@ USE_HIP_ATTN = True    # the guidance network's cuboid attention (forward + data
 
 
 def _hip_attention_ok(at, x, vol):
-    return (USE_HIP_ATTN and x.is_cuda and x.dtype == torch.float32 and at.qkv.bias is None and vol <= 64
-            and x.shape[-1] // at.num_heads <= 128)
+    hd = x.shape[-1] // at.num_heads
+    # pd_cuboid_attention_bwd keeps q, k, dO, v and two vol x vol tiles in dynamic LDS (csrc/attention.hip): mirror its bound so that a
+    # geometry it refuses (volume 64 with head_dim 128) takes the torch path instead of raising inside the guidance gradient
+    lds_bwd = 4 * (2 * vol * hd + 2 * vol * (hd + 1) + 2 * vol * (vol + 1))
+    return (USE_HIP_ATTN and x.is_cuda and x.dtype == torch.float32 and at.qkv.bias is None and vol <= 64 and hd <= 128
+            and lds_bwd <= 160 * 1024 - 512 and not at.training)
 
 
 def attention_forward(at: CuboidSelfAttentionLayer, x, tables):

@@ -366,7 +366,8 @@ extern "C" int pd_cuboid_attention(const pd_cuboid_attn_args* pa, pd_stream_t st
     return PD_ERR_UNSUPPORTED;
   }
   const size_t lds = sizeof(float) * ((size_t)a.vol * hd * 2 + (size_t)a.vol * (hd + 1) + (size_t)a.vol * (a.vol + 1));
-  static bool attr_set = false;
+  static bool attr_set_dev[PD_MAX_DEVICES];
+  bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)cuboid_attn_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     (void)hipFuncSetAttribute((const void*)cuboid_attn_generic_kernel<pd_bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
@@ -477,7 +478,12 @@ extern "C" int pd_cuboid_attention_bwd(const float* qkv, const float* d_out, con
   }
   if (B == 0) return PD_OK;
   const size_t lds = sizeof(float) * ((size_t)vol * hd * 2 + (size_t)vol * (hd + 1) * 2 + (size_t)vol * (vol + 1) * 2);
-  static bool attr_set = false;
+  if (lds > 160 * 1024 - 512) {     // e.g. volume 64 with head_dim 128: 164,864 B
+    pd_set_error("pd_cuboid_attention_bwd: volume %d x head_dim %d needs %zu B of LDS (max %d)", vol, hd, lds, 160 * 1024 - 512);
+    return PD_ERR_UNSUPPORTED;
+  }
+  static bool attr_set_dev[PD_MAX_DEVICES];
+  bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)cuboid_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     attr_set = true;

@@ -632,7 +632,8 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   constexpr int epi = 8 * 32 * ((C / 128) * 32) * 4;
   static_assert(epi <= work, "the epilogue slab must not reach the bias / token tables");
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-  static bool attr_set = false;
+  static bool attr_set_dev[PD_MAX_DEVICES];
+  bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_block_kernel<C, KT, RPC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {

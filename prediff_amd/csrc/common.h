@@ -20,6 +20,15 @@ extern "C" void pd_set_error(const char* fmt, ...);
     }                                                 \
   } while (0)
 
+// hipFuncSetAttribute is per device: one process may drive modules on several GPUs, so the "already raised the dynamic-LDS limit"
+// flags of the launch helpers are kept per device (indexed by the current device of the calling thread).
+#define PD_MAX_DEVICES 64
+static inline int pd_cur_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= PD_MAX_DEVICES) d = 0;
+  return d;
+}
+
 #define PD_CHECK_LAUNCH()                                                 \
   do {                                                                    \
     hipError_t e__ = hipGetLastError();                                   \

@@ -470,7 +470,8 @@ __global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
 template <int ACT>
 static int launch_ffn64(const pd_ffn_args_k& a, hipStream_t s) {
   const int bytes = 2 * 32768 + 64 * 64 * 2 + a.Hd * 4;          // two weight slots (the epilogue slab re-uses them) + H tile + b1
-  static int attr_set = 0;
+  static int attr_set_dev[PD_MAX_DEVICES];
+  int& attr_set = attr_set_dev[pd_cur_device()];
   if (attr_set < bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)ffn64_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
@@ -489,7 +490,8 @@ static int launch_ffn(const pd_ffn_args_k& a, hipStream_t s) {
   const int lds = 128 * C * 2 + 128 * 64 * 2 + 64 * C * 2 + C * 64 * 2 + a.Hd * 4;
   constexpr int epi = 8 * 32 * (C / 2) * 4;
   const int bytes = lds > epi ? lds : epi;
-  static int attr_set = 0;
+  static int attr_set_dev[PD_MAX_DEVICES];
+  int& attr_set = attr_set_dev[pd_cur_device()];
   if (attr_set < bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<C, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {

@@ -235,7 +235,8 @@ static int launch_igemm(const pd_igemm_args& a, hipStream_t s) {
   constexpr int stage = (BM + BN) * BK * 2 * (SPLIT ? 2 : 1);
   constexpr int epi = 4 * (BM / 2) * (BN / 2) * 4 / ESLAB;
   constexpr int lds = NS * stage > epi ? NS * stage : epi;   // the accumulator slab of the epilogue re-uses the operand ring
-  static bool attr_set = false;
+  static bool attr_set_dev[PD_MAX_DEVICES];
+  bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, NS, SPLIT, KIND, OCC, ESLAB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);

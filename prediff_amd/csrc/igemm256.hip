@@ -390,7 +390,8 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const pd_igemm
 template <int KIND, bool F8 = false>
 static int launch256_splitk(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
-  static bool attr_set = false;
+  static bool attr_set_dev[PD_MAX_DEVICES];
+  bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, 8, true, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
@@ -433,7 +434,8 @@ template <int KIND, int RT, bool F8 = false>
 static int launch256(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
   constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
-  static bool attr_set = false;
+  static bool attr_set_dev[PD_MAX_DEVICES];
+  bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT, false, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {

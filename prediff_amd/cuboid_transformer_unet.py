@@ -520,8 +520,12 @@ class CuboidTransformerUNet(nn.Module):
             norm(name + ".gn1", m.in_layers[0]); conv(name + ".conv1", m.in_layers[2])
             norm(name + ".gn2", m.out_layers[0]); conv(name + ".conv2", m.out_layers[3])
             if self.fp8_conv:
-                for cn, cm in ((".conv1", m.in_layers[2]), (".conv2", m.out_layers[3])):
-                    if cm.in_channels % 128 == 0 and (cm.in_channels // 4) <= 256 and 256 % (cm.in_channels // 4) == 0:
+                # the library's conditions, mirrored so that a layer it would refuse keeps bf16 operands instead of raising at forward time:
+                # pd_groupnorm_silu_fp8 (vector path: (C/G) % 4 == 0, G <= 256, C/4 | 256) and pd_igemm fp8 (256-tile kernel: C % 128 == 0)
+                for cn, cm, G in ((".conv1", m.in_layers[2], m.in_groups), (".conv2", m.out_layers[3], m.out_groups)):
+                    Cc = cm.in_channels
+                    if (Cc % 128 == 0 and (Cc // 4) <= 256 and 256 % (Cc // 4) == 0 and Cc % G == 0 and (Cc // G) % 4 == 0 and G <= 256
+                            and cm.out_channels % 64 == 0):
                         P[name + cn + ".w8"] = pack_conv_fp8(cm.weight.to(device))      # (e4m3 (27, N, C), scale)
             if m.use_embed:
                 P[name + ".emb.w"], P[name + ".emb.b"] = f32(m.emb_layers[1].weight), f32(m.emb_layers[1].bias)

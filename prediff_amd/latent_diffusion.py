@@ -133,7 +133,11 @@ class LatentDiffusion(_module_base()):
         self.use_hip_graph = True
         # lanes: the batch is advanced as `num_streams` equal sub-batches, each a HIP graph replayed on its own stream with its own
         # workspace.  Trajectories are independent, so the sub-batches fill each other's idle CUs (tile-count quantisation, HBM-bound
-        # phases of the fused kernels): +12...20 % throughput at 32-64 trajectories.  Results are identical to num_streams = 1.
+        # phases of the fused kernels): +12...20 % throughput at 32-64 trajectories.  precision="fp32" (never splits K): results
+        # are bit-identical to num_streams = 1.  bf16 / fp8 with <= 16 trajectories per launch: the split-K Conv3d (csrc/igemm256.hip)
+        # picks its K slicing from the per-launch batch, so another lane count / micro-batch / ensemble sharding changes the fp32
+        # summation order and the latents agree to bf16 noise (5e-3 per forward), not bit for bit (DESIGN.md §4;
+        # tests/test_hip_configs.py::test_v1_lane_split_tolerance).  `torch_nn_module.split_k = False` is the reproducible mode.
         self.num_streams = 2
         self.aligned_lanes = 1        # knowledge-aligned loop: denoiser lanes next to the guidance stream (see p_sample_loop)
         self.guidance_high_priority = False   # knowledge-aligned loop: run the guidance on a high-priority side stream (A/B switch;
@@ -486,11 +490,13 @@ class LatentDiffusion(_module_base()):
             # into lanes as well only makes the three compete (measured at 32 / 8 trajectories: 33.4 / 11.6 ms per step with one
             # lane, 34.8 / 13.6 with two, 37.2 / 16.0 with four -- profiles/r02_j_time_alignment*.log).  `aligned_lanes` overrides.
             saved = self.num_streams
-            self.num_streams = max(1, int(self.aligned_lanes))
-            if B % max(1, self.num_streams):
-                self.num_streams = 1
-            eps_lanes = self._lanes("eps", B, cond, device, True) if self.num_streams > 1 else None
-            self.num_streams = saved
+            try:                                 # an exception in the capture must not leave the module with another lane count
+                self.num_streams = max(1, int(self.aligned_lanes))
+                if B % max(1, self.num_streams):
+                    self.num_streams = 1
+                eps_lanes = self._lanes("eps", B, cond, device, True) if self.num_streams > 1 else None
+            finally:
+                self.num_streams = saved
             if eps_lanes is None:
                 key = str(device)
                 if len(self._lane_streams.get(key, ())) < 1:

@@ -124,8 +124,9 @@ def test_v1_ddim50_vs_oracle():
           f"by step (1,10,25,40,50): fp32 {errs['fp32_by_step']} bf16 {errs['bf16_by_step']} fp8 {errs['fp8_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
     _report("v1_ddim50", oracle_cpu_s=round(t_cpu, 1), **errs)
     assert errs["fp32"] < 1e-3
-    assert errs["bf16"] < 0.25 and np.isfinite(errs["bf16"])
-    assert errs["fp8"] < 0.5 and np.isfinite(errs["fp8"])          # report-only operand type (BASELINE config 5)
+    # guard rails at 2x what is measured (bf16 1.0e-2, fp8 3.8e-2 after all 50 steps: DESIGN.md §4), so that a regression shows
+    assert errs["bf16"] < 2e-2 and np.isfinite(errs["bf16"])
+    assert errs["fp8"] < 8e-2 and np.isfinite(errs["fp8"])          # report-only operand type (BASELINE config 5)
 
 
 @pytest.mark.parametrize("kind", ["zeros", "sparse90"])
@@ -251,9 +252,9 @@ def test_fullres_forward():
     finally:
         torch.set_num_threads(nthr)
     t_cpu = time.time() - t0
-    # "fp8": e4m3 operands for the 3x3x3 convolutions (3 mantissa bits: report-only accuracy, BASELINE config 5); the bound below only
-    # catches a broken kernel, the number to read is the printed one
-    for precision, tol in (("fp32", 1e-4), ("bf16", 2e-2), ("fp8", 0.25)):
+    # "fp8": e4m3 operands (3 mantissa bits: report-only accuracy, BASELINE config 5); bounds at 2x what is measured (bf16 7.4e-3,
+    # fp8 4.3e-2)
+    for precision, tol in (("fp32", 1e-4), ("bf16", 1.5e-2), ("fp8", 8e-2)):
         net = CuboidTransformerUNet(**FULLRES_UNET_CFG, precision=precision)
         net.load_state_dict(sd, strict=True)
         net = net.cuda()
@@ -283,4 +284,79 @@ def test_v1_unet_fp8_conv(golden):
     assert torch.isfinite(outs["fp8"]).all()
     e8 = rel_l2(outs["fp8"], outs["bf16"])
     print(f"[v1 unet fp8 conv] rel-L2 vs the bf16 engine {e8:.3e}")
-    assert 1e-4 < e8 < 0.25          # different arithmetic (not the bf16 path by accident), same function
+    assert 1e-4 < e8 < 8e-2          # different arithmetic (not the bf16 path by accident), same function (measured 3.3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ config 4, the whole chain
+def test_v1_aligned_chain_100():
+    """BASELINE config 4 over its full horizon: 100 knowledge-aligned ancestral steps (t = 99 ... 0, guide_scale 50) at the v1 size,
+    B = 2, one noise tape.  Oracle = oracle.diffusion.ddpm_sample_loop around the oracle denoiser and the guidance network's PyTorch
+    CPU path (the form pinned against the reference golden by tests/test_alignment.py).  The fp32-class engine has to stay inside the
+    north_star bar (1e-3 rel-L2) over all 100 steps; the bf16 engine's drift over the same chain is measured and bounded."""
+    from prediff_amd.alignment import SEVIRAvgIntensityAlignment
+    B, T = 2, 100
+    sd = _v1_unet_sd()
+    zc = seeded_input("c4c", (B, 7, 16, 16, 64), 51)
+    tape = [seeded_input("c4x", (B, 6, 16, 16, 64), 52)] + [seeded_input(f"c4n{k}", (B, 6, 16, 16, 64), 53) for k in range(T)]
+    avg = torch.tensor([[0.31], [0.12]])
+
+    def make_alignment():
+        al = SEVIRAvgIntensityAlignment(alignment_type="avg_x", guide_scale=50.0, model_type="cuboid", model_args=dict(V1_ALIGN_ARGS))
+        al.model.load_state_dict(seeded_state_dict(al.model.state_dict(), 701))
+        al.model.eval()
+        return al
+
+    al_cpu = make_alignment()
+    buf = {k: torch.as_tensor(v) for k, v in OD.schedule_buffers(OD.beta_schedule("linear", 1000)).items()}
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 32))
+    t0 = time.time()
+    try:
+        def den(z, t, c):
+            with torch.no_grad():
+                return OU.unet_forward(sd, V1_UNET_CFG, z, t, c)
+        traj = OD.ddpm_sample_loop(buf, den, zc, tape, T, align_fn=lambda z, t: al_cpu.get_mean_shift(z, t, avg_x_gt=avg).detach())
+    finally:
+        torch.set_num_threads(nthr)
+    t_cpu = time.time() - t0
+    ref = traj[-1]
+    errs = {}
+    for precision in ("fp32", "bf16"):
+        ldm = _v1_ldm(precision)
+        al = make_alignment()
+        al.model.cuda()
+        ldm.set_alignment(al.get_mean_shift)
+        out, inter = ldm.p_sample_loop(cond=zc.cuda(), shape=ldm.get_batch_latent_shape(B), timesteps=T, use_alignment=True,
+                                       alignment_kwargs={"avg_x_gt": avg.cuda()}, noise_tape=[x.cuda() for x in tape],
+                                       return_intermediates=True, log_every_t=1)
+        errs[precision] = rel_l2(out, ref)
+        errs[precision + "_by_step"] = [round(rel_l2(inter[k], traj[k]), 6) for k in (1, 25, 50, 75, 100) if k < len(inter)]
+        del ldm, al
+    print(f"[v1 aligned chain, 100 steps] rel-L2 vs the oracle loop: fp32 {errs['fp32']:.3e} {errs['fp32_by_step']}, "
+          f"bf16 {errs['bf16']:.3e} {errs['bf16_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
+    _report("v1_aligned_chain_100", oracle_cpu_s=round(t_cpu, 1), **errs)
+    assert errs["fp32"] < 1e-3
+    assert errs["bf16"] < 5e-2 and np.isfinite(errs["bf16"])
+
+
+def test_v1_lane_split_tolerance():
+    """V1-size channels, bf16: the split-K Conv3d picks its K slicing from the per-launch batch (<= 16 trajectories), so 8 trajectories
+    as one launch, as two lanes of 4 and with split_k = False agree to bf16 noise, not bit for bit; split_k = False is the
+    batch-split-reproducible mode (bit-identical across lane counts)."""
+    B = 8
+    zc, xT = seeded_input("lsc", (B, 7, 16, 16, 64), 61).cuda(), seeded_input("lsx", (B, 6, 16, 16, 64), 62).cuda()
+    res = {}
+    for split_k in (True, False):
+        for lanes in (1, 2):
+            ldm = _v1_ldm("bf16")
+            ldm.torch_nn_module.split_k = split_k
+            ldm.num_streams = lanes
+            res[split_k, lanes] = ldm.sample(cond=zc, batch_size=B, sampler="ddim", ddim_steps=2, eta=0.0, x_T=xT, return_decoded=False)
+            del ldm
+    e_split = rel_l2(res[True, 2], res[True, 1])
+    e_mode = rel_l2(res[True, 1], res[False, 1])
+    print(f"[v1 lane split, bf16, 8 trajectories, 2 DDIM steps] split-K: 2 lanes vs 1 lane {e_split:.3e}; split-K vs no split {e_mode:.3e}; "
+          f"no split: 2 lanes == 1 lane {torch.equal(res[False, 2], res[False, 1])}")
+    _report("v1_lane_split", split_vs_lanes=e_split, split_vs_nosplit=e_mode)
+    assert torch.equal(res[False, 2], res[False, 1])
+    assert e_split < 1e-2 and e_mode < 1e-2
