@@ -205,6 +205,18 @@ int pd_attn_block_fused_supported(int C, int heads, int vol);
 int pd_attn_block_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv, const float* bqkv,
                         const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias, const uint8_t* mask,
                         int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps, pd_stream_t stream);
+/* The same with a host-side hint: tok_affine = {n_inner, outer, inner, slot} (HOST pointer, or NULL) states that
+ * tok_index[c][s] == (c / n_inner) * outer + (c % n_inner) * inner + s * slot for every cuboid c and slot s < vol (un-shifted, un-padded
+ * axial cuboids; n_inner <= 0 = no such form): the kernel then computes the token ids instead of loading the table in front of
+ * its row gather.  In place (out == x) the epilogue adds into the rows with L2 float atomics (no residual re-read; a row belongs to
+ * exactly one workgroup and (acc + b) + x is the same fp32 sum, so results are bit-identical to the load/store form). */
+int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv, const float* bqkv,
+                           const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias, const uint8_t* mask,
+                           int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps, const int32_t* tok_affine,
+                           pd_stream_t stream);
+/* Engine switches of the fused level-0 kernels (A/B measurements, tests): bit 0 in-place atomic epilogue, bit 1 deep weight ring for
+ * launches of at most one workgroup per CU, bit 2 arithmetic token ids.  Default 7. */
+extern int pd_fused_opts;
 
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
  * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]

@@ -72,6 +72,7 @@ _PROTOS = {
     "pd_ffn_fused_supported": (C.c_int, [C.c_int, C.c_int]),
     "pd_attn_block_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pd_attn_block_fused": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),
+    "pd_attn_block_fused_ex": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "pd_ffn_fused": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
@@ -94,6 +95,8 @@ def lib():
         if l.pd_sizeof_igemm_args() != C.sizeof(IgemmArgs) or l.pd_sizeof_cuboid_attn_args() != C.sizeof(CuboidAttnArgs):
             raise PrediffHipError(f"{LIB_PATH} is stale: its argument structs do not match prediff_amd/_lib.py "
                                   f"(rebuild with `make -C prediff_amd/csrc`)")
+        if os.environ.get("PD_FUSED_OPTS"):       # A/B measurements (scripts/r03_*.sh): engine switches of the fused level-0 kernels
+            C.c_int.in_dll(l, "pd_fused_opts").value = int(os.environ["PD_FUSED_OPTS"])
         _lib = l
     return _lib
 
@@ -303,9 +306,23 @@ def attn_block_fused_supported(Cn, heads, vol):
     return bool(lib().pd_attn_block_fused_supported(Cn, heads, vol))
 
 
-def attn_block_fused(x, out, gamma, beta, Wqkv, bqkv, Wp, bp, tok_index, bias, mask, B, ntok, Cn, heads, nc, vol, scale, eps=1e-5):
-    _check(lib().pd_attn_block_fused(ptr(x), ptr(out), ptr(gamma), ptr(beta), ptr(Wqkv), ptr(bqkv), ptr(Wp), ptr(bp), ptr(tok_index),
-                                     ptr(bias), ptr(mask), B, ntok, Cn, heads, nc, vol, scale, eps, stream_ptr()), "pd_attn_block_fused")
+def attn_block_fused(x, out, gamma, beta, Wqkv, bqkv, Wp, bp, tok_index, bias, mask, B, ntok, Cn, heads, nc, vol, scale, eps=1e-5,
+                     tok_affine=None):
+    """tok_affine: (n_inner, outer, inner, slot) from cuboid_geometry.affine_form(tok_index), or None (the kernel loads the table)."""
+    aff = (C.c_int32 * 4)(*tok_affine) if tok_affine is not None else None
+    _check(lib().pd_attn_block_fused_ex(ptr(x), ptr(out), ptr(gamma), ptr(beta), ptr(Wqkv), ptr(bqkv), ptr(Wp), ptr(bp), ptr(tok_index),
+                                        ptr(bias), ptr(mask), B, ntok, Cn, heads, nc, vol, scale, eps,
+                                        C.cast(aff, C.c_void_p) if aff is not None else None, stream_ptr()), "pd_attn_block_fused")
+
+
+def fused_opts(value=None):
+    """pd_fused_opts (bit 0 atomic in-place epilogue, bit 1 deep weight ring for small grids, bit 2 arithmetic token ids); returns the
+    previous value."""
+    v = C.c_int.in_dll(lib(), "pd_fused_opts")
+    old = v.value
+    if value is not None:
+        v.value = int(value)
+    return old
 
 
 def ffn_fused_supported(Cn, Hd):

@@ -97,6 +97,10 @@ struct pd_attn_block_args_k {
   int B, ntok, nc, vol;
   float scale, eps;
   uint32_t wqkv_bytes, wp_bytes;
+  // token of (cuboid c, slot s) = (c / aff_ninner) * aff_outer + (c % aff_ninner) * aff_inner + s * aff_slot when aff_on (un-shifted,
+  // un-padded axial cuboids: the host checked the table against this form) -- no dependent table load in front of the row gather
+  int aff_on, aff_ninner, aff_outer, aff_inner, aff_slot;
+  int epi_atomic;              // out == x (in place): the epilogue adds acc + b_proj INTO the rows with L2 float atomics (no residual re-read)
   unsigned long long* trace;   // profiling only: per-phase clock stamps of wave 0 of workgroup 600 (null in production)
   int dbg;   // profiling ablations: 1 no weight DMA after chunk 2, 2 no q/k/v GEMMs, 4 no attention core, 8 no proj GEMM,
              // 16 no LN loads, 32 no residual loads, 64 no stores
@@ -105,8 +109,11 @@ struct pd_attn_block_args_k {
 // KT = key tiles of 16 per cuboid: a workgroup's 64 rows are 4 / KT whole cuboids of up to 16 KT slots each (KT = 1: the axial
 // cuboids of the SEVIR-LR grid; KT = 2 / 4: cuboid volumes up to 32 / 64, e.g. 25 and 48 on the 48 x 48 full-resolution grid --
 // the slots beyond the volume are empty rows, 22-25 % of the tile there).
-template <int C, int KT = 1, int RPC_ = 16 * KT>
-__global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_args_k p) {
+// NS = slots of the weight ring: 3 for two workgroups per CU (79 KB each); 6 (127 KB, one workgroup per CU) for small grids that
+// leave every CU at most one workgroup anyway: five chunks (80 KB) in flight instead of two, so that a step no longer waits for
+// the L2 -> LDS latency of the chunk it needs next.
+template <int C, int KT = 1, int RPC_ = 16 * KT, int NS = 3>
+__global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const pd_attn_block_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 64, HD = 64, HEADS = C / HD;
   constexpr int RPC = RPC_, CPW = 64 / RPC, QPC = RPC / 16;   // rows per cuboid (16 KT, or 64 for 3 key tiles: 33-48 slots), cuboids per
@@ -124,9 +131,10 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
   constexpr int NDMA = CHUNK / 8192;               // DMA instructions per chunk (512 threads x 16 B each)
   constexpr int PF = 1;                            // weight-fragment prefetch distance of the q/k/v GEMMs, in k-steps of 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(NS >= 3, "ring: chunk s lives in slot (s + 2) % NS; slots 0 and 1 are the A region");
   char* sA = smem;                                 // A tile, then ring slots 0 and 1
-  char* sR2 = sA + 2 * CHUNK;                      // ring slot 2
-  char* sQ = sR2 + CHUNK;                          // Q tile [row][d], re-used for O
+  char* sR2 = sA + 2 * CHUNK;                      // ring slots 2 .. NS-1
+  char* sQ = sR2 + (NS - 2) * CHUNK;               // Q tile [row][d], re-used for O
   char* sK = sQ + TILE;                            // K tile [row][d]
   char* sVT = sK + TILE;                           // V^T tile [d][row]
   float* sBias = (float*)(sVT + TILE);             // [HEADS][16][16]
@@ -152,9 +160,8 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
   const int drow = tid >> 3, dpos = tid & 7;
   const int dchunk = dpos ^ ((drow >> 1) & 7);
   const uint32_t w_voff = ((uint32_t)drow * C + dchunk * 8) * 2u;
-  auto ring = [&](int s) {                          // chunk s lives in ring slot (s + 2) % 3
-    const int b = (s + 2) % 3;
-    return b == 2 ? sR2 : sA + b * CHUNK;
+  auto ring = [&](int s) {                          // chunk s lives in ring slot (s + 2) % NS (slots are contiguous from sA)
+    return sA + ((s + 2) % NS) * CHUNK;
   };
   // chunk s = NCH * head + j:  j < 3 KH: kind j / KH (0 q, 1 k, 2 v), K half j % KH;  else proj output half j - 3 KH
   auto issue_chunk = [&](int s) {
@@ -172,7 +179,8 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
         BLDS16(rWp, d + i * 8192, w_voff, ((oh * 128 + i * 64) * C + h * HD) * 2);
     }
   };
-  issue_chunk(0);
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 2; ++s0) issue_chunk(s0);        // slots 2 .. NS-1 (slots 0 and 1 are still the A tile)
 
   // ---- token table of the 4 cuboids, relative-position bias (padded to 16 x 16 per head) ----
   if (tid < BM) {
@@ -181,7 +189,8 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
     int row = -1;
     if (gc < (int64_t)p.B * p.nc && slot < vol) {
       const int b = (int)(gc / p.nc), c = (int)(gc - (int64_t)b * p.nc);
-      const int tok = p.tok_index[c * vol + slot];
+      const int tok = p.aff_on ? (c / p.aff_ninner) * p.aff_outer + (c % p.aff_ninner) * p.aff_inner + slot * p.aff_slot
+                               : p.tok_index[c * vol + slot];
       if (tok >= 0) row = b * p.ntok + tok;
     }
     sTok[tid] = row;
@@ -232,21 +241,22 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
 #pragma unroll
   for (int r = 0; r < 4; ++r) vrow_ok |= (sTok[tq * 16 + 4 * lg + r] >= 0 ? 1u : 0u) << r;
   __syncthreads();                                        // A-tile region is now free: ring slots 0 and 1
-  issue_chunk(1);
-  issue_chunk(2);
+  issue_chunk(NS - 2);
+  issue_chunk(NS - 1);
   TRACE();
 
   const uint32_t w_lane_off = (uint32_t)((tn * 32 + l16) * 128 + ((lg ^ swz16) << 4));
   const uint32_t q_lds = (uint32_t)(uintptr_t)sQ, k_lds = (uint32_t)(uintptr_t)sK, vt_lds = (uint32_t)(uintptr_t)sVT;
   const uint32_t bq_lds = (uint32_t)(uintptr_t)sBq, bias_lds = (uint32_t)(uintptr_t)sBias;
   const int cub_of_wave = (int)(((int64_t)blockIdx.x * CPW + (wave & 3) / QPC) % p.nc);  // cuboid (mask table row) of this wave's core
-  // end of a weight-chunk step: chunk s+1 has landed (chunk s+2 may stay in flight), everyone is done with chunk s, refill its slot
+  // end of a weight-chunk step: chunk s+1 has landed (chunks s+2 .. s+NS-1 may stay in flight -- only when all of them were issued
+  // is the counted wait exact), everyone is done with chunk s, refill its slot
   auto step_end = [&](int s) {
-    if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    if (s + NS - 1 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + 3 < NCHUNK && !(p.dbg & 1)) issue_chunk(s + 3);
+    if (s + NS < NCHUNK && !(p.dbg & 1)) issue_chunk(s + NS);
   };
 
   for (int h = 0; h < HEADS; ++h) {
@@ -357,6 +367,7 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
     // next weight chunk is issued, so that the counted vmcnt in front of the core covers them without draining that chunk
     float bkg[KT > 1 ? KT : 1][4];
     if constexpr (KT > 1 || PD_AB_GENERIC_CORE) {
+      static_assert(KT == 1 || NS == 3, "the deep ring is built for the 16-slot cuboids only");
       const int s = NCH * h + 3 * KH - 1;
       if (s + 2 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -589,6 +600,25 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
 
   TRACE();
   // ---- epilogue: acc2 -> per-wave LDS slab [32][OH * 32] fp32 -> + b_proj + x -> out rows of the token table ----
+  if (p.epi_atomic) {
+    // In place (out == x): every output row belongs to exactly one workgroup, so x += acc + b_proj is ONE fire-and-forget
+    // global_atomic_add_f32 per element, executed in the L2 -- no residual re-read (a third of the kernel's HBM traffic and an
+    // exposed round trip at the end of every tile), no LDS staging.  (acc + b) + x is the same fp32 sum as the load/store form:
+    // bit-identical results.  Lane: column oh*128 + wn*32 + lrow, rows wm*32 + (r & 3) + 8 (r >> 2) + 4 lhalf -> every instruction
+    // covers two 128 B row segments.
+#pragma unroll
+    for (int t = 0; t < OH; ++t) {
+      const int n = t * 128 + wn * 32 + lrow;
+      const float bv = p.bp ? p.bp[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mr = sTok[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf];
+        if (mr >= 0 && !(p.dbg & 64)) unsafeAtomicAdd(p.out + (int64_t)mr * C + n, acc2[t][r] + bv);
+      }
+    }
+    TRACE();
+    return;
+  }
   constexpr int WN = OH * 32;                      // columns per wave: OH pieces of 32
   constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 16 at C = 256
   constexpr int RPP = 64 / LPR;
@@ -624,18 +654,18 @@ __global__ void __launch_bounds__(512, 4) attn_block_kernel(const pd_attn_block_
 #endif
 }
 
-template <int C, int KT = 1, int RPC = 16 * KT>
+template <int C, int KT = 1, int RPC = 16 * KT, int NS = 3>
 static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   constexpr int heads = C / 64;
-  constexpr int work = 3 * 16384 + 3 * 64 * 64 * 2;                 // weight ring + Q, K, V^T tiles: re-used by the epilogue slab
+  constexpr int work = NS * 16384 + 3 * 64 * 64 * 2;                // weight ring + Q, K, V^T tiles: re-used by the epilogue slab
   constexpr int lds = work + heads * 256 * 4 + 64 * 4 + 3 * C * 4;
   constexpr int epi = 8 * 32 * ((C / 128) * 32) * 4;
   static_assert(epi <= work, "the epilogue slab must not reach the bias / token tables");
-  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  static_assert((NS == 3 ? 2 : 1) * lds <= 160 * 1024, "two workgroups per CU (one with the deep ring)");
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_block_kernel<C, KT, RPC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_block_kernel<C, KT, RPC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_block_fused: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -644,7 +674,7 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   }
   const int64_t cuboids = (int64_t)a.B * a.nc;
   constexpr int CPW = 64 / RPC;
-  hipLaunchKernelGGL((attn_block_kernel<C, KT, RPC>), dim3((unsigned)((cuboids + CPW - 1) / CPW)), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((attn_block_kernel<C, KT, RPC, NS>), dim3((unsigned)((cuboids + CPW - 1) / CPW)), dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -656,10 +686,15 @@ extern "C" int pd_attn_block_fused_supported(int C, int heads, int vol) {
   return (C == 256 || C == 128) && heads * 64 == C && vol >= 1 && vol <= 64;
 }
 
-extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
-                                   const float* bqkv, const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias,
-                                   const uint8_t* mask, int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps,
-                                   pd_stream_t stream) {
+// Engine switches (A/B and tests): bit 0 atomic in-place epilogue, bit 1 deep weight ring for grids of at most one workgroup per CU,
+// bit 2 arithmetic token ids for affine cuboid tables.
+extern "C" int pd_fused_opts = 7;
+#define PD_NUM_CU 256
+
+extern "C" int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
+                                      const float* bqkv, const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias,
+                                      const uint8_t* mask, int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps,
+                                      const int32_t* tok_affine, pd_stream_t stream) {
   PD_CHECK_ARG(x && out && gamma && beta && Wqkv && Wp && tok_index && bias, "pd_attn_block_fused: null pointer");
   PD_CHECK_ARG(pd_attn_block_fused_supported(C, heads, vol), "pd_attn_block_fused: unsupported units=%d heads=%d cuboid volume=%d "
                "(units in {128,256}, head_dim 64, volume <= 64)", C, heads, vol);
@@ -672,14 +707,30 @@ extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamm
   a.wp_bytes = (uint32_t)((int64_t)C * C * 2);
   a.dbg = pd_attn_block_debug_flags;
   a.trace = pd_attn_block_trace;
+  a.aff_on = (tok_affine && (pd_fused_opts & 4) && tok_affine[0] > 0) ? 1 : 0;
+  a.aff_ninner = a.aff_on ? tok_affine[0] : 1;
+  a.aff_outer = a.aff_on ? tok_affine[1] : 0;
+  a.aff_inner = a.aff_on ? tok_affine[2] : 0;
+  a.aff_slot = a.aff_on ? tok_affine[3] : 0;
+  a.epi_atomic = (x == out && (pd_fused_opts & 1)) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const int kt = (vol + 15) / 16;     // key tiles of 16 per cuboid; 3 and 4 tiles: one cuboid per 64-row workgroup
+  // at most one workgroup per CU anyway: the deep-ring variant (one 127 KB workgroup per CU)
+  const bool deep = (pd_fused_opts & 2) && kt == 1 && ((int64_t)B * nc + 3) / 4 <= PD_NUM_CU;
   if (C == 256) {
-    if (kt == 1) return launch_attn_block<256, 1>(a, s);
+    if (kt == 1) return deep ? launch_attn_block<256, 1, 16, 6>(a, s) : launch_attn_block<256, 1>(a, s);
     if (kt == 2) return launch_attn_block<256, 2>(a, s);
     return kt == 3 ? launch_attn_block<256, 3, 64>(a, s) : launch_attn_block<256, 4>(a, s);
   }
-  if (kt == 1) return launch_attn_block<128, 1>(a, s);
+  if (kt == 1) return deep ? launch_attn_block<128, 1, 16, 6>(a, s) : launch_attn_block<128, 1>(a, s);
   if (kt == 2) return launch_attn_block<128, 2>(a, s);
   return kt == 3 ? launch_attn_block<128, 3, 64>(a, s) : launch_attn_block<128, 4>(a, s);
+}
+
+extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
+                                   const float* bqkv, const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias,
+                                   const uint8_t* mask, int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps,
+                                   pd_stream_t stream) {
+  return pd_attn_block_fused_ex(x, out, gamma, beta, Wqkv, bqkv, Wp, bp, tok_index, bias, mask, B, ntok, C, heads, nc, vol, scale, eps,
+                                nullptr, stream);
 }

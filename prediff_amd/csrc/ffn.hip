@@ -38,6 +38,7 @@ struct pd_ffn_args_k {
   int M, Hd, act;
   float eps;
   uint32_t w1_bytes, w2_bytes;
+  int epi_atomic;              // out == x (in place): the epilogue adds acc + b2 INTO the rows with L2 float atomics (no residual re-read)
   unsigned long long* trace;   // profiling only: per-slot clock stamps of waves 0 and 4 of workgroup 300 (null in production)
   int dbg;   // profiling ablations: 1 no weight DMA after chunk 0, 2 no GEMM-1, 4 no activation + H store, 8 no GEMM-2,
              // 16 no LN loads, 32 no residual loads, 64 no stores
@@ -275,17 +276,19 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(((ks) & 1) ? ((base_vgpr) ^ 64u) : (base_vgpr)),     \
                "n"(((ks) >> 1) * 8192 + (dt) * 2048))
 
-template <int ACT>
-__global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
+// NS = weight slots: 2 (76 KB: two workgroups per CU) or 4 (140 KB, one workgroup per CU: grids of at most one workgroup per CU
+// anyway) -- three chunks (96 KB) in flight instead of one, so that a step no longer waits for the L2 -> LDS latency of its successor.
+template <int ACT, int NS = 2>
+__global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ffn_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = 256, BM = 64, HC = 64, KS = C / 64;
   constexpr int SLOT = 32768;                      // one weight chunk: W1_j [64 hidden][256 k] or W2_j [256 out][64 hidden]
   constexpr int PF = 2;                            // W1-fragment prefetch distance, k-steps of 32
   constexpr int NSTEP = 2 * KS;                    // k-steps of 32 over K = C
+  static_assert(NS % 2 == 0, "W1 chunks (even) and W2 chunks (odd) keep their slot parity: chunk s lives in slot (s + 1) % NS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sS0 = smem;                                // A tile, then weight slot 0
-  char* sS1 = smem + SLOT;                         // weight slot 1
-  char* sH = smem + 2 * SLOT;                      // H tile [64 rows][64 hidden] bf16, 16 B chunk XOR (row >> 1) & 7
+  char* sH = smem + NS * SLOT;                     // H tile [64 rows][64 hidden] bf16, 16 B chunk XOR (row >> 1) & 7
   float* sB1 = (float*)(sH + BM * HC * 2);         // whole b1 (Hd floats)
 
   const int tid = threadIdx.x;
@@ -302,8 +305,9 @@ __global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
   const int dchunk = dpos ^ ((drow >> 1) & 7);
   const uint32_t w1_voff = ((uint32_t)drow * C + dchunk * 8) * 2u;                       // + (j*64*C + i*64)*2: K slab i of W1_j
   const uint32_t w2_voff = ((uint32_t)drow * (uint32_t)p.Hd + dchunk * 8) * 2u;          // + (i*64*Hd + j*64)*2: output slab i of W2_j
+  auto slot_of = [&](int s) { return sS0 + ((s + 1) % NS) * SLOT; };
   auto issue = [&](int s) {
-    char* d = ((s + 1) & 1 ? sS1 : sS0) + wave * 1024;
+    char* d = slot_of(s) + wave * 1024;
     const int j = s >> 1;
     if (!(s & 1)) {
 #pragma unroll
@@ -313,7 +317,8 @@ __global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
       for (int i = 0; i < KS; ++i) BLDS16(rW2, d + i * 8192, w2_voff, (i * 64 * p.Hd + j * HC) * 2);
     }
   };
-  issue(0);                                        // W1_0 -> slot 1
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);   // chunks 0 .. NS-2 -> slots 1 .. NS-1 (slot 0 is still the A tile)
 
   // ---- phase 0: LayerNorm -> bf16 A tile (KS slabs of [64][64]); b1 -> LDS while the row loads are in flight ----
   ln_block_to_tile<C, BM, 8>(p.x, p.gamma, p.beta, p.eps, sS0, wave, lane, (p.dbg & 16) != 0,
@@ -340,18 +345,20 @@ __global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
   for (int ks = 0; ks < NSTEP; ++ks)
     areg[ks] = *(const bf16x8*)(sS0 + (ks >> 1) * (BM * 128) + (tq * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
   __syncthreads();                                 // the A-tile region is free: weight slot 0
-  issue(1);                                        // W2_0 -> slot 0
+  issue(NS - 1);                                   // -> slot 0
 
-  const uint32_t w_lane = (uint32_t)(uintptr_t)sS1 + (uint32_t)((tn * 32 + l16) * 128 + ((lg ^ swz16) << 4));
+  const uint32_t w_lane_off = (uint32_t)((tn * 32 + l16) * 128 + ((lg ^ swz16) << 4));
   const uint32_t h_lds = (uint32_t)(uintptr_t)sH, b1_lds = (uint32_t)(uintptr_t)sB1;
   const int g2_a = (wm * 32 + lrow) * 128;                               // H row of GEMM-2's A operand
   const int g2_b = (wn >> 1) * 8192 + ((wn & 1) * 32 + lrow) * 128;      // W2 chunk: slab (64 output channels), row in it; + oh * 16384
   // end of a step: the next step's weights have landed (the only DMA in flight), everyone is done with this step's slot and H
+  // (chunks s+2 .. s+NS-1 may stay in flight -- the counted wait is exact only when all of them were issued)
   auto step_end = [&](int s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NS > 2 && s + NS - 1 < NCHUNK && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * KS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + 2 < NCHUNK && !(p.dbg & 1)) issue(s + 2);
+    if (s + NS < NCHUNK && !(p.dbg & 1)) issue(s + NS);
   };
 
   for (int j = 0; j < NJ; ++j) {
@@ -359,6 +366,7 @@ __global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
     {
       // lane: token row tq*16 + l16 (column of the tile), hidden units tn*32 + 16 dt + 4 lg + (0..3)
       f32x4 acc1[2], bb[2];
+      const uint32_t w_lane = (uint32_t)(uintptr_t)slot_of(2 * j) + w_lane_off;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
         asm volatile("ds_read_b128 %0, %1" : "=v"(bb[dt]) : "v"(b1_lds + (uint32_t)((j * HC + tn * 32 + dt * 16 + 4 * lg) * 4)));
@@ -411,7 +419,7 @@ __global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
         bf16x8 fa[2], fb[2][2];                                         // [pipeline slot][output half]: two k-sub-steps in flight
         const uint32_t xs = (uint32_t)((lhalf ^ swz) << 4);              // 16 B slot of k-sub-step 0; sub-step kk: ^ (kk << 5)
         const uint32_t a2 = h_lds + (uint32_t)g2_a + xs;
-        const uint32_t b2 = (uint32_t)(uintptr_t)sS0 + (uint32_t)g2_b + xs;
+        const uint32_t b2 = (uint32_t)(uintptr_t)slot_of(2 * j + 1) + (uint32_t)g2_b + xs;
         auto ld2 = [&](int kk, int slot) {
           asm volatile("ds_read_b128 %0, %1" : "=v"(fa[slot]) : "v"(a2 ^ (uint32_t)(kk << 5)));
           asm volatile("ds_read_b128 %0, %1" : "=v"(fb[slot][0]) : "v"(b2 ^ (uint32_t)(kk << 5)));
@@ -436,6 +444,21 @@ __global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
     }
   }
 
+  if (p.epi_atomic) {
+    // in place (out == x): x += acc + b2 as one fire-and-forget L2 float atomic per element (see csrc/attn_block.hip); a row belongs
+    // to one workgroup, (acc + b) + x is the same fp32 sum as the load/store form
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = t * 128 + wn * 32 + lrow;
+      const float bv = p.b2[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        if (m < p.M && !(p.dbg & 64)) unsafeAtomicAdd(p.out + (int64_t)m * C + n, acc2[t][r] + bv);
+      }
+    }
+    return;
+  }
   // ---- epilogue: acc2 -> per-wave LDS slab [32][64] fp32 -> + b2 + x -> out ----
   constexpr int WN = 64;                           // columns per wave: 2 pieces of 32
   constexpr int LPR = WN / 4, RPP = 64 / LPR, NPASS = 32 / RPP;
@@ -467,20 +490,20 @@ __global__ void __launch_bounds__(512, 4) ffn64_kernel(const pd_ffn_args_k p) {
 #endif
 }
 
-template <int ACT>
+template <int ACT, int NS = 2>
 static int launch_ffn64(const pd_ffn_args_k& a, hipStream_t s) {
-  const int bytes = 2 * 32768 + 64 * 64 * 2 + a.Hd * 4;          // two weight slots (the epilogue slab re-uses them) + H tile + b1
+  const int bytes = NS * 32768 + 64 * 64 * 2 + a.Hd * 4;         // the weight slots (the epilogue slab re-uses them) + H tile + b1
   static int attr_set_dev[PD_MAX_DEVICES];
   int& attr_set = attr_set_dev[pd_cur_device()];
   if (attr_set < bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn64_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)ffn64_kernel<ACT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
       pd_set_error("pd_ffn_fused: hipFuncSetAttribute(%d) failed: %s", bytes, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
     }
     attr_set = bytes;
   }
-  hipLaunchKernelGGL((ffn64_kernel<ACT>), dim3((a.M + 63) / 64), dim3(512), bytes, s, a);
+  hipLaunchKernelGGL((ffn64_kernel<ACT, NS>), dim3((a.M + 63) / 64), dim3(512), bytes, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -525,8 +548,13 @@ extern "C" int pd_ffn_fused(const float* x, float* out, const float* gamma, cons
   a.w2_bytes = (uint32_t)((int64_t)C * Hd * 2);
   a.dbg = pd_ffn_debug_flags;
   a.trace = pd_ffn_trace;
+  extern int pd_fused_opts;        // csrc/attn_block.hip: bit 0 atomic in-place epilogue, bit 1 deep weight ring for small grids
+  a.epi_atomic = (x == out && (pd_fused_opts & 1)) ? 1 : 0;
+  // at most one workgroup per CU anyway (<= 256 tiles of 64 rows): the four-slot ring, one 140 KB workgroup per CU
+  const bool deep = (pd_fused_opts & 2) && (M + 63) / 64 <= 256 && Hd * 4 + 4 * 32768 + 8192 <= 160 * 1024;
   hipStream_t s = (hipStream_t)stream;
 #define PD_FFN(ACT)                                  \
+  if (C == 256 && pd_ffn_use_64 && deep) return launch_ffn64<ACT, 4>(a, s);   \
   if (C == 256 && pd_ffn_use_64 && Hd * 4 + 2 * 32768 + 8192 <= 80 * 1024) return launch_ffn64<ACT>(a, s);   \
   if (C == 256) return launch_ffn<256, ACT>(a, s);   \
   if (C == 128) return launch_ffn<128, ACT>(a, s);   \

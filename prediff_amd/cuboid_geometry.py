@@ -95,8 +95,28 @@ def attention_tables(shape, cuboid, shift, strategy, padding_type):
         valid = tok >= 0
         mask = mask & valid[:, :, None] & valid[:, None, :]
     mask_t = None if mask.all() else torch.from_numpy(mask.astype(np.uint8)).contiguous()
-    return dict(cuboid=cub, shift=sh, pad=pad, nc=int(nc), vol=int(vol),
-                tok_index=torch.from_numpy(tok.astype(np.int32)).contiguous(), mask=mask_t)
+    tok_t = torch.from_numpy(tok.astype(np.int32)).contiguous()
+    return dict(cuboid=cub, shift=sh, pad=pad, nc=int(nc), vol=int(vol), tok_index=tok_t, mask=mask_t, affine=affine_form(tok_t))
+
+
+def affine_form(tok_index: torch.Tensor):
+    """(n_inner, outer, inner, slot) with tok_index[c, s] == (c // n_inner) * outer + (c % n_inner) * inner + s * slot for every entry,
+    or None.  True for the un-shifted, un-padded axial cuboids of the SEVIR grids: pd_attn_block_fused_ex then computes the token ids
+    instead of loading the table in front of its row gather."""
+    tok = tok_index.cpu().numpy().astype(np.int64)
+    nc, vol = tok.shape
+    if (tok < 0).any():
+        return None
+    slot = int(tok[0, 1] - tok[0, 0]) if vol > 1 else 0
+    inner = int(tok[1, 0] - tok[0, 0]) if nc > 1 else 0
+    c = np.arange(nc)[:, None]
+    s = np.arange(vol)[None, :]
+    for n_inner in sorted({nc} | {d for d in range(1, nc + 1) if nc % d == 0}):
+        outer = int(tok[n_inner, 0] - tok[0, 0]) if n_inner < nc else 0
+        if tok[0, 0] == 0 and np.array_equal((c // n_inner) * outer + (c % n_inner) * inner + s * slot, tok):
+            if max(abs(outer), abs(inner), abs(slot)) < 2 ** 24:
+                return (int(n_inner), outer, inner, slot)
+    return None
 
 
 def relative_position_bias(table: torch.Tensor, rel_index: torch.Tensor, vol: int) -> torch.Tensor:

@@ -702,7 +702,7 @@ class CuboidTransformerUNet(nn.Module):
             # one launch, q/k/v/attention output never leave the CU (csrc/attn_block.hip)
             L.attn_block_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".qkv.w"][0], P[name + ".qkv.b"],
                                P[name + ".proj.w"][0], P[name + ".proj.b"], tabs["tok"], P[name + ".bias"], tabs["mask"],
-                               B, S, C, at.num_heads, geo["nc"], geo["vol"], float(at.scale))
+                               B, S, C, at.num_heads, geo["nc"], geo["vol"], float(at.scale), tok_affine=geo.get("affine"))
             return
         a, alo = self._bf("ln.a", B * S, ld, dev)
         L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld)

@@ -526,6 +526,50 @@ def test_attn_block_fused_vs_oracle(golden, case):
         assert abs(float(y.double().abs().sum()) / float(g[f"y_{case}_abs_sum"][0]) - 1) < 6e-3
 
 
+@pytest.mark.parametrize("shape,cuboid,Cn,heads,B", [((13, 16, 16), (13, 1, 1), 256, 4, 2), ((13, 16, 16), (1, 16, 1), 256, 4, 6),
+                                                      ((13, 16, 16), (1, 1, 16), 256, 4, 1), ((5, 8, 8), (1, 8, 1), 128, 2, 3)])
+def test_fused_engine_switches(shape, cuboid, Cn, heads, B):
+    """pd_fused_opts: the in-place atomic epilogue (bit 0), the deep weight ring of launches with at most one workgroup per CU
+    (bit 1; B = 6 at the v1 grid is 312 workgroups: the two-per-CU ring) and the arithmetic token ids (bit 2) change the schedule,
+    not the arithmetic: every combination gives bit-identical rows, for the attention block and for the FFN."""
+    from prediff_amd.cuboid_geometry import attention_tables
+    T, H, W = shape
+    ntok = T * H * W
+    g = torch.Generator(device="cpu").manual_seed(ntok + Cn + B)
+    x = (torch.randn(B, ntok, Cn, generator=g) * 1.5 + 0.2).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(Cn, generator=g)).to(DEV), (0.1 * torch.randn(Cn, generator=g)).to(DEV)
+    wq_p, _ = pack_linear((torch.randn(3 * Cn, Cn, generator=g) / math.sqrt(Cn)).to(DEV), False)
+    wp_p, _ = pack_linear((torch.randn(Cn, Cn, generator=g) / math.sqrt(Cn)).to(DEV), False)
+    bp = (torch.randn(Cn, generator=g) * 0.1).to(DEV)
+    tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+    vol, nc = tabs["vol"], tabs["nc"]
+    assert tabs["affine"] is not None
+    bias = (torch.randn(heads, vol, vol, generator=g) * 0.5).to(DEV)
+    tok = tabs["tok_index"].to(DEV)
+    Hd = 4 * Cn
+    w1p, _ = pack_linear((torch.randn(Hd, Cn, generator=g) / math.sqrt(Cn)).to(DEV), False)
+    w2p, _ = pack_linear((torch.randn(Cn, Hd, generator=g) / math.sqrt(Hd)).to(DEV), False)
+    b1, b2 = torch.randn(Hd, generator=g).to(DEV) * 0.1, torch.randn(Cn, generator=g).to(DEV) * 0.1
+    res = {}
+    old = L.fused_opts()
+    try:
+        for opts in (0, 1, 2, 4, 7):
+            L.fused_opts(opts)
+            xa = x.clone()
+            L.attn_block_fused(xa, xa, gamma, beta, wq_p, None, wp_p, bp, tok, bias, None, B, ntok, Cn, heads, nc, vol, (Cn // heads) ** -0.5,
+                               tok_affine=tabs["affine"])
+            xf = x.clone().reshape(B * ntok, Cn)
+            L.ffn_fused(xf, xf, gamma, beta, w1p, b1, w2p, b2, B * ntok, Cn, Hd, act="gelu")
+            torch.cuda.synchronize()
+            res[opts] = (xa, xf)
+    finally:
+        L.fused_opts(old)
+    assert bool(torch.isfinite(res[0][0]).all()) and not torch.equal(res[0][0], x)
+    for opts in (1, 2, 4, 7):
+        assert torch.equal(res[opts][0], res[0][0]), f"attention block: pd_fused_opts = {opts} changes the result"
+        assert torch.equal(res[opts][1], res[0][1]), f"FFN: pd_fused_opts = {opts} changes the result"
+
+
 # ------------------------------------------------------------------------------------------------ split-K (small grids)
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(1, 13, 16, 16, 256, 256), (4, 13, 8, 8, 512, 512), (2, 5, 8, 8, 128, 192), (3, 13, 16, 16, 256, 256)])
 def test_igemm_conv3d_split_k(B, T, H, W, Cin, Cout):
