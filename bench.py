@@ -105,6 +105,93 @@ def kernel_times(ldm, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
     return conv_s, len(conv_pairs) // reps, attn_s, len(attn_pairs) // reps
 
 
+def kernel_times_two_lanes(ldm_a, ldm_b, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
+    """The Conv3d launches AS THEY RUN IN THE TIMED CONFIGURATION: two lanes of B trajectories advancing concurrently on two streams
+    (two module instances driven by two host threads, one HIP-event pair per Conv3d launch on its own stream).  Returns the average
+    launch duration (s) over both lanes.  Beside an isolated lane's figure this shows what the two lanes cost each other."""
+    import threading
+    from prediff_amd import _lib as L
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    pairs = [[], []]
+    orig_igemm = L.igemm
+    tls = threading.local()
+
+    def timed_igemm(*a, **k):
+        lane = getattr(tls, "lane", None)
+        if lane is not None and k.get("taps", 1) == 27:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_igemm(*a, **k)
+            e1.record()
+            pairs[lane].append((e0, e1))
+        else:
+            orig_igemm(*a, **k)
+
+    inputs = []
+    for ldm in (ldm_a, ldm_b):
+        z = torch.randn(ldm.get_batch_latent_shape(B), device=device)
+        zc = torch.randn((B,) + tuple(cond_shape), device=device)
+        t = torch.full((B,), 500, dtype=torch.long, device=device)
+        ldm.torch_nn_module(z, t, zc)                      # warm-up: packing, workspaces
+        inputs.append((z, t, zc))
+    torch.cuda.synchronize(device)
+    gate = threading.Barrier(2)
+
+    def run(lane):
+        tls.lane = lane
+        torch.cuda.set_device(device)
+        net = (ldm_a, ldm_b)[lane].torch_nn_module
+        with torch.cuda.stream(streams[lane]):
+            gate.wait()
+            for _ in range(reps):
+                net(*inputs[lane])
+        streams[lane].synchronize()
+
+    L.igemm = timed_igemm
+    try:
+        th = [threading.Thread(target=run, args=(l,)) for l in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    finally:
+        L.igemm = orig_igemm
+    torch.cuda.synchronize(device)
+    allp = pairs[0] + pairs[1]
+    return sum(a.elapsed_time(b) for a, b in allp) * 1e-3 / max(1, len(allp)), len(allp)
+
+
+VAE_ENC_GFLOP_PER_FRAME, VAE_DEC_GFLOP_PER_FRAME = 68.0, 155.2      # SURVEY.md §8(a) a13 / a14 (one 128 x 128 frame, 2 * MAC)
+
+
+def vae_times(device, trajectories=32, reps=3):
+    """Frame-wise KL-VAE of the v1 configuration (the two ends of sample()): encode of the 7 context frames and decode of the 6
+    predicted frames of `trajectories` trajectories, bf16 engine, seeded weights; wall time over `reps` calls each."""
+    from prediff_amd.autoencoder_kl import AutoencoderKL
+    from prediff_amd.presets import V1_VAE_CFG
+    from prediff_amd.seeding import seeded_state_dict
+    vae = AutoencoderKL(**V1_VAE_CFG, precision="bf16")
+    vae.load_state_dict(seeded_state_dict(vae.state_dict(), 77))
+    vae = vae.to(device).eval()
+    n_enc, n_dec = 7 * trajectories, 6 * trajectories
+    x = torch.rand(n_enc, 1, 128, 128, device=device)
+    z = torch.randn(n_dec, 64, 16, 16, device=device)
+    out = {}
+    with torch.no_grad():
+        for name, fn, n, gf in (("encode", lambda: vae.encode(x).mode(), n_enc, VAE_ENC_GFLOP_PER_FRAME),
+                                ("decode", lambda: vae.decode(z), n_dec, VAE_DEC_GFLOP_PER_FRAME)):
+            fn()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(device)
+            el = (time.perf_counter() - t0) / reps
+            tf = n * gf / el / 1e3
+            out[name] = {"frames": n, "ms": round(el * 1e3, 3), "frames_per_s": round(n / el, 1), "gflop_per_frame": gf,
+                         "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+    del vae
+    return out
+
+
 def cpu_baseline(budget_s=15.0):
     """Oracle forward (fp32, B=1) on the host cores: bounded sample of the same workload."""
     from oracle import unet as OU
@@ -121,19 +208,23 @@ def cpu_baseline(budget_s=15.0):
         for nthr in sorted({ncpu, min(ncpu, 32)}, reverse=True):
             torch.set_num_threads(nthr)
             OU.unet_forward(sd, V1_UNET_CFG, x, t, c)      # warm-up
-            n, t0 = 0, time.perf_counter()
+            times, t0 = [], time.perf_counter()
             while True:
+                t1 = time.perf_counter()
                 OU.unet_forward(sd, V1_UNET_CFG, x, t, c)
-                n += 1
+                times.append(time.perf_counter() - t1)
                 el = time.perf_counter() - t0
-                if el > budget_s / 2 or n >= 12:
+                if el > budget_s / 2 or len(times) >= 12:
                     break
-            if best is None or n / el > best[0]:
-                best = (n / el, nthr, n, el)
+            # host timing varies +-15 % run to run (other tenants of the box): the value is the best single forward, the spread is reported
+            if best is None or 1.0 / min(times) > best[0]:
+                best = (1.0 / min(times), nthr, len(times), el, len(times) / el, 1.0 / max(times))
         torch.set_num_threads(ncpu)
-    v, nthr, n, el = best
+    v, nthr, n, el, mean_rate, worst = best
     return {"value": round(v, 4), "unit": "steps/s", "cores": nthr, "kind": "port",
-            "sample": f"{n} oracle denoiser forwards (fp32, B=1, v1 config, torch CPU, {nthr} of {ncpu} threads) in {el:.1f} s"}
+            "mean": round(mean_rate, 4), "worst": round(worst, 4),
+            "sample": f"best of {n} oracle denoiser forwards (fp32, B=1, v1 config, torch CPU, {nthr} of {ncpu} threads) in {el:.1f} s; "
+                      f"mean {mean_rate:.3f}, slowest {worst:.3f} steps/s"}
 
 
 def self_launch(n_gpus):
@@ -345,6 +436,21 @@ def main():
                     el, Ss = timed_steps(Bs, lanes_for(Bs, args), k_extra, 3)
                     small[f"B{Bs}"] = {"value": round(Bs * k_extra / el, 2), "unit": "steps/s", "lanes": Ss, "ms_per_step": round(el / k_extra * 1e3, 4)}
 
+    # ---- the fp32-class engine (hi/lo split operands, 3 MFMAs per product: the form the <= 1e-3 parity claim is pinned with) at the
+    #      headline configuration: its throughput beside the bf16 headline ----
+    fp32_line = None
+    if not args.no_extra and not args.no_graph and args.config == "v1" and args.precision == "bf16" and world == 1:
+        ldm_bf16 = ldm
+        ldm = v1_model("fp32", device, args.config)
+        k32 = min(args.steps, 8)
+        el32, S32 = timed_steps(B, args.streams, k32, 2)
+        fp32_line = {"value": round(B * k32 / el32, 2), "unit": "steps/s", "dtype": "bf16x3 (hi/lo split operands, fp32-class accuracy)",
+                     "steps": k32, "ms_per_step": round(el32 / k32 * 1e3, 4), "trajectories_per_gpu": B, "lanes": S32,
+                     "parity": "v1 DDIM-50 vs the oracle loop 1.4e-5 rel-L2 (tests/test_hip_configs.py::test_v1_ddim50_vs_oracle)"}
+        del ldm
+        ldm = ldm_bf16
+        torch.cuda.empty_cache()
+
     if rank == 0:
         n_gpus = world
         value = n_gpus * B * args.steps / elapsed
@@ -382,6 +488,15 @@ def main():
                          "avg_launch_us": round(ker_s * 1e6, 2), "launches_per_step": launches * S,
                          "gflop_per_launch": round(flops_per_launch / 1e9, 3)},
         }
+        if S == 2 and args.config == "v1" and not args.no_extra:
+            # the same kernel as it runs in the timed configuration: both lanes active
+            ldm_b = v1_model(args.precision, device, args.config)
+            ker2_s, n2 = kernel_times_two_lanes(ldm, ldm_b, Bl, device, cond_shape=WL["cond"])
+            del ldm_b
+            ach2 = flops_per_launch / ker2_s / 1e12
+            line["roofline"]["in_situ"] = {"what": "average launch duration with both lanes active (two streams, HIP events per launch)",
+                                           "avg_launch_us": round(ker2_s * 1e6, 2), "achieved": round(ach2, 2),
+                                           "frac": round(ach2 / conv_peak, 4), "launches_timed": n2}
         if attn_s and args.config == "v1":
             # level-0 block: LN -> QKV (2*S*3C*C) -> core (4*S*vol*C) -> proj (2*S*C*C), S = 3328 tokens, C = 256, vol 13 or 16
             gf = Bl * (2 * 3328 * 768 * 256 + 2 * 3328 * 256 * 256 + 4 * 3328 * 15 * 256) / 1e9
@@ -393,6 +508,10 @@ def main():
             line["ensemble_strong_scaling"] = strong      # BASELINE configs[2]: ensemble=32 over the node's GPUs
         if small:
             line["small_batch"] = small                   # B in {1..16} beside the headline batch
+        if fp32_line is not None:
+            line["precision_fp32"] = fp32_line
+        if not args.no_extra and args.config == "v1" and n_gpus == 1:
+            line["vae"] = vae_times(device, trajectories=min(B, 32))
         if not args.no_cpu_baseline and n_gpus == 1 and args.config == "v1":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
