@@ -196,14 +196,6 @@ int pd_ffn_fused_supported(int C, int Hd);
 int pd_ffn_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* W1, const float* b1,
                  const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, pd_stream_t stream);
 
-/* The same block for C = 256 with the two GEMMs on different waves of the workgroup (producers: LN(x) W1^T + b1 -> act -> LDS;
- * consumers: += H W2^T one chunk behind; csrc/ffn_pc.hip).  W2_frag is W2 (256, Hd) in MFMA-fragment order:
- * [Hd/64 chunk j][4 cw][4 kk][2 ct][64 lanes][8] bf16, element e of lane (kh = lane >> 5, n = lane & 31) = W2[64 cw + 32 ct + n][64 j + 16 kk + 8 kh + e]
- * (prediff_amd/packing.py:pack_ffn_w2_frag).  Supported when pd_ffn_fused_pc_supported(C, Hd) (C == 256, Hd % 64 == 0, Hd >= 128). */
-int pd_ffn_fused_pc_supported(int C, int Hd);
-int pd_ffn_fused_pc(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* W1, const float* b1,
-                    const pd_bf16* W2_frag, const float* b2, int64_t M, int C, int Hd, int act, float eps, pd_stream_t stream);
-
 /* Fused cuboid self-attention block, bf16 engine:  out = x + proj(attention(qkv(LayerNorm(x))))  for head_dim 64 and cuboid volume
  * <= 64 (CuboidSelfAttentionLayer.forward cuboid_transformer.py:812-966 + the residual of :1151), in place allowed (out == x).
  * x/out (B, ntok, C) fp32; Wqkv (3C, C) and Wp (C, C) bf16 row-major; bqkv (3C) / bp (C) fp32 or NULL; tok_index, bias, mask
@@ -223,7 +215,7 @@ int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const
                            int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps, const int32_t* tok_affine,
                            pd_stream_t stream);
 /* Engine switches of the fused level-0 kernels (A/B measurements, tests): bit 0 in-place atomic epilogue, bit 1 deep weight ring for
- * launches of at most one workgroup per CU, bit 2 arithmetic token ids.  Default 7. */
+ * launches of at most one workgroup per CU, bit 2 arithmetic token ids.  Default 4 (bits 0 and 1 measured slower / neutral). */
 extern int pd_fused_opts;
 
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs

@@ -74,8 +74,6 @@ _PROTOS = {
     "pd_attn_block_fused": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),
     "pd_attn_block_fused_ex": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "pd_ffn_fused": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
-    "pd_ffn_fused_pc_supported": (C.c_int, [C.c_int, C.c_int]),
-    "pd_ffn_fused_pc": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -329,16 +327,6 @@ def fused_opts(value=None):
 
 def ffn_fused_supported(Cn, Hd):
     return bool(lib().pd_ffn_fused_supported(Cn, Hd))
-
-
-def ffn_fused_pc_supported(Cn, Hd):
-    return bool(lib().pd_ffn_fused_pc_supported(Cn, Hd))
-
-
-def ffn_fused_pc(x, out, gamma, beta, W1, b1, W2_frag, b2, M, Cn, Hd, act="gelu", eps=1e-5):
-    """Producer / consumer FFN kernel for units 256 (csrc/ffn_pc.hip); W2_frag from packing.pack_ffn_w2_frag."""
-    _check(lib().pd_ffn_fused_pc(ptr(x), ptr(out), ptr(gamma), ptr(beta), ptr(W1), ptr(b1), ptr(W2_frag), ptr(b2), M, Cn, Hd, ACT[act],
-                                 eps, stream_ptr()), "pd_ffn_fused_pc")
 
 
 def ffn_fused(x, out, gamma, beta, W1, b1, W2, b2, M, Cn, Hd, act="gelu", eps=1e-5):

@@ -687,8 +687,11 @@ extern "C" int pd_attn_block_fused_supported(int C, int heads, int vol) {
 }
 
 // Engine switches (A/B and tests): bit 0 atomic in-place epilogue, bit 1 deep weight ring for grids of at most one workgroup per CU,
-// bit 2 arithmetic token ids for affine cuboid tables.
-extern "C" int pd_fused_opts = 7;
+// bit 2 arithmetic token ids for affine cuboid tables.  Measured (profiles/r03_b_fused_opts_ab.log, 32 trajectories): the atomic
+// epilogue is SLOWER (122 -> 159 us: fp32 L2 atomics run far below the plain store rate), the deep ring gains nothing even with one
+// workgroup per CU (25.6 -> 27.3 us at 4 trajectories: DMA latency is not what a lone tile waits for), the arithmetic ids are
+// neutral.  So only bit 2 is on; the other two stay as opt-in switches with their bit-identity test.
+extern "C" int pd_fused_opts = 4;
 #define PD_NUM_CU 256
 
 extern "C" int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,

@@ -19,7 +19,6 @@ What is different is *how* the forward runs (inference only, no autograd):
     throughput mode the benchmark quotes.
 """
 import math
-import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -27,7 +26,7 @@ from torch import nn
 
 from . import _lib as L
 from .cuboid_geometry import attention_tables, relative_position_bias, relative_position_index
-from .packing import pack_conv, pack_conv_fp8, pack_ffn_w2_frag, pack_linear, pad64
+from .packing import pack_conv, pack_conv_fp8, pack_linear, pad64
 from .patterns import CuboidSelfAttentionPatterns
 
 
@@ -336,7 +335,6 @@ class CuboidTransformerUNet(nn.Module):
         self.fp8_conv = precision == "fp8"
         self.precision = "bf16" if self.fp8_conv else precision
         self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
-        self.ffn_variant = os.environ.get("PD_FFN_VARIANT", "pc")   # units 256: "pc" = producer/consumer waves (csrc/ffn_pc.hip), "64" = ffn64_kernel
         self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 64)
         self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
         self.input_shape, self.target_shape = input_shape, target_shape
@@ -548,8 +546,6 @@ class CuboidTransformerUNet(nn.Module):
             for a, ff in enumerate(blk.ffn_l):
                 n = f"{name}.ffn{a}"
                 norm(n + ".ln", ff.layer_norm); lin(n + ".fc1", ff.ffn_1); lin(n + ".fc2", ff.ffn_2)
-                if not split and not ff.gated and L.ffn_fused_pc_supported(ff.ffn_2.out_features, ff.ffn_1.out_features):
-                    P[n + ".fc2.wf"] = pack_ffn_w2_frag(ff.ffn_2.weight.to(device))     # fragment order for the consumer waves (csrc/ffn_pc.hip)
                 if ff.gated:
                     lin(n + ".gate", ff.ffn_1_gate)
 
@@ -740,11 +736,6 @@ class CuboidTransformerUNet(nn.Module):
         ld = pad64(C)
         Hd = ff.ffn_1.out_features
         ldh = pad64(Hd)
-        if self.precision == "bf16" and self.fuse_ffn and self.ffn_variant == "pc" and (name + ".fc2.wf") in P:
-            # units 256: GEMM-1 + activation and GEMM-2 on different waves of the workgroup (csrc/ffn_pc.hip)
-            L.ffn_fused_pc(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".fc1.w"][0], P[name + ".fc1.b"], P[name + ".fc2.wf"],
-                           P[name + ".fc2.b"], B * S, C, Hd, act=ff.activation_name)
-            return
         if self.precision == "bf16" and self.fuse_ffn and not ff.gated and L.ffn_fused_supported(C, Hd):
             # one launch, hidden activations never leave the CU (csrc/ffn.hip)
             L.ffn_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".fc1.w"][0], P[name + ".fc1.b"], P[name + ".fc2.w"][0],

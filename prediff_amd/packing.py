@@ -41,17 +41,6 @@ def pack_conv(weight: torch.Tensor, split: bool, c_pad: Optional[int] = None):
     return split_bf16(w, split)
 
 
-def pack_ffn_w2_frag(weight: torch.Tensor) -> torch.Tensor:
-    """ffn_2 weight (256, Hd) -> bf16 in the MFMA-fragment order pd_ffn_fused_pc's consumer waves load straight into registers
-    (csrc/ffn_pc.hip): [Hd/64 chunk j][4 consumers cw][4 k-steps kk][2 column tiles ct][64 lanes][8], where element e of lane
-    (kh = lane >> 5, n = lane & 31) is W2[64 cw + 32 ct + n][64 j + 16 kk + 8 kh + e] -- the B operand of v_mfma_f32_32x32x16_bf16,
-    1 KB contiguous per wave instruction."""
-    Cn, Hd = weight.shape
-    assert Cn == 256 and Hd % 64 == 0
-    w = weight.detach().to(torch.bfloat16).reshape(4, 2, 32, Hd // 64, 4, 2, 8)      # cw, ct, n, j, kk, kh, e
-    return w.permute(3, 0, 4, 1, 5, 2, 6).contiguous().reshape(-1)                   # j, cw, kk, ct, kh, n, e
-
-
 # ---------------------------------------------------------------------------------------------------- fp8 (OCP e4m3) operands
 FP8_MAX = 448.0          # largest finite e4m3fn value
 

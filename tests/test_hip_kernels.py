@@ -415,48 +415,6 @@ def test_ffn_fused(M, Cn, act):
     assert torch.equal(xin, out)
 
 
-@pytest.mark.parametrize("M,Hd,act", [(64, 128, "gelu"), (832 * 4, 1024, "gelu"), (1000, 1024, "gelu"), (3328 * 3 + 17, 1024, "gelu"),
-                                      (777, 512, "leaky"), (130, 256, "gelu")])
-def test_ffn_fused_pc(M, Hd, act):
-    """pd_ffn_fused_pc (units 256: producer / consumer waves, W2 in fragment order) against the same-rounding fp32 statement, the
-    un-rounded fp32 statement, and pd_ffn_fused (ffn64_kernel: the same per-element accumulation order -> bit-identical)."""
-    from prediff_amd.packing import pack_ffn_w2_frag
-    Cn = 256
-    g = torch.Generator(device="cpu").manual_seed(M + Hd)
-    x = (torch.randn(M, Cn, generator=g) * 2 + 0.3 + torch.arange(M)[:, None] * 1e-4).to(DEV)
-    gamma, beta = (1 + 0.1 * torch.randn(Cn, generator=g)).to(DEV), (0.1 * torch.randn(Cn, generator=g)).to(DEV)
-    w1 = (torch.randn(Hd, Cn, generator=g) / math.sqrt(Cn)).to(DEV)
-    w2 = (torch.randn(Cn, Hd, generator=g) / math.sqrt(Hd)).to(DEV)
-    b1, b2 = torch.randn(Hd, generator=g).to(DEV) * 0.1, torch.randn(Cn, generator=g).to(DEV) * 0.1
-    w1p, _ = pack_linear(w1, False)
-    w2p, _ = pack_linear(w2, False)
-    w2f = pack_ffn_w2_frag(w2)
-    assert L.ffn_fused_pc_supported(Cn, Hd) and not L.ffn_fused_pc_supported(512, 2048) and not L.ffn_fused_pc_supported(128, 512)
-    out = torch.full_like(x, float("nan"))
-    L.ffn_fused_pc(x, out, gamma, beta, w1p, b1, w2f, b2, M, Cn, Hd, act=act)
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(out).all())
-    actf = F.gelu if act == "gelu" else (lambda v: F.leaky_relu(v, 0.1))
-    h = bf(actf(bf(F.layer_norm(x, (Cn,), gamma, beta, 1e-5)) @ bf(w1).t() + b1))
-    ref = x + h @ bf(w2).t() + b2
-    assert rel_l2(out, ref) < 2e-4
-    full = x + actf(F.layer_norm(x, (Cn,), gamma, beta, 1e-5) @ w1.t() + b1) @ w2.t() + b2
-    assert rel_l2(out, full) < 6e-3
-    o64 = torch.empty_like(x)
-    L.ffn_fused(x, o64, gamma, beta, w1p, b1, w2p, b2, M, Cn, Hd, act=act)
-    e = rel_l2(out, o64)
-    print(f"[ffn_fused_pc M={M} Hd={Hd}] vs ffn64: rel-L2 {e:.3e}, bit-identical {torch.equal(out, o64)}")
-    assert e < 1e-5
-    xin = x.clone()
-    L.ffn_fused_pc(xin, xin, gamma, beta, w1p, b1, w2f, b2, M, Cn, Hd, act=act)      # in place
-    assert torch.equal(xin, out)
-    # deterministic across launches (the consumers' counted waits, not luck, order the fragment loads)
-    for _ in range(5):
-        o2 = torch.empty_like(x)
-        L.ffn_fused_pc(x, o2, gamma, beta, w1p, b1, w2f, b2, M, Cn, Hd, act=act)
-        assert torch.equal(o2, out)
-
-
 # ------------------------------------------------------------------------------------------------ fused attention block
 ATTN_BLOCK = [((13, 16, 16), (13, 1, 1), (0, 0, 0), "zeros", 256, 4, 2), ((13, 16, 16), (1, 16, 1), (0, 0, 0), "zeros", 256, 4, 3),
               ((13, 16, 16), (1, 1, 16), (0, 0, 0), "zeros", 256, 4, 1), ((5, 8, 8), (1, 8, 1), (0, 0, 0), "zeros", 128, 2, 3),
