@@ -47,7 +47,8 @@ WORKLOADS = {
                      "no knowledge alignment (BASELINE.json configs[1])", precision="bf16"),
     "fullres": dict(unet="FULLRES_UNET_CFG", ldm="FULLRES_LDM_KW", cond=(13, 48, 48, 64), unet_gflop=11360.0, conv3d_gflop=6920.0, tokens=57600,
                     label="SEVIR full-res 13->12 x384x384 (latent 25x48x48, C 256/512, depth [4,4], axial cuboids 25/48/48), DDIM-50 "
-                          "eta=0 (BASELINE.json configs[4]; fp8 = e4m3 operands for the Conv3d launches, the other GEMMs stay bf16)",
+                          "eta=0 (BASELINE.json configs[4]; fp8 = e4m3 operands for the Conv3d launches and the K >= 512 token linears -- qkv / proj / FFN of "
+                          "the level-1 blocks --, bf16 for the fused level-0 blocks)",
                     precision="fp8"),
 }
 CONV3D_LAUNCHES_PER_STEP = 34
@@ -263,7 +264,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="latent trajectories (ensemble members) per GPU")
     ap.add_argument("--streams", type=int, default=2, help="lanes: the batch advances as this many equal sub-batches on concurrent HIP streams")
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp32", "fp8"],
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32", "fp8", "fp8_conv"],
                     help="operand type; default: the one BASELINE.json quotes the workload on (v1: bf16, fullres: fp8)")
     ap.add_argument("--config", default="v1", choices=sorted(WORKLOADS), help="v1 = BASELINE configs[1] (the metric); fullres = configs[4] geometry, bf16")
     ap.add_argument("--no-graph", action="store_true")
@@ -460,21 +461,24 @@ def main():
         achieved = flops_per_launch / ker_s / 1e12
         traffic = None
         tp = os.path.join(ROOT, "profiles", "conv3d_hbm_traffic.json")
-        if os.path.exists(tp) and args.config == "v1" and args.precision in ("bf16", "fp8"):
+        if os.path.exists(tp) and args.config == "v1" and args.precision in ("bf16", "fp8", "fp8_conv"):
             try:
                 traffic = json.load(open(tp)).get(f"B{Bl}" + ("" if args.precision == "bf16" else "_fp8"))
             except Exception:
                 traffic = None
-        # --precision fp8: e4m3 operands for the Conv3d launches only (the dominant kernel, priced against the fp8 peak); every other
+        # --precision fp8 / fp8_conv: the Conv3d launches (the dominant kernel) run on e4m3 operands and are priced against the fp8 peak; every other
         # GEMM of the step stays bf16
-        conv_peak = PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS
+        conv_peak = PEAK_FP8_TFLOPS if args.precision.startswith("fp8") else PEAK_BF16_TFLOPS
         line = {
             "metric": "denoising_steps_per_sec", "value": round(value, 2), "unit": "steps/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "bf16x3", "fp8": "fp8"}[args.precision],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "bf16x3", "fp8": "fp8", "fp8_conv": "fp8"}[args.precision],
             "data": "synthetic (seeded random weights of the v1 architecture, N(0,1) latents/context)",
             "config": {"workload": WL["label"],
-                       **({"operands": "e4m3 x e4m3 (scaled K=128 MFMA) for the 3x3x3 Conv3d launches, bf16 elsewhere"} if args.precision == "fp8" else {}),
+                       **({"operands": "e4m3 x e4m3 (scaled K=128 MFMA) for the 3x3x3 Conv3d launches and the K >= 512 linears (qkv, proj, FFN-1, FFN-2 of the "
+                                       "level-1 blocks; e4m3 A operands written by LayerNorm, the attention core and the FFN-1 epilogue); bf16 in the "
+                                       "fused level-0 attention / FFN kernels, the K = 256 linears and the VAE"} if args.precision == "fp8" else
+                          {"operands": "e4m3 x e4m3 (scaled K=128 MFMA) for the 3x3x3 Conv3d launches, bf16 elsewhere"} if args.precision == "fp8_conv" else {}),
                        "trajectories_per_gpu": B, "global_trajectories": B * n_gpus, "sampler": "ddim50", "hip_graph": not args.no_graph,
                        "lanes": S, "trajectories_per_launch": Bl,
                        "parallelism": f"ensemble-shard x{n_gpus}"},

@@ -75,7 +75,9 @@ typedef struct pd_igemm_args {
   int32_t fp8;             /* != 0: A and W hold OCP e4m3 bytes (lda / ldw / strides count elements = bytes; Cin % 128 == 0, lda/ldw % 16 == 0);
                               the tensor scales go in alpha.  Long-K row-wise linear and stride-1 convolution launches only (the 256 x 256
                               kernel, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales); no split, no batch */
-  int32_t reserved0;
+  int32_t out_fp8_log2;    /* k > 0: out_bf16 points to OCP e4m3 BYTES (ld_outb counts bytes) and receives e4m3(v * 2^k), round to nearest
+                              even, saturating at +-448 -- the A operand of a following fp8 launch (8-column vector epilogue: N % 8 == 0,
+                              no out_bf16_lo).  0: bf16 output */
 } pd_igemm_args;
 int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
 
@@ -83,6 +85,11 @@ int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
  * (pad columns [C, ld_out) are written as zero).  cuboid_transformer.py:813 (attn pre-norm), :197 (FFN pre-norm). */
 int pd_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
                  int64_t rows, int C, int ld_out, float eps, pd_stream_t stream);
+
+/* pd_layernorm with an OCP e4m3 output (the A operand of an fp8 pd_igemm launch): out[row, c] = e4m3(y * fp8_scale), round to nearest
+ * even, saturating at +-448; rows of ld_out bytes (pad columns zero). */
+int pd_layernorm_fp8(const float* x, const float* gamma, const float* beta, uint8_t* out, int64_t rows, int C, int ld_out, float eps,
+                     float fp8_scale, pd_stream_t stream);
 
 /* PatchMerging3D gather + LayerNorm(prod(ds)*C): x (B,T,H,W,C) fp32 -> (B,T/dt,H/dh,W/dw, dt*dh*dw*C) bf16, zero padding at
  * the far edge.  cuboid_transformer.py:274-293. */
@@ -135,6 +142,8 @@ typedef struct pd_cuboid_attn_args {
   int32_t B, ntok, C, heads, nc, vol, ld_qkv, ld_out;
   float scale;
   int32_t force_generic;
+  int32_t out_fp8_log2;      /* k > 0 (MFMA cores, cuboid volume <= 64 only): out_bf16 points to e4m3 BYTES (ld_out counts bytes) and receives
+                                e4m3(o * 2^k), round to nearest even, saturating: the A operand of an fp8 proj launch.  0: bf16 output */
 } pd_cuboid_attn_args;
 int pd_cuboid_attention(const pd_cuboid_attn_args* a, pd_stream_t stream);
 

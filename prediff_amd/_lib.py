@@ -31,14 +31,14 @@ class IgemmArgs(C.Structure):
                  "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw", "ut", "uh", "uw", "vT", "vH", "vW",
                  "rows_per_sample", "ld_rowvec", "ld_res", "res_period", "ld_mul", "act", "ld_out", "ld_outb", "split")] + \
                [("alpha", C.c_float), ("tile", C.c_int32), ("vec_epilogue", C.c_int32), ("a_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("debug_flags", C.c_int32), ("ksplit", C.c_int32),
-                ("splitk_ws", C.c_void_p), ("splitk_ws_elems", C.c_int64), ("fp8", C.c_int32), ("reserved0", C.c_int32)]
+                ("splitk_ws", C.c_void_p), ("splitk_ws_elems", C.c_int64), ("fp8", C.c_int32), ("out_fp8_log2", C.c_int32)]
 
 
 class CuboidAttnArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("qkv_bf16", "qkv_f32", "tok_index", "bias", "mask", "out_bf16", "out_bf16_lo", "out_f32")] + \
                [(n, C.c_int32) for n in ("B", "ntok", "C", "heads", "nc", "vol", "ld_qkv", "ld_out")] + \
-               [("scale", C.c_float), ("force_generic", C.c_int32)]
+               [("scale", C.c_float), ("force_generic", C.c_int32), ("out_fp8_log2", C.c_int32)]
 
 
 _lib = None
@@ -50,6 +50,7 @@ _PROTOS = {
     "pd_sizeof_cuboid_attn_args": (C.c_int, []),
     "pd_igemm": (C.c_int, [C.POINTER(IgemmArgs), C.c_void_p]),
     "pd_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "pd_layernorm_fp8": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "pd_patch_merge_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_void_p]),
     "pd_groupnorm_nchunk": (C.c_int, [C.c_int, C.c_int]),
     "pd_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 +
@@ -145,7 +146,7 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
           A_lo=None, W_lo=None, bias=None, rowvec=None, rows_per_sample=0, residual=None, res_period=0,
           ld_res=None, mul=None, act="none", alpha=1.0, out_f32=None, out_bf16=None, out_bf16_lo=None,
           ld_out=None, ld_outb=None, nbatch=1, a_batch_stride=0, w_batch_stride=0, out_batch_stride=0,
-          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None, fp8=False):
+          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None, fp8=False, out_fp8_log2=0):
     """Thin wrapper around pd_igemm.  `geom` = dict(B,Ti,Hi,Wi,To,Ho,Wo,KT,KH,KW,st,sh,sw,pt,ph,pw,ut,uh,uw) or None
     for a plain linear layer."""
     a = IgemmArgs()
@@ -176,6 +177,7 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
     a.tile = tile
     a.debug_flags = debug_flags
     a.fp8 = 1 if fp8 else 0           # A / W are e4m3 bytes (torch.float8_e4m3fn); tensor scales in alpha
+    a.out_fp8_log2 = out_fp8_log2     # k > 0: out_bf16 is an e4m3 byte tensor receiving e4m3(v * 2^k)
     if splitk_ws is not None:       # fp32 workspace: lets the library split the K loop of small-grid, long-K launches
         a.splitk_ws, a.splitk_ws_elems = ptr(splitk_ws), splitk_ws.numel()
     _check(lib().pd_igemm(C.byref(a), stream_ptr()), "pd_igemm")
@@ -197,6 +199,12 @@ def conv_geom(B, in_thw, kernel, stride=(1, 1, 1), pad=(1, 1, 1), up=(1, 1, 1), 
 def layernorm(x, gamma, beta, out, out_lo, rows, Cn, ld_out, eps=1e-5):
     _check(lib().pd_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(out_lo), rows, Cn, ld_out, eps, stream_ptr()),
            "pd_layernorm")
+
+
+def layernorm_fp8(x, gamma, beta, out, rows, Cn, ld_out, fp8_scale, eps=1e-5):
+    """LayerNorm -> e4m3 rows (value * fp8_scale, saturating): the A operand of an fp8 pd_igemm launch."""
+    _check(lib().pd_layernorm_fp8(ptr(x), ptr(gamma), ptr(beta), ptr(out), rows, Cn, ld_out, eps, fp8_scale, stream_ptr()),
+           "pd_layernorm_fp8")
 
 
 def patch_merge_layernorm(x, gamma, beta, out, out_lo, B, T, H, W, Cn, ds, ld_out, eps=1e-5):
@@ -231,13 +239,14 @@ def cast_rows(x, out, out_lo, n_samples, rows_in, row_off, rows_out, Cn, ld_in, 
 
 
 def cuboid_attention(*, qkv_bf16=None, qkv_f32=None, tok_index, bias, mask, out_bf16=None, out_bf16_lo=None,
-                     out_f32=None, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out, scale, force_generic=False):
+                     out_f32=None, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out, scale, force_generic=False, out_fp8_log2=0):
     a = CuboidAttnArgs()
     a.qkv_bf16, a.qkv_f32, a.tok_index, a.bias, a.mask = ptr(qkv_bf16), ptr(qkv_f32), ptr(tok_index), ptr(bias), ptr(mask)
     a.out_bf16, a.out_bf16_lo, a.out_f32 = ptr(out_bf16), ptr(out_bf16_lo), ptr(out_f32)
     a.B, a.ntok, a.C, a.heads, a.nc, a.vol, a.ld_qkv, a.ld_out = B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out
     a.scale = scale
     a.force_generic = 1 if force_generic else 0
+    a.out_fp8_log2 = out_fp8_log2     # k > 0: out_bf16 is an e4m3 byte tensor receiving e4m3(o * 2^k) (MFMA cores only)
     _check(lib().pd_cuboid_attention(C.byref(a), stream_ptr()), "pd_cuboid_attention")
 
 

@@ -133,10 +133,10 @@ class AutoencoderKL(nn.Module):
         super().__init__()
         if act_fn not in ("silu", "swish"):
             raise NotImplementedError(f"act_fn={act_fn!r}: only SiLU is fused in the GroupNorm kernel")
-        if precision not in ("bf16", "fp32", "fp8"):
-            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
+        if precision not in ("bf16", "fp32", "fp8", "fp8_conv"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'fp8' or 'fp8_conv'")
         # "fp8" is a denoiser option (e4m3 operands for its 3x3x3 convolutions); the VAE has no such launches and runs its bf16 engine
-        self.precision = "bf16" if precision == "fp8" else precision
+        self.precision = "bf16" if precision.startswith("fp8") else precision
         self.latent_channels, self.norm_num_groups = latent_channels, norm_num_groups
         self.encoder = Encoder(in_channels, latent_channels, down_block_types, block_out_channels, layers_per_block, norm_num_groups)
         self.decoder = Decoder(latent_channels, out_channels, up_block_types, block_out_channels, layers_per_block, norm_num_groups)

@@ -140,9 +140,16 @@ __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_a
     asm volatile("s_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
     // lane: query, d = d0 + 4g + r
     if (orow) {
-      const uint32_t lo = pack_bf16x2(o[0], o[1]);
-      const uint32_t hi = pack_bf16x2(o[2], o[3]);
-      *(uint2*)(orow + d0) = make_uint2(lo, hi);
+      if (p.out_fp8_log2 > 0) {         // e4m3 bytes, value * 2^k, saturating: the A operand of an fp8 proj launch
+        const float f8s = __builtin_amdgcn_ldexpf(1.0f, p.out_fp8_log2);
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o[0] * f8s, -448.f), 448.f), fminf(fmaxf(o[1] * f8s, -448.f), 448.f), 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o[2] * f8s, -448.f), 448.f), fminf(fmaxf(o[3] * f8s, -448.f), 448.f), w, true);
+        *(int*)((uint8_t*)p.out_bf16 + ((int64_t)b * p.ntok + qtok) * p.ld_out + h * hd + 4 * g + d0) = w;
+      } else {
+        const uint32_t lo = pack_bf16x2(o[0], o[1]);
+        const uint32_t hi = pack_bf16x2(o[2], o[3]);
+        *(uint2*)(orow + d0) = make_uint2(lo, hi);
+      }
     }
   }
 }
@@ -336,6 +343,10 @@ extern "C" int pd_cuboid_attention(const pd_cuboid_attn_args* pa, pd_stream_t st
   const int64_t nitems = (int64_t)a.B * a.nc * a.heads;
   const bool mfma_ok = a.qkv_bf16 && a.vol <= 64 && (hd % 32) == 0 && a.out_bf16 && !a.out_f32 && !a.out_bf16_lo &&
                        (a.ld_qkv % 8) == 0 && (a.ld_out % 4) == 0 && !a.force_generic;
+  if (a.out_fp8_log2 > 0 && !mfma_ok) {
+    pd_set_error("pd_cuboid_attention: an e4m3 output is built for the MFMA cores only (bf16 q/k/v, cuboid volume <= 64, head_dim %% 32 == 0, out_bf16 alone)");
+    return PD_ERR_UNSUPPORTED;
+  }
   if (mfma_ok) {
     const int kt = (a.vol + 15) / 16;
     const int64_t nwaves = nitems * kt;                  // one wave per 16-query tile

@@ -317,6 +317,10 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
   if (a.vec_epilogue && !a.out_f32 && a.out_bf16 && (a.N & 7) == 0 && (a.ld_outb & 7) == 0 && (a.outb_batch_stride & 7) == 0 &&
       (((uintptr_t)a.out_bf16 | (uintptr_t)a.out_bf16_lo) & 15) == 0)
     a.vec_epilogue = 2;   // 16 B bf16 stores
+  if (a.out_fp8_log2 > 0) {
+    PD_CHECK_ARG(a.vec_epilogue == 2 && !a.out_bf16_lo && !a.split && a.out_fp8_log2 <= 16,
+                 "pd_igemm: an e4m3 output needs the 8-column vector epilogue (out_bf16 only, N %% 8 == 0, ld_outb %% 8 == 0, 16 B aligned), no split");
+  }
   int tile = a.tile ? a.tile : pd_igemm_default_tile;
   // a 1-tap, stride-1, unpadded, un-upsampled "convolution" is a plain row-wise linear layer: row m reads A row m
   const bool pointwise = a.taps == 1 && a.st == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.ph == 0 && a.pw == 0 && a.ut == 1 &&

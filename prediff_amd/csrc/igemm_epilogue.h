@@ -62,7 +62,20 @@ __device__ __forceinline__ void igemm_epilogue_rows(const pd_igemm_args& p, cons
         for (int q = 0; q < CW / 4; ++q)
           *(float4*)(outf + (int64_t)m * p.ld_out + n + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
       }
-      if (has_ob) {
+      if (CW == 8 && has_ob && p.out_fp8_log2 > 0) {
+        // e4m3 bytes, value * 2^k, round to nearest even, saturating: the A operand of a following fp8 launch
+        const float f8s = __builtin_amdgcn_ldexpf(1.0f, p.out_fp8_log2);
+        int w[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float y[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) y[k] = fminf(fmaxf(v[4 * q + k] * f8s, -448.f), 448.f);
+          w[q] = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+          w[q] = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w[q], true);
+        }
+        *(uint2*)((uint8_t*)outb + (int64_t)m * p.ld_outb + n) = make_uint2((uint32_t)w[0], (uint32_t)w[1]);
+      } else if (has_ob) {
         uint32_t hi[CW / 2], lo[CW / 2];
 #pragma unroll
         for (int e = 0; e < CW / 2; ++e) {

@@ -10,11 +10,12 @@ constexpr int LN_MAXV = 16;   // up to 64*4*16 = 4096 channels per row
 
 // NV = float4 vectors per lane per row (ceil(C/256)), R = rows handled concurrently by one wave (independent load /
 // reduce chains keep R x NV 16 B loads in flight per lane: the kernel is pure HBM streaming).
-template <bool GATHER, int NV, int R>
+// F8: the output is OCP e4m3, value * fp8_scale, saturating (v_cvt_pk_fp8_f32 rounds to nearest even), one byte per channel.
+template <bool GATHER, int NV, int R, bool F8 = false>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, pd_bf16* __restrict__ out,
                                                         pd_bf16* __restrict__ out_lo, int64_t rows, int C, int ld_out,
-                                                        float eps,
+                                                        float eps, float fp8_scale,
                                                         // patch-merge gather geometry (GATHER only)
                                                         int T, int H, int W, int Cs, int dt, int dh, int dw) {
   const int lane = threadIdx.x & 63;
@@ -91,7 +92,13 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         y[2] = (v[r][j].z - mean[r]) * rstd[r] * g.z + be.z;
         y[3] = (v[r][j].w - mean[r]) * rstd[r] * g.w + be.w;
       }
-      if (out_lo) {
+      if (F8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = fminf(fmaxf(y[k] * fp8_scale, -448.f), 448.f);
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
+        *(int*)((uint8_t*)out + row * (int64_t)ld_out + c) = w;
+      } else if (out_lo) {
         uint16_t hi[4], lo[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) f2bf_split(y[k], hi[k], lo[k]);
@@ -105,13 +112,13 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
-template <bool GATHER>
+template <bool GATHER, bool F8 = false>
 static void launch_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo, int64_t rows, int C,
-                             int ld_out, float eps, int T, int H, int W, int Cs, int dt, int dh, int dw, hipStream_t s) {
+                             int ld_out, float eps, int T, int H, int W, int Cs, int dt, int dh, int dw, hipStream_t s, float fp8_scale = 0.f) {
   const int nv = (C + 255) / 256;
 #define PD_LN(NV, R)                                                                                                              \
-  hipLaunchKernelGGL((layernorm_kernel<GATHER, NV, R>), dim3((unsigned)((rows + 4 * (R) - 1) / (4 * (R)))), dim3(256), 0, s, x, gamma, \
-                     beta, out, out_lo, rows, C, ld_out, eps, T, H, W, Cs, dt, dh, dw)
+  hipLaunchKernelGGL((layernorm_kernel<GATHER, NV, R, F8>), dim3((unsigned)((rows + 4 * (R) - 1) / (4 * (R)))), dim3(256), 0, s, x, gamma, \
+                     beta, out, out_lo, rows, C, ld_out, eps, fp8_scale, T, H, W, Cs, dt, dh, dw)
   if (nv <= 1) PD_LN(1, 4);
   else if (nv <= 2) PD_LN(2, 2);
   else if (nv <= 4) PD_LN(4, 1);
@@ -128,6 +135,19 @@ extern "C" int pd_layernorm(const float* x, const float* gamma, const float* bet
                "pd_layernorm: ld_out=%d must be >= C, multiple of 4 and within the last 256-column block", ld_out);
   if (rows <= 0) return PD_OK;
   launch_layernorm<false>(x, gamma, beta, out, out_lo, rows, C, ld_out, eps, 0, 0, 0, 0, 1, 1, 1, (hipStream_t)stream);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
+extern "C" int pd_layernorm_fp8(const float* x, const float* gamma, const float* beta, uint8_t* out, int64_t rows, int C, int ld_out,
+                                float eps, float fp8_scale, pd_stream_t stream) {
+  PD_CHECK_ARG(x && gamma && beta && out && fp8_scale > 0.f, "pd_layernorm_fp8: null pointer / bad scale");
+  PD_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 256 * LN_MAXV, "pd_layernorm_fp8: C=%d must be a multiple of 4 and <= %d", C, 256 * LN_MAXV);
+  PD_CHECK_ARG(ld_out >= C && (ld_out & 3) == 0 && ld_out <= ((C + 255) / 256) * 256,
+               "pd_layernorm_fp8: ld_out=%d must be >= C, multiple of 4 and within the last 256-column block", ld_out);
+  if (rows <= 0) return PD_OK;
+  launch_layernorm<false, true>(x, gamma, beta, (pd_bf16*)out, nullptr, rows, C, ld_out, eps, 0, 0, 0, 0, 1, 1, 1, (hipStream_t)stream,
+                                fp8_scale);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }

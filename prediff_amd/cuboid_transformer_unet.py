@@ -26,7 +26,7 @@ from torch import nn
 
 from . import _lib as L
 from .cuboid_geometry import attention_tables, relative_position_bias, relative_position_index
-from .packing import pack_conv, pack_conv_fp8, pack_linear, pad64
+from .packing import pack_conv, pack_conv_fp8, pack_linear, pack_linear_fp8, pad64
 from .patterns import CuboidSelfAttentionPatterns
 
 
@@ -327,12 +327,16 @@ class CuboidTransformerUNet(nn.Module):
             raise NotImplementedError(f"norm_layer={norm_layer!r}")
         if downsample_type != "patch_merge" or upsample_type != "upsample":
             raise NotImplementedError
-        if precision not in ("bf16", "fp32", "fp8"):
-            raise ValueError("precision must be 'bf16' (throughput), 'fp32' (hi/lo split, fp32-class accuracy) or 'fp8' "
-                             "(bf16 engine with e4m3 operands for the 3x3x3 convolutions)")
-        # "fp8": the bf16 engine with the TimeEmbedResBlock convolutions (45 % of the FLOPs, the long-K launches) on OCP e4m3
-        # operands through the scaled K = 128 MFMA; everything else as in "bf16".  Accuracy is report-only (BASELINE config 5).
-        self.fp8_conv = precision == "fp8"
+        if precision not in ("bf16", "fp32", "fp8", "fp8_conv"):
+            raise ValueError("precision must be 'bf16' (throughput), 'fp32' (hi/lo split, fp32-class accuracy), 'fp8_conv' (bf16 engine with "
+                             "e4m3 operands for the 3x3x3 convolutions) or 'fp8' (e4m3 for the convolutions and the K >= 512 token linears)")
+        # "fp8_conv": the bf16 engine with the TimeEmbedResBlock convolutions (45 % of the FLOPs, the long-K launches) on OCP e4m3
+        # operands through the scaled K = 128 MFMA; everything else as in "bf16".  "fp8" (BASELINE config 5's operand type): also the
+        # K >= 512 token linears (qkv / proj / FFN of the level >= 1 blocks), their A operands written as e4m3 by LayerNorm, the attention
+        # core and the FFN-1 epilogue.  Accuracy is report-only: 3 mantissa bits cost 3-4 % per forward with the convolutions alone and
+        # 6 % with the linears as well (tests/test_hip_configs.py prints both).
+        self.fp8_conv = precision in ("fp8", "fp8_conv")
+        self.fp8_linear = precision == "fp8"
         self.precision = "bf16" if self.fp8_conv else precision
         self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
         self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 64)
@@ -495,7 +499,7 @@ class CuboidTransformerUNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ packing
     def _params_key(self, device):
-        return (str(device), self.precision, self.fp8_conv) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (str(device), self.precision, self.fp8_conv, self.fp8_linear) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self, device):
         """fp32 checkpoint tensors -> K-contiguous bf16 (hi[/lo]) operands + fp32 epilogue vectors (once per weight version)."""
@@ -505,9 +509,13 @@ class CuboidTransformerUNet(nn.Module):
         def f32(t):
             return t.detach().float().contiguous().to(device)
 
-        def lin(name, m: nn.Linear):
+        def lin(name, m: nn.Linear, fp8_ok=False):
             P[name + ".w"] = pack_linear(m.weight.to(device), split)
             P[name + ".b"] = f32(m.bias) if m.bias is not None else None
+            # precision="fp8": the long-K token linears (K >= 512: the level >= 1 blocks) on e4m3 operands too -- pd_igemm's fp8 form needs
+            # K % 128 == 0, and an e4m3-producing epilogue in front of it needs N % 8 == 0
+            if fp8_ok and self.fp8_linear and m.in_features >= 512 and m.in_features % 128 == 0 and m.out_features % 8 == 0:
+                P[name + ".w8"] = pack_linear_fp8(m.weight.to(device))                   # (e4m3 (N, K), scale)
 
         def conv(name, m):
             P[name + ".w"] = pack_conv(m.weight.to(device), split)
@@ -535,9 +543,9 @@ class CuboidTransformerUNet(nn.Module):
         def stack(name, blk: StackCuboidSelfAttentionBlock, level):
             for a, at in enumerate(blk.attn_l):
                 n = f"{name}.attn{a}"
-                norm(n + ".ln", at.norm); lin(n + ".qkv", at.qkv)
+                norm(n + ".ln", at.norm); lin(n + ".qkv", at.qkv, fp8_ok=True)
                 if at.use_final_proj:
-                    lin(n + ".proj", at.proj)
+                    lin(n + ".proj", at.proj, fp8_ok=True)
                 vol = self._geom[level][a]["vol"]
                 if at.use_relative_pos:
                     P[n + ".bias"] = relative_position_bias(at.relative_position_bias_table, at.relative_position_index.cpu(), vol).to(device)
@@ -545,7 +553,7 @@ class CuboidTransformerUNet(nn.Module):
                     P[n + ".bias"] = torch.zeros(at.num_heads, vol, vol, device=device)
             for a, ff in enumerate(blk.ffn_l):
                 n = f"{name}.ffn{a}"
-                norm(n + ".ln", ff.layer_norm); lin(n + ".fc1", ff.ffn_1); lin(n + ".fc2", ff.ffn_2)
+                norm(n + ".ln", ff.layer_norm); lin(n + ".fc1", ff.ffn_1, fp8_ok=not ff.gated); lin(n + ".fc2", ff.ffn_2, fp8_ok=not ff.gated)
                 if ff.gated:
                     lin(n + ".gate", ff.ffn_1_gate)
 
@@ -606,6 +614,7 @@ class CuboidTransformerUNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ building blocks
     FP8_ACT_SCALE = 16.0      # GroupNorm -> SiLU outputs are O(1): x16 keeps |y| < 28 in range and 1e-3 above the subnormals
+    FP8_ACT_LOG2 = 4          # the same scale for the LayerNorm / attention-core / FFN-1 outputs of the fp8 linears (2^4)
 
     def _gn_fp8(self, x, g, beta, B, S, C, G, name, dev, ss=None):
         """GroupNorm -> SiLU -> e4m3 rows (value * FP8_ACT_SCALE), the A operand of an fp8 convolution launch."""
@@ -704,6 +713,22 @@ class CuboidTransformerUNet(nn.Module):
                                P[name + ".proj.w"][0], P[name + ".proj.b"], tabs["tok"], P[name + ".bias"], tabs["mask"],
                                B, S, C, at.num_heads, geo["nc"], geo["vol"], float(at.scale), tok_affine=geo.get("affine"))
             return
+        if (name + ".qkv.w8") in P and (name + ".proj.w8") in P and geo["vol"] <= 64 and (C // at.num_heads) % 32 == 0 and ld == C:
+            # precision="fp8", long-K level: LayerNorm -> e4m3, QKV on e4m3 operands (bf16 q/k/v for the core), the core's output -> e4m3,
+            # proj on e4m3 operands (+ residual).  Tensor scales (powers of two) ride in alpha.
+            k8 = self.FP8_ACT_LOG2
+            a8 = self._buf("ln.a8", (B * S, C), torch.float8_e4m3fn, dev)
+            L.layernorm_fp8(x, P[name + ".ln.g"], P[name + ".ln.beta"], a8, B * S, C, C, float(2 ** k8))
+            w8, sw = P[name + ".qkv.w8"]
+            qkv = self._buf("qkv.bf16", (B * S, 3 * C), torch.bfloat16, dev)
+            L.igemm(a8, w8, M=B * S, N=3 * C, Cin=C, bias=P[name + ".qkv.b"], out_bf16=qkv, alpha=1.0 / (2 ** k8 * sw), fp8=True)
+            o8 = self._buf("attn.o8", (B * S, C), torch.float8_e4m3fn, dev)
+            L.cuboid_attention(qkv_bf16=qkv, out_bf16=o8, tok_index=tabs["tok"], bias=P[name + ".bias"], mask=tabs["mask"], B=B, ntok=S,
+                               Cn=C, heads=at.num_heads, nc=geo["nc"], vol=geo["vol"], ld_qkv=3 * C, ld_out=C, scale=float(at.scale),
+                               out_fp8_log2=k8)
+            w8, sw = P[name + ".proj.w8"]
+            L.igemm(o8, w8, M=B * S, N=C, Cin=C, bias=P[name + ".proj.b"], residual=x, out_f32=x, alpha=1.0 / (2 ** k8 * sw), fp8=True)
+            return
         a, alo = self._bf("ln.a", B * S, ld, dev)
         L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld)
         wq, wqlo = P[name + ".qkv.w"]
@@ -740,6 +765,18 @@ class CuboidTransformerUNet(nn.Module):
             # one launch, hidden activations never leave the CU (csrc/ffn.hip)
             L.ffn_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".fc1.w"][0], P[name + ".fc1.b"], P[name + ".fc2.w"][0],
                         P[name + ".fc2.b"], B * S, C, Hd, act=ff.activation_name)
+            return
+        if (name + ".fc1.w8") in P and (name + ".fc2.w8") in P and ld == C and ldh == Hd:
+            # precision="fp8", long-K level: LayerNorm -> e4m3 -> FFN-1 (activation -> e4m3 in its epilogue) -> FFN-2 (+ residual)
+            k8 = self.FP8_ACT_LOG2
+            a8 = self._buf("ln.a8", (B * S, C), torch.float8_e4m3fn, dev)
+            L.layernorm_fp8(x, P[name + ".ln.g"], P[name + ".ln.beta"], a8, B * S, C, C, float(2 ** k8))
+            h8 = self._buf("ffn.h8", (B * S, Hd), torch.float8_e4m3fn, dev)
+            w8, sw = P[name + ".fc1.w8"]
+            L.igemm(a8, w8, M=B * S, N=Hd, Cin=C, bias=P[name + ".fc1.b"], act=ff.activation_name, out_bf16=h8, ld_outb=Hd,
+                    alpha=1.0 / (2 ** k8 * sw), fp8=True, out_fp8_log2=k8)
+            w8, sw = P[name + ".fc2.w8"]
+            L.igemm(h8, w8, M=B * S, N=C, Cin=Hd, bias=P[name + ".fc2.b"], residual=x, out_f32=x, alpha=1.0 / (2 ** k8 * sw), fp8=True)
             return
         a, alo = self._bf("ln.a", B * S, ld, dev)
         L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld)

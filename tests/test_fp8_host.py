@@ -51,7 +51,9 @@ def test_precision_fp8_constructor_flags():
     from prediff_amd.autoencoder_kl import AutoencoderKL
     from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
     net = CuboidTransformerUNet(**TINY_UNET_CFGS["axial"], precision="fp8")
-    assert net.fp8_conv and net.precision == "bf16"                              # the bf16 engine with e4m3 convolution operands
+    assert net.fp8_conv and net.fp8_linear and net.precision == "bf16"           # the bf16 engine with e4m3 convolution + long-K linear operands
+    net_c = CuboidTransformerUNet(**TINY_UNET_CFGS["axial"], precision="fp8_conv")
+    assert net_c.fp8_conv and not net_c.fp8_linear and net_c.precision == "bf16"   # e4m3 for the convolutions only
     assert not CuboidTransformerUNet(**TINY_UNET_CFGS["axial"], precision="bf16").fp8_conv
     assert AutoencoderKL(**TINY_VAE_CFG, precision="fp8").precision == "bf16"    # the VAE has no fp8 launches
     with pytest.raises(ValueError):

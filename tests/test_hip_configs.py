@@ -110,7 +110,7 @@ def test_v1_ddim50_vs_oracle():
     t_cpu = time.time() - t0
     ref = traj[-1]
     errs = {}
-    for precision in ("fp32", "bf16", "fp8"):
+    for precision in ("fp32", "bf16", "fp8_conv", "fp8"):
         ldm = _v1_ldm(precision)
         out, inter = ldm.sample(cond=zc.cuda(), batch_size=B, sampler="ddim", ddim_steps=50, eta=0.0, x_T=xT.cuda(),
                                 return_decoded=False, return_intermediates=True)
@@ -120,13 +120,15 @@ def test_v1_ddim50_vs_oracle():
         out2 = ldm.sample(cond=zc.cuda(), batch_size=B, sampler="ddim", ddim_steps=50, eta=0.0, x_T=xT.cuda(), return_decoded=False)
         assert torch.equal(out2, out)
         del ldm
-    print(f"[v1 DDIM-50] rel-L2 vs oracle loop after 50 steps: fp32 {errs['fp32']:.3e}, bf16 {errs['bf16']:.3e}, fp8 (e4m3 Conv3d) {errs['fp8']:.3e}; "
-          f"by step (1,10,25,40,50): fp32 {errs['fp32_by_step']} bf16 {errs['bf16_by_step']} fp8 {errs['fp8_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
+    print(f"[v1 DDIM-50] rel-L2 vs oracle loop after 50 steps: fp32 {errs['fp32']:.3e}, bf16 {errs['bf16']:.3e}, fp8_conv (e4m3 Conv3d) "
+          f"{errs['fp8_conv']:.3e}, fp8 (e4m3 Conv3d + K >= 512 linears) {errs['fp8']:.3e}; by step (1,10,25,40,50): fp32 {errs['fp32_by_step']} "
+          f"bf16 {errs['bf16_by_step']} fp8_conv {errs['fp8_conv_by_step']} fp8 {errs['fp8_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
     _report("v1_ddim50", oracle_cpu_s=round(t_cpu, 1), **errs)
     assert errs["fp32"] < 1e-3
     # guard rails at 2x what is measured (bf16 1.0e-2, fp8 3.8e-2 after all 50 steps: DESIGN.md §4), so that a regression shows
     assert errs["bf16"] < 2e-2 and np.isfinite(errs["bf16"])
-    assert errs["fp8"] < 8e-2 and np.isfinite(errs["fp8"])          # report-only operand type (BASELINE config 5)
+    assert errs["fp8_conv"] < 8e-2 and np.isfinite(errs["fp8_conv"])          # report-only operand types (BASELINE config 5): measured
+    assert errs["fp8"] < 0.16 and np.isfinite(errs["fp8"])                    # 3.8e-2 (convolutions) / 9.2e-2 (+ the level-1 linears)
 
 
 @pytest.mark.parametrize("kind", ["zeros", "sparse90"])
@@ -252,9 +254,9 @@ def test_fullres_forward():
     finally:
         torch.set_num_threads(nthr)
     t_cpu = time.time() - t0
-    # "fp8": e4m3 operands (3 mantissa bits: report-only accuracy, BASELINE config 5); bounds at 2x what is measured (bf16 7.4e-3,
-    # fp8 4.3e-2)
-    for precision, tol in (("fp32", 1e-4), ("bf16", 1.5e-2), ("fp8", 8e-2)):
+    # "fp8_conv" / "fp8": e4m3 operands (3 mantissa bits: report-only accuracy, BASELINE config 5) for the convolutions / also for the
+    # K >= 512 linears; bounds at 2x what is measured (bf16 7.4e-3, fp8_conv 4.3e-2)
+    for precision, tol in (("fp32", 1e-4), ("bf16", 1.5e-2), ("fp8_conv", 8e-2), ("fp8", 0.14)):
         net = CuboidTransformerUNet(**FULLRES_UNET_CFG, precision=precision)
         net.load_state_dict(sd, strict=True)
         net = net.cuda()
@@ -274,17 +276,18 @@ def test_v1_unet_fp8_conv(golden):
     sd = seeded_state_dict(TP.unet_template(V1_UNET_CFG, "v1_unet_schema.json"), 1234)
     x, cond, t = seeded_input("v1x", (1, 6, 16, 16, 64), 2).cuda(), seeded_input("v1c", (1, 7, 16, 16, 64), 3).cuda(), torch.tensor([500]).cuda()
     outs = {}
-    for precision in ("bf16", "fp8"):
+    for precision in ("bf16", "fp8_conv", "fp8"):
         net = CuboidTransformerUNet(**V1_UNET_CFG, precision=precision)
         net.load_state_dict(sd, strict=True)
         outs[precision] = net.cuda()(x, t, cond)
         e = rel_l2(outs[precision][0, :, ::4, ::4, ::8], g["out_slice"])
         print(f"[v1 unet {precision}] rel-L2 vs the reference golden (fp32 slice) {e:.3e}")
         _report("v1_unet_fp8_conv", precision=precision, rel_l2=e)
-    assert torch.isfinite(outs["fp8"]).all()
-    e8 = rel_l2(outs["fp8"], outs["bf16"])
-    print(f"[v1 unet fp8 conv] rel-L2 vs the bf16 engine {e8:.3e}")
-    assert 1e-4 < e8 < 8e-2          # different arithmetic (not the bf16 path by accident), same function (measured 3.3e-2)
+    assert torch.isfinite(outs["fp8"]).all() and torch.isfinite(outs["fp8_conv"]).all()
+    e8c, e8 = rel_l2(outs["fp8_conv"], outs["bf16"]), rel_l2(outs["fp8"], outs["bf16"])
+    print(f"[v1 unet fp8] rel-L2 vs the bf16 engine: e4m3 convolutions {e8c:.3e}, + e4m3 K >= 512 linears {e8:.3e}")
+    assert 1e-4 < e8c < 8e-2          # different arithmetic (not the bf16 path by accident), same function (measured 3.3e-2)
+    assert e8c < e8 < 0.14            # the linears add their own 3-mantissa-bit noise (measured 6e-2)
 
 
 # ------------------------------------------------------------------------------------------------ config 4, the whole chain

@@ -703,3 +703,75 @@ def test_groupnorm_silu_fp8(B, S, C, G, ss):
     print(f"[gn silu fp8 C={C}] identical bytes {same:.4f}, rel-L2 of the dequantised values {err:.2e}")
     assert same > 0.99 and err < 1e-2
     assert rel_l2(out.float() / 16.0, y) < 4e-2          # e4m3: 3 mantissa bits
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 512), (333, 256), (64, 1024)])
+def test_layernorm_fp8(rows, C):
+    """LayerNorm with an e4m3 output (value * scale, RNE, saturating: the A operand of the fp8 linears) against torch's cast of the fp32
+    statement; one row is scaled up to exercise the saturation."""
+    g = torch.Generator(device="cpu").manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+    gamma[3] = 40.0                                       # |y| * 16 > 448 in that column: saturates instead of turning into NaN
+    out = torch.empty(rows, C, dtype=torch.float8_e4m3fn, device=DEV)
+    L.layernorm_fp8(x, gamma, beta, out, rows, C, C, 16.0)
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    ref = (y * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    same = float((out.view(torch.uint8) == ref.view(torch.uint8)).float().mean())
+    print(f"[layernorm fp8 C={C}] identical bytes {same:.4f}")
+    assert bool(torch.isfinite(out.float()).all()) and same > 0.99
+    assert rel_l2(out.float()[:, 4:] / 16.0, y[:, 4:]) < 4e-2
+
+
+@pytest.mark.parametrize("M,N,K,act", [(832, 2048, 512, "gelu"), (300, 512, 2048, "none"), (256, 1536, 512, "none")])
+def test_igemm_fp8_output(M, N, K, act):
+    """pd_igemm on e4m3 operands whose epilogue (bias, activation) writes e4m3 again (out_fp8_log2: the FFN-1 -> FFN-2 hand-over of
+    the fp8 linears) against the fp32 statement on the same quantised operands, quantised the same way."""
+    from prediff_amd.packing import pack_linear_fp8, to_fp8
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias = (0.2 * torch.randn(N, generator=g)).to(DEV)
+    a8, sa = to_fp8(x, 16.0), 16.0
+    w8, sw = pack_linear_fp8(w)
+    out8 = torch.empty(M, N, dtype=torch.float8_e4m3fn, device=DEV)
+    L.igemm(a8, w8, M=M, N=N, Cin=K, bias=bias, act=act, alpha=1.0 / (sa * sw), out_bf16=out8, ld_outb=N, fp8=True, out_fp8_log2=4)
+    y = (a8.float() @ w8.float().T) / (sa * sw) + bias
+    if act == "gelu":
+        y = F.gelu(y)
+    ref = (y * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    same = float((out8.view(torch.uint8) == ref.view(torch.uint8)).float().mean())
+    err = rel_l2(out8.float(), ref.float())
+    print(f"[igemm fp8 -> fp8 {M}x{N}x{K} {act}] identical bytes {same:.4f}, rel-L2 of the dequantised values {err:.2e}")
+    assert same > 0.98 and err < 2e-2
+    # the bf16 output of the same launch agrees with the e4m3 one to e4m3 precision
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.igemm(a8, w8, M=M, N=N, Cin=K, bias=bias, act=act, alpha=1.0 / (sa * sw), out_bf16=outb, fp8=True)
+    assert rel_l2(out8.float() / 16.0, outb.float()) < 4e-2
+
+
+def test_cuboid_attention_fp8_output():
+    """The MFMA attention core writing e4m3 (the A operand of an fp8 proj launch) against its bf16 output, quantised by torch."""
+    from prediff_amd.cuboid_geometry import attention_tables
+    B, Cn, heads, shape, cuboid = 2, 512, 4, (13, 8, 8), (13, 1, 1)
+    ntok = shape[0] * shape[1] * shape[2]
+    tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+    vol, nc = tabs["vol"], tabs["nc"]
+    g = torch.Generator(device="cpu").manual_seed(7)
+    qkv = torch.randn(B * ntok, 3 * Cn, generator=g).to(DEV).to(torch.bfloat16)
+    bias = (0.5 * torch.randn(heads, vol, vol, generator=g)).to(DEV)
+    tok = tabs["tok_index"].to(DEV)
+    kw = dict(qkv_bf16=qkv, tok_index=tok, bias=bias, mask=None, B=B, ntok=ntok, Cn=Cn, heads=heads, nc=nc, vol=vol, ld_qkv=3 * Cn, ld_out=Cn,
+              scale=(Cn // heads) ** -0.5)
+    ob = torch.zeros(B * ntok, Cn, dtype=torch.bfloat16, device=DEV)
+    L.cuboid_attention(out_bf16=ob, **kw)
+    o8 = torch.zeros(B * ntok, Cn, dtype=torch.float8_e4m3fn, device=DEV)
+    L.cuboid_attention(out_bf16=o8, out_fp8_log2=4, **kw)
+    assert rel_l2(o8.float() / 16.0, ob.float()) < 4e-2
+    # from the fp32 accumulators, not via bf16: matches the quantisation of the bf16 output except at double-rounding boundaries
+    ref = (ob.float() * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    same = float((o8.view(torch.uint8) == ref.view(torch.uint8)).float().mean())
+    print(f"[attention core fp8 output] bytes identical to the quantised bf16 output {same:.4f}")
+    assert same > 0.95
+    with pytest.raises(L.PrediffHipError):                  # the generic fp32 core has no e4m3 output
+        L.cuboid_attention(out_bf16=o8, out_fp8_log2=4, force_generic=True, **kw)
