@@ -284,6 +284,56 @@ def gen_diffusion():
     save("sample3", decoded=dec, latent=lat_out, tape=torch.stack(tape), zc=ldm.cond_stage_forward({"y": y}))
 
 
+def gen_training_side():
+    """what the training side computes WITHOUT a gradient -- q_sample, the loss of a batch (p_losses, eval mode), the
+    variational-bound weights, the EMA shadow update (utils/ema.py) and a validation-style evaluation with the EMA weights swapped in."""
+    from prediff.utils.ema import LitEma
+    cfg = TINY_UNET_CFGS["axial"]
+    net = R.CuboidTransformerUNet(**cfg)
+    reseed(net, 600)
+    vae = R.AutoencoderKL(**TINY_VAE_CFG)          # (the reference insists on a first-stage module; it is not used here)
+    reseed(vae, 601)
+    ldm = R.LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(cfg["target_shape"][0], 32, 32, 1), timesteps=1000,
+                            beta_schedule="linear", use_ema=True, original_elbo_weight=0.1, latent_shape=tuple(cfg["target_shape"]),
+                            first_stage_model=vae, cond_stage_model=None, scale_factor=1.0).eval()
+    B = 3
+    lat = (B,) + tuple(cfg["target_shape"])
+    x0 = seeded_input("tsx0", lat, 31)
+    noise = seeded_input("tsn", lat, 32)
+    zc = seeded_input("tszc", (B,) + tuple(cfg["input_shape"]), 33)
+    t = torch.tensor([999, 417, 0])
+    arrs = {"lvlb_weights": ldm.lvlb_weights, "q_sample": ldm.q_sample(x0, t, noise)}
+    loss, ld = ldm.p_losses(x0, zc, t, noise=noise)
+    arrs["loss"] = loss.reshape(1)
+    for k, v in ld.items():
+        arrs["ld_" + k.replace("/", "_")] = v.reshape(1)
+    # EMA: three updates while the weights move (p <- p * 0.9 + 0.01 per step), then the loss with the EMA weights swapped in
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    for p_ in net.parameters():
+        p_.requires_grad_(True)
+    ema = LitEma(net)
+    for step in range(3):
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.mul_(0.9).add_(0.01)
+        ema(net)
+    names = [n for n, _ in net.named_parameters()]
+    probe = [names[0], names[len(names) // 2], names[-1]]
+    arrs["ema_num_updates"] = ema.num_updates.reshape(1)
+    for i, n in enumerate(probe):
+        arrs[f"ema_shadow_{i}"] = dict(ema.named_buffers())[ema.m_name2s_name[n]]
+    arrs["ema_abs_sum"] = sum(v.double().abs().sum() for k, v in ema.named_buffers() if k not in ("decay", "num_updates")).reshape(1)
+    ldm.model_ema = ema
+    with ldm.ema_scope():
+        loss_e, _ = ldm.p_losses(x0, zc, t, noise=noise)
+    arrs["loss_ema"] = loss_e.reshape(1)
+    loss_after, _ = ldm.p_losses(x0, zc, t, noise=noise)          # weights restored
+    arrs["loss_moved"] = loss_after.reshape(1)
+    save("train_side", **arrs)
+    with open(os.path.join(HERE, "train_side_probe.json"), "w") as f:
+        json.dump({"probe": probe, "n_params": len(names)}, f)
+
+
 def gen_alignment():
     """SEVIRAvgIntensityAlignment: U_phi forward, guidance gradient, aligned p_sample and aligned sample()."""
     from _cases import TINY_ALIGN_ARGS, V1_ALIGN_ARGS
@@ -409,7 +459,9 @@ def gen_nbody():
 
 def main():
     which = sys.argv[1:] or ["skill", "index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion", "alignment",
-                             "v1_aligned", "nbody"]
+                             "v1_aligned", "nbody", "train_side"]
+    if "train_side" in which:
+        gen_training_side()
     if "v1_aligned" in which:
         torch.set_grad_enabled(True)
         gen_v1_aligned()
