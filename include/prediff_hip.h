@@ -105,6 +105,20 @@ int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, con
                       const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo,
                       int B, int S, int C, int G, int ld_out, float eps, int silu, pd_stream_t stream);
 
+/* The statistics pass of pd_groupnorm_silu alone: stats[b][g] = {mean, rstd} (fp32) of nn.GroupNorm(G, C, eps) over channels-last
+ * x (B, S, C); partials as for pd_groupnorm_silu.  For consumers that normalise on the fly (pd_conv2d_gn_silu). */
+int pd_groupnorm_stats(const float* x, double* partials, float* stats, int B, int S, int C, int G, float eps, pd_stream_t stream);
+
+/* ResnetBlock2D's  GroupNorm -> SiLU -> Conv2d 3x3 (stride 1, zero padding 1) [+ bias] [+ fp32 residual]  in one launch
+ * (taming/resnet.py:454-495 at temb = None): x (N, H, W, Cin) fp32 channels last is normalised with stats (N, G, 2) = {mean, rstd}
+ * from pd_groupnorm_stats, passed through SiLU and rounded to bf16 inside the kernel's LDS halo tile; W packed bf16 [9][Cout][Cin]
+ * (prediff_amd/packing.py:pack_conv, taps (ky, kx)); out (N, H, W, Cout) fp32, may alias residual.  Supported when
+ * pd_conv2d_gn_silu_supported(H, W, Cin, Cout, G): H % 8 == 0, W % 16 == 0, Cin % 64 == 0, Cout % 128 == 0, (Cin / G) % 4 == 0;
+ * otherwise use pd_groupnorm_silu + pd_igemm. */
+int pd_conv2d_gn_silu_supported(int H, int W, int Cin, int Cout, int G);
+int pd_conv2d_gn_silu(const float* x, const float* stats, const float* gamma, const float* beta, const pd_bf16* W, const float* bias,
+                      const float* residual, float* out, int N, int H, int W_, int Cin, int Cout, int G, pd_stream_t stream);
+
 /* pd_groupnorm_silu with an OCP e4m3 output (the A operand of an fp8 pd_igemm launch): out[b, s, c] = e4m3(y * fp8_scale),
  * round to nearest even, saturating at +-448; rows of C bytes.  C % 4 == 0, C/4 divides 256, 4 | C/G. */
 int pd_groupnorm_silu_fp8(const float* x, const float* gamma, const float* beta, const float* ss_scale,

@@ -55,6 +55,9 @@ _PROTOS = {
     "pd_groupnorm_nchunk": (C.c_int, [C.c_int, C.c_int]),
     "pd_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 +
                           [C.c_float, C.c_int, C.c_void_p]),
+    "pd_groupnorm_stats": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "pd_conv2d_gn_silu_supported": (C.c_int, [C.c_int] * 5),
+    "pd_conv2d_gn_silu": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_void_p]),
     "pd_groupnorm_silu_fp8": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "pd_groupnorm_silu_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
     "pd_cast_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 6 + [C.c_void_p]),
@@ -221,6 +224,21 @@ def groupnorm_silu(x, gamma, beta, partials, out, out_lo, B, S, Cn, G, ld_out, e
     _check(lib().pd_groupnorm_silu(ptr(x), ptr(gamma), ptr(beta), ptr(ss_scale), ptr(ss_shift), ld_ss, ptr(partials),
                                    ptr(out), ptr(out_lo), B, S, Cn, G, ld_out, eps, 1 if silu else 0, stream_ptr()),
            "pd_groupnorm_silu")
+
+
+def groupnorm_stats(x, partials, stats, B, S, Cn, G, eps):
+    """stats (B, G, 2) fp32 = {mean, rstd} of GroupNorm(G, Cn, eps) over channels-last x (B, S, Cn)."""
+    _check(lib().pd_groupnorm_stats(ptr(x), ptr(partials), ptr(stats), B, S, Cn, G, eps, stream_ptr()), "pd_groupnorm_stats")
+
+
+def conv2d_gn_silu_supported(H, W, Cin, Cout, G):
+    return bool(lib().pd_conv2d_gn_silu_supported(H, W, Cin, Cout, G))
+
+
+def conv2d_gn_silu(x, stats, gamma, beta, W, bias, residual, out, N, H, Wd, Cin, Cout, G):
+    """GroupNorm -> SiLU -> Conv2d 3x3 (+ bias, + fp32 residual) in one launch (csrc/conv2d_gn.hip): the VAE ResBlock body."""
+    _check(lib().pd_conv2d_gn_silu(ptr(x), ptr(stats), ptr(gamma), ptr(beta), ptr(W), ptr(bias), ptr(residual), ptr(out), N, H, Wd, Cin,
+                                   Cout, G, stream_ptr()), "pd_conv2d_gn_silu")
 
 
 def groupnorm_silu_fp8(x, gamma, beta, partials, out, B, S, Cn, G, eps, fp8_scale, silu=True, ss_scale=None, ss_shift=None, ld_ss=0):

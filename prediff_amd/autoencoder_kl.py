@@ -137,6 +137,7 @@ class AutoencoderKL(nn.Module):
             raise ValueError("precision must be 'bf16', 'fp32', 'fp8' or 'fp8_conv'")
         # "fp8" is a denoiser option (e4m3 operands for its 3x3x3 convolutions); the VAE has no such launches and runs its bf16 engine
         self.precision = "bf16" if precision.startswith("fp8") else precision
+        self.fuse_resblock = True     # bf16 engine: GroupNorm -> SiLU -> Conv2d 3x3 of the ResBlocks as one launch (csrc/conv2d_gn.hip)
         self.latent_channels, self.norm_num_groups = latent_channels, norm_num_groups
         self.encoder = Encoder(in_channels, latent_channels, down_block_types, block_out_channels, layers_per_block, norm_num_groups)
         self.decoder = Decoder(latent_channels, out_channels, up_block_types, block_out_channels, layers_per_block, norm_num_groups)
@@ -216,21 +217,36 @@ class AutoencoderKL(nn.Module):
                 bias=P[name + ".b"], residual=residual, out_f32=out)
         return Ho, Wo
 
+    def _gn_conv(self, P, gn_name, conv_name, x, N, hw, Cin, Cout, out, dev, residual=None):
+        """GroupNorm -> SiLU -> Conv2d 3x3 (+ residual): ONE fused launch behind the statistics pass where the geometry allows
+        (bf16 engine; csrc/conv2d_gn.hip: the halo of a pixel tile is normalised into LDS once and read by all nine taps), else the
+        apply pass + implicit GEMM."""
+        H, W = hw
+        G = self.norm_num_groups
+        if self.precision == "bf16" and self.fuse_resblock and L.conv2d_gn_silu_supported(H, W, Cin, Cout, G) and pad64(Cin) == Cin:
+            S = H * W
+            part = self._buf("gn.part", (N * L.groupnorm_nchunk(S, Cin) * G * 2,), torch.float64, dev)
+            stats = self._buf("gn.stats", (N, G, 2), torch.float32, dev)
+            L.groupnorm_stats(x, part, stats, N, S, Cin, G, VAE_EPS)
+            L.conv2d_gn_silu(x, stats, P[gn_name + ".g"], P[gn_name + ".beta"], P[conv_name + ".w"][0], P[conv_name + ".b"], residual, out,
+                             N, H, W, Cin, Cout, G)
+            return
+        a, alo, ld = self._gn(P, gn_name, x, N, H * W, Cin, dev)
+        self._conv(P, conv_name, a, alo, ld, N, hw, Cout, out, dev, residual=residual)
+
     def _resnet(self, P, name, m: ResnetBlock2D, x, N, hw, dev):
         """ResnetBlock2D.forward, temb=None (taming/resnet.py:454-495).  x: fp32 (N*S, Cin) -> fp32 (N*S, Cout)."""
         S = hw[0] * hw[1]
         Cin, Cout = m.in_channels, m.out_channels
-        a, alo, ld = self._gn(P, name + ".norm1", x, N, S, Cin, dev)
         h = self._buf("res.h", (N * S, Cout), torch.float32, dev)
-        self._conv(P, name + ".conv1", a, alo, ld, N, hw, Cout, h, dev)
-        a, alo, ld = self._gn(P, name + ".norm2", h, N, S, Cout, dev)
+        self._gn_conv(P, name + ".norm1", name + ".conv1", x, N, hw, Cin, Cout, h, dev)
         if m.conv_shortcut is None:
-            self._conv(P, name + ".conv2", a, alo, ld, N, hw, Cout, x, dev, residual=x)
+            self._gn_conv(P, name + ".norm2", name + ".conv2", h, N, hw, Cout, Cout, x, dev, residual=x)
             return x
         out = self._buf(f"res.out{Cout}", (N * S, Cout), torch.float32, dev)
         xa, xalo, ldx = self._cast(x, N * S, Cin, "sc.a", dev)
         self._conv(P, name + ".conv_shortcut", xa, xalo, ldx, N, hw, Cout, out, dev, k=1)
-        self._conv(P, name + ".conv2", a, alo, ld, N, hw, Cout, out, dev, residual=out)
+        self._gn_conv(P, name + ".norm2", name + ".conv2", h, N, hw, Cout, Cout, out, dev, residual=out)
         return out
 
     def _attention(self, P, name, x, N, S, C, dev):

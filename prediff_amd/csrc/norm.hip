@@ -425,6 +425,40 @@ extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float
   return PD_OK;
 }
 
+// Statistics only: mean / rstd per (sample, group) as fp32 pairs, from the same fp64 partial sums and the same reduction order as the
+// apply kernels' prologue -- for consumers that normalise on the fly (pd_conv2d_gn_silu: the VAE's fused ResBlock convolution).
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const double* __restrict__ partials, float* __restrict__ stats, int S, int C, int G,
+                                                          int nchunk, float eps) {
+  const int b = blockIdx.x;
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double ss = 0, qq = 0;
+    const double* pp = partials + (int64_t)b * nchunk * G * 2 + g * 2;
+    for (int k = 0; k < nchunk; ++k) { ss += pp[(int64_t)k * G * 2]; qq += pp[(int64_t)k * G * 2 + 1]; }
+    const double cnt = (double)S * cpg;
+    const double mean = ss / cnt;
+    double var = qq / cnt - mean * mean;
+    if (var < 0) var = 0;
+    stats[((int64_t)b * G + g) * 2] = (float)mean;
+    stats[((int64_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+extern "C" int pd_groupnorm_stats(const float* x, double* partials, float* stats, int B, int S, int C, int G, float eps, pd_stream_t stream) {
+  PD_CHECK_ARG(x && partials && stats, "pd_groupnorm_stats: null pointer");
+  PD_CHECK_ARG(G > 0 && C % G == 0 && G <= 4096 && B > 0 && S > 0, "pd_groupnorm_stats: bad B/S/C/G (%d,%d,%d,%d)", B, S, C, G);
+  const int nchunk = pd_groupnorm_nchunk(S, C);
+  hipStream_t s = (hipStream_t)stream;
+  const int CV = C / 4, cpg = C / G;
+  const bool vec = (C % 4 == 0) && CV <= 256 && (256 % CV == 0) && (cpg % 4 == 0) && G <= 256 && (((uintptr_t)x) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(gn_stats_vec_kernel, dim3(nchunk, B), dim3(256), 0, s, x, partials, S, C, G);
+  else hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), (512 + 2 * G) * sizeof(double), s, x, partials, S, C, G);
+  PD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partials, stats, S, C, G, nchunk, eps);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
+}
+
 // GroupNorm [-> SiLU] -> e4m3 rows (the operand of an fp8 pd_igemm launch): out[b, s, c] = e4m3(y * fp8_scale), ld_out == C
 extern "C" int pd_groupnorm_silu_fp8(const float* x, const float* gamma, const float* beta, const float* ss_scale,
                                      const float* ss_shift, int ld_ss, double* partials, uint8_t* out, int B, int S, int C, int G,

@@ -41,3 +41,12 @@ def test_bench_strong_scaling_and_small_batch_lines():
     assert s["ensemble"] == 32 and s["trajectories_per_gpu"] == 32 and s["scaling"] == "strong" and s["value"] > 0
     assert set(d["small_batch"]) == {"B1", "B4", "B16"} and all(v["value"] > 0 for v in d["small_batch"].values())
     assert d["attention_block"]["frac"] > 0 and d["roofline"]["traffic_source"]
+    # round 3: the Conv3d kernel as it runs in the timed two-lane configuration, the fp32-class engine's throughput beside the bf16
+    # headline, and the VAE's two ends of sample() with their roofline fractions
+    ins = d["roofline"]["in_situ"]
+    assert ins["avg_launch_us"] > 0 and abs(ins["frac"] - ins["achieved"] / d["roofline"]["peak"]) < 1e-3 and ins["launches_timed"] > 0
+    f32 = d["precision_fp32"]
+    assert f32["value"] > 0 and f32["value"] < d["value"] and f32["trajectories_per_gpu"] == 32 and "bf16x3" in f32["dtype"]
+    for end in ("encode", "decode"):
+        v = d["vae"][end]
+        assert v["frames"] > 0 and v["ms"] > 0 and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-3

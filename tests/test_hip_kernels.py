@@ -775,3 +775,83 @@ def test_cuboid_attention_fp8_output():
     assert same > 0.95
     with pytest.raises(L.PrediffHipError):                  # the generic fp32 core has no e4m3 output
         L.cuboid_attention(out_bf16=o8, out_fp8_log2=4, force_generic=True, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ VAE ResBlock: fused GN -> SiLU -> Conv2d
+@pytest.mark.parametrize("N,H,W,Cin,Cout,res", [(3, 16, 16, 128, 128, False), (2, 32, 48, 128, 256, True), (5, 8, 16, 512, 512, True),
+                                                 (1, 128, 128, 128, 128, True), (2, 16, 32, 256, 128, False), (7, 16, 16, 64, 128, True)])
+def test_conv2d_gn_silu(N, H, W, Cin, Cout, res):
+    """pd_groupnorm_stats + pd_conv2d_gn_silu (taming/resnet.py:454-495, one (norm, nonlinearity, conv) of ResnetBlock2D) against the
+    fp32 torch statement, against the same statement with the kernel's roundings (bf16 activations after SiLU, bf16 weights), and
+    against the un-fused HIP chain pd_groupnorm_silu -> pd_igemm it replaces."""
+    G = 32 if Cin >= 128 else 16          # (Cin / G) % 4 == 0
+    g = torch.Generator(device="cpu").manual_seed(N + H + Cin + Cout)
+    x = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.3 + torch.linspace(-1, 1, Cin)[None, None, None, :]).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(Cin, generator=g)).to(DEV), (0.2 * torch.randn(Cin, generator=g)).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(DEV)
+    w[:, :, 0, 2] += 0.05                                             # asymmetric taps: a transposed / mirrored tap order would show
+    bias = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    resid = torch.randn(N, H, W, Cout, generator=g).to(DEV) if res else None
+    assert L.conv2d_gn_silu_supported(H, W, Cin, Cout, G) and not L.conv2d_gn_silu_supported(12, 16, 128, 128, 32)
+    S = H * W
+    part = torch.empty(N * L.groupnorm_nchunk(S, Cin) * G * 2, dtype=torch.float64, device=DEV)
+    stats = torch.empty(N, G, 2, device=DEV)
+    L.groupnorm_stats(x, part, stats, N, S, Cin, G, 1e-6)
+    xg = x.reshape(N, S, G, Cin // G).double()
+    mean, var = xg.mean(dim=(1, 3)), xg.var(dim=(1, 3), unbiased=False)
+    assert rel_l2(stats[:, :, 0], mean) < 1e-6 and rel_l2(stats[:, :, 1], 1.0 / torch.sqrt(var + 1e-6)) < 1e-5
+    w_p, _ = pack_conv(w, False)
+    out = torch.full((N, H, W, Cout), float("nan"), device=DEV)
+    L.conv2d_gn_silu(x, stats, gamma, beta, w_p, bias, resid, out, N, H, W, Cin, Cout, G)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    act = F.silu(F.group_norm(x.permute(0, 3, 1, 2), G, gamma, beta, 1e-6))
+    full = F.conv2d(act, w, bias, padding=1).permute(0, 2, 3, 1) + (resid if res else 0)
+    same = F.conv2d(bf(act), bf(w), bias, padding=1).permute(0, 2, 3, 1) + (resid if res else 0)
+    e_full, e_same = rel_l2(out, full), rel_l2(out, same)
+    # the un-fused chain
+    a = torch.empty(N * S, Cin, dtype=torch.bfloat16, device=DEV)
+    L.groupnorm_silu(x, gamma, beta, part, a, None, N, S, Cin, G, Cin, 1e-6, silu=True)
+    ref = torch.empty(N * S, Cout, device=DEV)
+    L.igemm(a, w_p, M=N * S, N=Cout, Cin=Cin, taps=9, w_tap_stride=Cout * Cin, geom=L.conv_geom(N, (1, H, W), (1, 3, 3), pad=(0, 1, 1)),
+            bias=bias, residual=(resid.reshape(N * S, Cout) if res else None), out_f32=ref)
+    e_chain = rel_l2(out.reshape(N * S, Cout), ref)
+    print(f"[conv2d_gn_silu {N}x{H}x{W} {Cin}->{Cout}] rel-L2 vs fp32 {e_full:.2e}, same roundings {e_same:.2e}, un-fused HIP chain {e_chain:.2e}")
+    assert e_full < 6e-3 and e_same < 3e-4 and e_chain < 3e-4
+    if res:      # in place on the residual (how the ResBlock's conv2 is called)
+        r2 = resid.clone()
+        L.conv2d_gn_silu(x, stats, gamma, beta, w_p, bias, r2, r2, N, H, W, Cin, Cout, G)
+        assert torch.equal(r2, out)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,res", [(7, 128, 128, 128, 128, False), (10, 128, 128, 128, 128, True), (8, 32, 32, 512, 512, True)])
+def test_conv2d_gn_silu_two_workgroups_per_cu(N, H, W, Cin, Cout, res):
+    """More workgroups than CUs (896 / 1280 / 256 of ~70 KB LDS: two resident per CU): 12 launches, every one against the torch statement
+    with the kernel's roundings and bit-equal to the first.  A build of this kernel whose scale computation hipcc had packed into a
+    v_pk_mul_f32 behind the loads' s_waitcnt got 4 ... 50 of 896 tiles wrong per launch in exactly this configuration
+    (profiles/r03_h_conv2d_gn_hazard.md)."""
+    G = 32
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.3).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(Cin, generator=g)).to(DEV), (0.2 * torch.randn(Cin, generator=g)).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(DEV)
+    bias = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    resid = torch.randn(N, H, W, Cout, generator=g).to(DEV) if res else None
+    S = H * W
+    part = torch.empty(N * L.groupnorm_nchunk(S, Cin) * G * 2, dtype=torch.float64, device=DEV)
+    stats = torch.empty(N, G, 2, device=DEV)
+    L.groupnorm_stats(x, part, stats, N, S, Cin, G, 1e-6)
+    w_p, _ = pack_conv(w, False)
+    act = F.silu(F.group_norm(x.permute(0, 3, 1, 2), G, gamma, beta, 1e-6))
+    same = F.conv2d(bf(act), bf(w), bias, padding=1).permute(0, 2, 3, 1) + (resid if res else 0)
+    first = None
+    for k in range(12):
+        out = torch.full((N, H, W, Cout), float("nan"), device=DEV)
+        L.conv2d_gn_silu(x, stats, gamma, beta, w_p, bias, resid, out, N, H, W, Cin, Cout, G)
+        torch.cuda.synchronize()
+        worst = float((out - same).abs().max())
+        assert worst < 5e-3, (k, worst)
+        if first is None:
+            first = out
+        else:
+            assert torch.equal(out, first), k
