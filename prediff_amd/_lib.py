@@ -11,7 +11,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprediff_hip.so")
+# PD_LIB_PATH: another build of the same library (A/B of compiler flags, scripts/r03_call10.sh); the default is the in-tree build
+LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libprediff_hip.so")
 
 ACT = {"none": 0, None: 0, "identity": 0, "gelu": 1, "silu": 2, "leaky": 3, "relu": 4}
 

@@ -105,3 +105,43 @@ def test_no_gpu_means_loud_failure():
     from prediff_amd import _lib as L
     with pytest.raises(L.PrediffHipError):
         L._dev(torch.zeros(2))
+
+
+def test_affine_form_of_token_tables():
+    """cuboid_geometry.affine_form: the (n_inner, outer, inner, slot) strides reproduce the table entry for entry whenever they are
+    returned (the fused attention block computes token ids from them instead of loading the table), and tables that are not affine
+    -- a shifted window, a padded grid -- give None."""
+    import numpy as np
+    from prediff_amd.cuboid_geometry import attention_tables, affine_form
+    for shape, cuboid in (((13, 16, 16), (13, 1, 1)), ((13, 16, 16), (1, 16, 1)), ((13, 16, 16), (1, 1, 16)), ((6, 8, 8), (6, 1, 1)),
+                          ((25, 48, 48), (1, 48, 1)), ((4, 4, 4), (2, 2, 2))):
+        tabs = attention_tables(shape, cuboid, (0, 0, 0), ("l", "l", "l"), "zeros")
+        tok = tabs["tok_index"].numpy().astype(np.int64)
+        aff = tabs["affine"]
+        if aff is None:
+            continue
+        n_inner, outer, inner, slot = aff
+        c = np.arange(tok.shape[0])[:, None]
+        s = np.arange(tok.shape[1])[None, :]
+        assert np.array_equal((c // n_inner) * outer + (c % n_inner) * inner + s * slot, tok), (shape, cuboid)
+    # the three axial patterns of the v1 level-0 grid ARE affine (the fast path is taken where it matters)
+    for cuboid in ((13, 1, 1), (1, 16, 1), (1, 1, 16)):
+        assert attention_tables((13, 16, 16), cuboid, (0, 0, 0), ("l", "l", "l"), "zeros")["affine"] is not None
+    # shifted (rolled) and padded tables are not
+    assert attention_tables((4, 8, 8), (2, 4, 4), (1, 2, 2), ("l", "l", "l"), "zeros")["affine"] is None
+    assert attention_tables((13, 16, 16), (5, 1, 1), (0, 0, 0), ("l", "l", "l"), "zeros")["affine"] is None
+    import torch
+    assert affine_form(torch.tensor([[0, 1], [2, -1]])) is None
+
+
+def test_conv2d_gn_silu_supported_predicate():
+    """Host-side geometry predicate of the fused VAE ResBlock kernel (no launch): the shapes of the v1 VAE's ResBlocks qualify, the
+    32-channel stand-in VAE and odd grids do not (AutoencoderKL then runs pd_groupnorm_silu + pd_igemm)."""
+    from prediff_amd import _lib as L
+    assert L.conv2d_gn_silu_supported(128, 128, 128, 128, 32) and L.conv2d_gn_silu_supported(64, 64, 256, 256, 32)
+    assert L.conv2d_gn_silu_supported(16, 16, 512, 512, 32) and L.conv2d_gn_silu_supported(32, 32, 256, 512, 32)
+    assert not L.conv2d_gn_silu_supported(64, 64, 32, 64, 8)          # Cin % 64
+    assert not L.conv2d_gn_silu_supported(12, 16, 128, 128, 32)        # H % 8
+    assert not L.conv2d_gn_silu_supported(16, 24, 128, 128, 32)        # W % 16
+    assert not L.conv2d_gn_silu_supported(16, 16, 128, 64, 32)         # Cout % 128
+    assert not L.conv2d_gn_silu_supported(16, 16, 64, 128, 32)         # (Cin / G) % 4
