@@ -101,3 +101,25 @@ def test_repack_after_weight_update():
     assert float(out.abs().max()) > 0
     ref = OU.unet_forward({k: v.cpu() for k, v in sd.items()}, cfg, x.cpu(), t.cpu(), c.cpu())
     assert rel_l2(out, ref) < TOL["bf16"]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_v1_forward_repeats_bit_equal_at_full_occupancy(precision):
+    """32 trajectories through the v1 denoiser, ten times: the fused level-0 kernels run 1664 workgroups, two resident per CU, the
+    Conv3d / GEMM kernels several rounds of tiles.  Every repeat must be bit-equal to the first: a timing-dependent fault (the kind
+    profiles/r03_h_conv2d_gn_hazard.md records for an early build of the VAE kernel: wrong 16-lane groups in random workgroups, only
+    with co-resident workgroups) would show here even where a rel-L2 bound against the oracle would not."""
+    sd = seeded_state_dict(TP.unet_template(V1_UNET_CFG, "v1_unet_schema.json"), 1234)
+    net = CuboidTransformerUNet(**V1_UNET_CFG, precision=precision)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B = 32
+    x = torch.randn((B, 6, 16, 16, 64), generator=g).cuda()
+    cond = torch.randn((B, 7, 16, 16, 64), generator=g).cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    first = net(x, t, cond).clone()
+    assert bool(torch.isfinite(first).all())
+    for k in range(9):
+        out = net(x, t, cond)
+        assert torch.equal(out, first), f"repeat {k + 1} differs: max |d| {float((out - first).abs().max()):.3e}"
