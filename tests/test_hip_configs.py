@@ -268,6 +268,41 @@ def test_fullres_forward():
         del net
 
 
+def test_fullres_ddim_chain():
+    """Config 5 over a horizon, not one forward: a short DDIM chain (ddim_steps = 3 of the reference's uniform schedule helper = the four
+    timesteps 999, 667, 334, 1 of the 1000-step schedule, eta 0) of one trajectory on the full-resolution latent grid through
+    LatentDiffusion.sample, against the oracle loop on the same x_T (4 oracle forwards of 11.4 TFLOP on this box's CPU).  fp32-class engine within the north-star bar; bf16 and the two e4m3 modes bounded at 2x what is
+    measured."""
+    from prediff_amd.presets import FULLRES_LDM_KW
+    sd = seeded_state_dict(CuboidTransformerUNet(**FULLRES_UNET_CFG).state_dict(), 1234)
+    zc = seeded_input("frc", (1, 13, 48, 48, 64), 42)
+    xT = seeded_input("frxT", (1, 12, 48, 48, 64), 43)
+    tape = [xT] + [torch.zeros_like(xT)] * 8
+    ac = np.cumprod(1.0 - OD.beta_schedule("linear", 1000)).astype(np.float32)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 64))
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            traj = OD.ddim_sample_loop(ac, lambda z, t, c: OU.unet_forward(sd, FULLRES_UNET_CFG, z, t, c), zc, tape, 3, eta=0.0)
+    finally:
+        torch.set_num_threads(nthr)
+    t_cpu = time.time() - t0
+    errs = {}
+    for precision, tol in (("fp32", 1e-3), ("bf16", 1.7e-2), ("fp8_conv", 9e-2), ("fp8", 0.15)):      # measured 1.3e-5 / 8.2e-3 / 4.3e-2 / 7.5e-2
+        net = CuboidTransformerUNet(**FULLRES_UNET_CFG, precision=precision)
+        net.load_state_dict(sd, strict=True)
+        ldm = LatentDiffusion(torch_nn_module=net, first_stage_model=None, cond_stage_model=None, **FULLRES_LDM_KW).cuda().eval()
+        out, inter = ldm.sample(cond=zc.cuda(), batch_size=1, sampler="ddim", ddim_steps=3, eta=0.0, x_T=xT.cuda(), return_decoded=False,
+                                return_intermediates=True)
+        assert len(inter) == len(traj)
+        errs[precision] = [round(rel_l2(inter[k], traj[k]), 6) for k in range(1, len(traj))]
+        print(f"[fullres DDIM-3 {precision}] rel-L2 vs the oracle loop after each of the {len(traj) - 1} steps: {errs[precision]} (oracle {t_cpu:.0f} s on CPU)")
+        assert out.shape == (1, 12, 48, 48, 64) and errs[precision][-1] < tol and np.isfinite(errs[precision][-1])
+        del ldm, net
+    _report("fullres_ddim3", oracle_cpu_s=round(t_cpu, 1), **errs)
+
+
 def test_v1_unet_fp8_conv(golden):
     """precision="fp8" at the v1 size: GroupNorm -> SiLU -> e4m3 rows -> scaled-MFMA Conv3d for the 34 convolutions of a forward, the
     rest of the bf16 engine unchanged.  Against the reference golden (fp32 slice) and against the bf16 engine; report-only accuracy."""
