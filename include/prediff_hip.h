@@ -66,7 +66,7 @@ typedef struct pd_igemm_args {
   int32_t tile;            /* 0 = auto; 1 = 128x128, 2 = 64x64, 3-6 = pipeline variants of 128x128, 7 = 256x256 (8 waves), 8 / 9 = 128x64 / 64x128 */
   int32_t vec_epilogue;    /* set by the library */
   uint32_t a_bytes, w_bytes; /* set by the library: extent of one A / W batch (buffer-descriptor bounds) */
-  int32_t debug_flags;     /* profiling ablations only: 1 skip main loop, 2 skip stores, 4 skip activation (0 in production) */
+  int32_t debug_flags;     /* profiling ablations only: 1 skip main loop, 2 skip stores, 4 skip activation, 8 keep the dense tap loop of the 256 x 256 Conv3d kernel (0 in production) */
   int32_t ksplit;          /* set by the library: K-slices of a split-K launch (1 = none) */
   float* splitk_ws;        /* caller workspace for split-K partial sums (fp32, splitk_ws_elems elements) or NULL: without it a launch
                               is never split.  Used for small grids (few trajectories per launch): the K loop of a long-K launch is cut

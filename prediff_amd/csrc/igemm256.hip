@@ -157,11 +157,27 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
       woff[hh][i] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldw) * EB + schunk * 16 : PD_OOB;
     }
   const int kchunks = p.Cin >> KSH;
-  const int nk_all = p.taps * kchunks;
+  const int khw = p.KH * p.KW;
+  // ---- whole-tile tap skipping (KIND 2, un-split launches): when the input frame of a temporal filter tap lies outside [0, Ti) for
+  // EVERY row of the tile -- a tile inside the first / last frame(s) of a sample: at the v1 level-0 grid a 256-row tile IS one frame,
+  // so 2 of 13 tiles drop 9 of their 27 taps -- the zero-padding taps are left out of both DMA streams and of the MFMA loop instead of
+  // being streamed as zero rows (bit `tap` of tap_skip; debug_flags bit 8 keeps the dense loop for A/B runs).
+  uint32_t tap_skip = 0;
+  if (KIND == 2 && !SK && p.KT > 1 && p.taps <= 32 && khw < 32 && !(p.debug_flags & 8)) {
+    const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
+    const int m_last = min(p.M, m0 + BM) - 1;
+    const int b_first = m0 / thw_o;
+    if (b_first == m_last / thw_o) {                               // all rows belong to one sample
+      const int ot_a = (m0 - b_first * thw_o) / hw_o, ot_b = (m_last - b_first * thw_o) / hw_o;
+      for (int kt = 0; kt < p.KT; ++kt)
+        if (ot_b - p.pt + kt < 0 || ot_a - p.pt + kt >= p.Ti) tap_skip |= ((1u << khw) - 1u) << (kt * khw);
+    }
+  }
+  const int ntap = p.taps - __builtin_popcount(tap_skip);
+  const int nk_all = ntap * kchunks;
   const int kslice = SK ? (int)blockIdx.y : 0;
   const int kt0 = SK ? (int)((int64_t)nk_all * kslice / p.ksplit) : 0;
   const int nk = SK ? (int)((int64_t)nk_all * (kslice + 1) / p.ksplit) - kt0 : nk_all;
-  const int khw = p.KH * p.KW;
   char* const dma_dst = smem + wave * (8 * 128);   // + half * HT + i * (64 * 128) + buffer * KBUF  (lane * 16 is implicit)
 
   auto set_tap = [&](int hh, int tap) {
@@ -177,8 +193,9 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   };
   // K-tile counters of the DMA streams (A runs one K-tile ahead of the MFMAs, W two); all wave-uniform scalars
   const uint32_t w_tap_stride_b = (uint32_t)p.w_tap_stride * EB;
-  int a_tap = SK ? kt0 / kchunks : 0;
+  int a_tap = SK ? kt0 / kchunks : (tap_skip ? __builtin_ctz(~tap_skip) : 0);       // (first tap that is not skipped)
   int a_kc = SK ? kt0 - a_tap * kchunks : 0, w_kc = a_kc;
+  int w_tap = a_tap;
   uint32_t w_tap_b = (uint32_t)a_tap * w_tap_stride_b;     // byte offset of the current W tap
   if (SK && KIND != 0 && a_kc != 0) {                      // a slice that starts inside a tap: issue_a only sets a tap up at its first chunk
     set_tap(0, a_tap);
@@ -191,7 +208,12 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     BLDS16(rA, dst, aoff[hh][0], ka);
     BLDS16(rA, dst + 64 * 128, aoff[hh][1], ka);
   };
-  auto next_a = [&]() { if (++a_kc == kchunks) { a_kc = 0; ++a_tap; } };
+  auto next_a = [&]() {
+    if (++a_kc == kchunks) {
+      a_kc = 0;
+      do { ++a_tap; } while ((tap_skip >> a_tap) & 1u);    // (a_tap <= taps <= 32 > every set bit: the loop stops at the end)
+    }
+  };
   auto issue_w = [&](int buf) {            // both W halves of the W stream's current K-tile
     const int kw = __builtin_amdgcn_readfirstlane((int)(w_tap_b + (uint32_t)w_kc * 128u));
     char* dst = dma_dst + buf * KBUF + 2 * HT;
@@ -199,7 +221,10 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     BLDS16(rW, dst + 64 * 128, woff[0][1], kw);
     BLDS16(rW, dst + HT, woff[1][0], kw);
     BLDS16(rW, dst + HT + 64 * 128, woff[1][1], kw);
-    if (++w_kc == kchunks) { w_kc = 0; w_tap_b += w_tap_stride_b; }
+    if (++w_kc == kchunks) {
+      w_kc = 0;
+      do { ++w_tap; w_tap_b += w_tap_stride_b; } while ((tap_skip >> w_tap) & 1u);
+    }
   };
 
   f32x4 acc[RT][4];

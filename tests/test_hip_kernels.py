@@ -121,6 +121,45 @@ def test_igemm_conv3d(B, T, H, W, Cin, Cout, split, tile):
     assert rel_l2(out, ref) < (3e-5 if split else 3e-6)
 
 
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout,fp8", [(2, 13, 16, 16, 256, 256, False), (3, 4, 16, 16, 128, 256, False), (1, 13, 32, 16, 256, 256, False),
+                                                  (2, 13, 16, 16, 256, 256, True)])
+def test_igemm_conv3d_tap_skip_equals_dense(B, T, H, W, Cin, Cout, fp8):
+    """The 256 x 256 Conv3d kernel leaves out the temporal taps whose input frame is out of range for a WHOLE tile (tiles inside the
+    first / last frame of a sample when H * W is a multiple of 256: 9 of 27 taps).  The dense tap loop (debug_flags bit 8) streams
+    those taps as zero rows instead; both must give the same numbers (adding exact zeros) and agree with F.conv3d."""
+    import ctypes
+    g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
+    x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    M = B * T * H * W
+    geom = L.conv_geom(B, (T, H, W), (3, 3, 3))
+    if fp8:
+        from prediff_amd.packing import pack_conv_fp8, to_fp8
+        a = to_fp8(x.reshape(-1, Cin), 16.0)
+        w_p, sw = pack_conv_fp8(w)
+        kw = dict(alpha=1.0 / (16.0 * sw), fp8=True)
+    else:
+        a, _ = padded_bf16(x.reshape(-1, Cin), False)
+        w_p, _ = pack_conv(w, False)
+        kw = {}
+    dbg = ctypes.c_int.in_dll(L.lib(), "pd_igemm_debug_or")
+    outs = {}
+    try:
+        for flag in (0, 8):
+            dbg.value = flag
+            out = torch.full((M, Cout), float("nan"), device=DEV)
+            L.igemm(a, w_p, M=M, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, bias=bias, out_f32=out, **kw)
+            torch.cuda.synchronize()
+            outs[flag] = out
+    finally:
+        dbg.value = 0
+    assert torch.equal(outs[0], outs[8]) or float((outs[0] - outs[8]).abs().max()) == 0.0       # (-0.0 vs +0.0 would still be equal)
+    if not fp8:
+        ref = F.conv3d(bf(x).permute(0, 4, 1, 2, 3), bf(w), bias, padding=1).permute(0, 2, 3, 4, 1).reshape(M, Cout)
+        assert rel_l2(outs[0], ref) < 3e-6
+
+
 @pytest.mark.parametrize("tile", [0, 7])
 @pytest.mark.parametrize("mode", ["same", "up2", "down2"])
 def test_igemm_conv2d(mode, tile):
