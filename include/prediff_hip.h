@@ -74,10 +74,11 @@ typedef struct pd_igemm_args {
   int64_t splitk_ws_elems;
   int32_t fp8;             /* != 0: A and W hold OCP e4m3 bytes (lda / ldw / strides count elements = bytes; Cin % 128 == 0, lda/ldw % 16 == 0);
                               the tensor scales go in alpha.  Long-K row-wise linear and stride-1 convolution launches only (the 256 x 256
-                              kernel, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales); no split, no batch */
+                              kernel, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales); no hi/lo `split`, no batch.  With a
+                              `splitk_ws` small grids still take the split-K route (fp32 slabs), unless the OUTPUT is e4m3 (below) */
   int32_t out_fp8_log2;    /* k > 0: out_bf16 points to OCP e4m3 BYTES (ld_outb counts bytes) and receives e4m3(v * 2^k), round to nearest
                               even, saturating at +-448 -- the A operand of a following fp8 launch (8-column vector epilogue: N % 8 == 0,
-                              no out_bf16_lo).  0: bf16 output */
+                              no out_bf16_lo; such a launch is never K-split, with or without `splitk_ws`).  0: bf16 output */
 } pd_igemm_args;
 int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
 
@@ -231,15 +232,24 @@ int pd_attn_block_fused(const float* x, float* out, const float* gamma, const fl
 /* The same with a host-side hint: tok_affine = {n_inner, outer, inner, slot} (HOST pointer, or NULL) states that
  * tok_index[c][s] == (c / n_inner) * outer + (c % n_inner) * inner + s * slot for every cuboid c and slot s < vol (un-shifted, un-padded
  * axial cuboids; n_inner <= 0 = no such form): the kernel then computes the token ids instead of loading the table in front of
- * its row gather.  In place (out == x) the epilogue adds into the rows with L2 float atomics (no residual re-read; a row belongs to
- * exactly one workgroup and (acc + b) + x is the same fp32 sum, so results are bit-identical to the load/store form). */
+ * its row gather (bit-identical results either way). */
 int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv, const float* bqkv,
                            const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias, const uint8_t* mask,
                            int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps, const int32_t* tok_affine,
                            pd_stream_t stream);
-/* Engine switches of the fused level-0 kernels (A/B measurements, tests): bit 0 in-place atomic epilogue, bit 1 deep weight ring for
- * launches of at most one workgroup per CU, bit 2 arithmetic token ids.  Default 4 (bits 0 and 1 measured slower / neutral). */
-extern int pd_fused_opts;
+/* ---- Diagnostic / tuning globals (exported DATA symbols; bench.py, scripts/ and tests poke them through ctypes.in_dll for A/B
+ * measurements -- production callers leave them alone).  Every one is process-global and read at launch time. */
+extern int pd_fused_opts;              /* bit 2: arithmetic token ids for affine cuboid tables in pd_attn_block_fused_ex (default 4 = on) */
+extern int pd_igemm_default_tile;      /* 0 = automatic tile choice, else the tile code forced for every pd_igemm launch */
+extern int pd_igemm_debug_or;          /* OR-ed into pd_igemm_args.debug_flags (bit 8: dense tap loop instead of tap skipping) */
+extern int pd_igemm_disable_256;       /* != 0: never hand a launch to the 256 x 256 kernel */
+extern int pd_igemm_256_min_k;         /* smallest K of a row-wise linear launch the 256 x 256 kernel takes */
+extern int pd_igemm_splitk_max_tiles;  /* split-K only for grids of at most this many 256 x 256 tiles */
+extern int pd_ffn_use_64;              /* != 0 (default): units-256 FFNs run ffn64_kernel (64-row tiles) */
+extern int pd_ffn_debug_flags;         /* profiling ablations of the fused FFN (scripts/bench_ffn.py) */
+extern int pd_attn_block_debug_flags;  /* profiling ablations of the fused attention block (scripts/bench_attn_block.py) */
+extern unsigned long long* pd_ffn_trace;         /* device buffer for per-phase clock stamps, or NULL (production) */
+extern unsigned long long* pd_attn_block_trace;  /* likewise */
 
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
  * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PD_LIB_PATH: another build of the same library (A/B of compiler flags, scripts/r03_call10.sh); the default is the in-tree build
+# PD_LIB_PATH: another build of the same library (A/B of compiler flags); the default is the in-tree build
 LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libprediff_hip.so")
 
 ACT = {"none": 0, None: 0, "identity": 0, "gelu": 1, "silu": 2, "leaky": 3, "relu": 4}
@@ -100,7 +100,7 @@ def lib():
         if l.pd_sizeof_igemm_args() != C.sizeof(IgemmArgs) or l.pd_sizeof_cuboid_attn_args() != C.sizeof(CuboidAttnArgs):
             raise PrediffHipError(f"{LIB_PATH} is stale: its argument structs do not match prediff_amd/_lib.py "
                                   f"(rebuild with `make -C prediff_amd/csrc`)")
-        if os.environ.get("PD_FUSED_OPTS"):       # A/B measurements (scripts/r03_*.sh): engine switches of the fused level-0 kernels
+        if os.environ.get("PD_FUSED_OPTS"):       # A/B measurements: engine switch of the fused level-0 kernels
             C.c_int.in_dll(l, "pd_fused_opts").value = int(os.environ["PD_FUSED_OPTS"])
         _lib = l
     return _lib
@@ -344,8 +344,7 @@ def attn_block_fused(x, out, gamma, beta, Wqkv, bqkv, Wp, bp, tok_index, bias, m
 
 
 def fused_opts(value=None):
-    """pd_fused_opts (bit 0 atomic in-place epilogue, bit 1 deep weight ring for small grids, bit 2 arithmetic token ids); returns the
-    previous value."""
+    """pd_fused_opts (bit 2: arithmetic token ids for affine cuboid tables); returns the previous value."""
     v = C.c_int.in_dll(lib(), "pd_fused_opts")
     old = v.value
     if value is not None:

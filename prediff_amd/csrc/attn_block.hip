@@ -100,7 +100,6 @@ struct pd_attn_block_args_k {
   // token of (cuboid c, slot s) = (c / aff_ninner) * aff_outer + (c % aff_ninner) * aff_inner + s * aff_slot when aff_on (un-shifted,
   // un-padded axial cuboids: the host checked the table against this form) -- no dependent table load in front of the row gather
   int aff_on, aff_ninner, aff_outer, aff_inner, aff_slot;
-  int epi_atomic;              // out == x (in place): the epilogue adds acc + b_proj INTO the rows with L2 float atomics (no residual re-read)
   unsigned long long* trace;   // profiling only: per-phase clock stamps of wave 0 of workgroup 600 (null in production)
   int dbg;   // profiling ablations: 1 no weight DMA after chunk 2, 2 no q/k/v GEMMs, 4 no attention core, 8 no proj GEMM,
              // 16 no LN loads, 32 no residual loads, 64 no stores
@@ -109,9 +108,8 @@ struct pd_attn_block_args_k {
 // KT = key tiles of 16 per cuboid: a workgroup's 64 rows are 4 / KT whole cuboids of up to 16 KT slots each (KT = 1: the axial
 // cuboids of the SEVIR-LR grid; KT = 2 / 4: cuboid volumes up to 32 / 64, e.g. 25 and 48 on the 48 x 48 full-resolution grid --
 // the slots beyond the volume are empty rows, 22-25 % of the tile there).
-// NS = slots of the weight ring: 3 for two workgroups per CU (79 KB each); 6 (127 KB, one workgroup per CU) for small grids that
-// leave every CU at most one workgroup anyway: five chunks (80 KB) in flight instead of two, so that a step no longer waits for
-// the L2 -> LDS latency of the chunk it needs next.
+// NS = slots of the weight ring: 3 for two workgroups per CU (79 KB each).  (A 6-slot ring for grids of at most one workgroup per
+// CU was measured in round 3 and gained nothing: the DMA depth is not what a lone tile waits for.)
 template <int C, int KT = 1, int RPC_ = 16 * KT, int NS = 3>
 __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const pd_attn_block_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -600,25 +598,6 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
 
   TRACE();
   // ---- epilogue: acc2 -> per-wave LDS slab [32][OH * 32] fp32 -> + b_proj + x -> out rows of the token table ----
-  if (p.epi_atomic) {
-    // In place (out == x): every output row belongs to exactly one workgroup, so x += acc + b_proj is ONE fire-and-forget
-    // global_atomic_add_f32 per element, executed in the L2 -- no residual re-read (a third of the kernel's HBM traffic and an
-    // exposed round trip at the end of every tile), no LDS staging.  (acc + b) + x is the same fp32 sum as the load/store form:
-    // bit-identical results.  Lane: column oh*128 + wn*32 + lrow, rows wm*32 + (r & 3) + 8 (r >> 2) + 4 lhalf -> every instruction
-    // covers two 128 B row segments.
-#pragma unroll
-    for (int t = 0; t < OH; ++t) {
-      const int n = t * 128 + wn * 32 + lrow;
-      const float bv = p.bp ? p.bp[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int mr = sTok[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf];
-        if (mr >= 0 && !(p.dbg & 64)) unsafeAtomicAdd(p.out + (int64_t)mr * C + n, acc2[t][r] + bv);
-      }
-    }
-    TRACE();
-    return;
-  }
   constexpr int WN = OH * 32;                      // columns per wave: OH pieces of 32
   constexpr int LPR = WN / 4;                      // lanes per row (float4 each): 16 at C = 256
   constexpr int RPP = 64 / LPR;
@@ -686,13 +665,10 @@ extern "C" int pd_attn_block_fused_supported(int C, int heads, int vol) {
   return (C == 256 || C == 128) && heads * 64 == C && vol >= 1 && vol <= 64;
 }
 
-// Engine switches (A/B and tests): bit 0 atomic in-place epilogue, bit 1 deep weight ring for grids of at most one workgroup per CU,
-// bit 2 arithmetic token ids for affine cuboid tables.  Measured (profiles/r03_b_fused_opts_ab.log, 32 trajectories): the atomic
-// epilogue is SLOWER (122 -> 159 us: fp32 L2 atomics run far below the plain store rate), the deep ring gains nothing even with one
-// workgroup per CU (25.6 -> 27.3 us at 4 trajectories: DMA latency is not what a lone tile waits for), the arithmetic ids are
-// neutral.  So only bit 2 is on; the other two stay as opt-in switches with their bit-identity test.
+// Engine switch (A/B and tests): bit 2 = arithmetic token ids for affine cuboid tables (default on; neutral in time, removes a dependent
+// load).  Bits 0 (atomic in-place epilogue) and 1 (deep weight ring for small grids) of round 3 were measured slower / neutral
+// (profiles/r03_b_fused_opts_ab.log: 122 -> 159 us, 25.6 -> 27.3 us) and have been removed from the kernels.
 extern "C" int pd_fused_opts = 4;
-#define PD_NUM_CU 256
 
 extern "C" int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
                                       const float* bqkv, const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias,
@@ -715,17 +691,14 @@ extern "C" int pd_attn_block_fused_ex(const float* x, float* out, const float* g
   a.aff_outer = a.aff_on ? tok_affine[1] : 0;
   a.aff_inner = a.aff_on ? tok_affine[2] : 0;
   a.aff_slot = a.aff_on ? tok_affine[3] : 0;
-  a.epi_atomic = (x == out && (pd_fused_opts & 1)) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const int kt = (vol + 15) / 16;     // key tiles of 16 per cuboid; 3 and 4 tiles: one cuboid per 64-row workgroup
-  // at most one workgroup per CU anyway: the deep-ring variant (one 127 KB workgroup per CU)
-  const bool deep = (pd_fused_opts & 2) && kt == 1 && ((int64_t)B * nc + 3) / 4 <= PD_NUM_CU;
   if (C == 256) {
-    if (kt == 1) return deep ? launch_attn_block<256, 1, 16, 6>(a, s) : launch_attn_block<256, 1>(a, s);
+    if (kt == 1) return launch_attn_block<256, 1>(a, s);
     if (kt == 2) return launch_attn_block<256, 2>(a, s);
     return kt == 3 ? launch_attn_block<256, 3, 64>(a, s) : launch_attn_block<256, 4>(a, s);
   }
-  if (kt == 1) return deep ? launch_attn_block<128, 1, 16, 6>(a, s) : launch_attn_block<128, 1>(a, s);
+  if (kt == 1) return launch_attn_block<128, 1>(a, s);
   if (kt == 2) return launch_attn_block<128, 2>(a, s);
   return kt == 3 ? launch_attn_block<128, 3, 64>(a, s) : launch_attn_block<128, 4>(a, s);
 }

@@ -27,7 +27,7 @@
 // the halo tile normalised with scale 0, i.e. diagonal stripes of wrong pixels in random tiles, different on every launch.  Three
 // builds with different register allocation and with the statistics coming from LDS or from global memory failed at exactly that
 // instruction; one wait state (s_nop 0) in front of it, scalar v_mul_f32 instead, or one workgroup per CU gave 0 wrong tiles in
-// 100+ launches of 896 workgroups.  The same three instructions alone (scripts/dbg, not shipped) do not reproduce it, so the cause is
+// 100+ launches of 896 workgroups.  The same three instructions alone (scripts/ubench/hazards) do not reproduce it, so the cause is
 // not pinned; without SLP packing the kernel has no packed-f32 VALU at all (which the MFMA loop does not want beside it anyway) and
 // the stress in tests/test_hip_kernels.py (1280 workgroups x 16 launches, bit-equal and against torch) passes.  Record:
 // profiles/r03_h_conv2d_gn_hazard.md.
@@ -123,10 +123,20 @@ __global__ void __launch_bounds__(256, 2) conv2d_gn_kernel(const pd_conv2d_gn_ar
       if (inb[i]) v[i] = *(const float4*)(p.x + (((int64_t)n * p.H + gy) * p.Wd + gx) * p.Cin + c);
     }
     WG_BARRIER();                                    // every wave is done with the previous slice's tile
-    const float mean = mr.x, rstd = mr.y;
+    const float mean = mr.x;
+    float rstd = mr.y;
+    // Pinned in SOURCE (not only by the Makefile's -fno-slp-vectorize): one wait state between the s_waitcnt of the statistics load
+    // and the first use of rstd, and the four scale products as scalar v_mul_f32 the vectoriser cannot pack -- both forms measured
+    // 0 wrong tiles (header note); the Makefile additionally fails the build if any v_pk_*_f32 shows up in this object.
+    asm volatile("s_nop 0" : "+v"(rstd));
+    auto mul1 = [](float a, float b) __attribute__((always_inline)) {
+      float r;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      return r;
+    };
     // this thread's four channels: y = x * sc + sh with sc = rstd gamma, sh = beta - mean rstd gamma; SiLU as y * rcp(1 + exp2(-y log2 e))
     // (v_exp_f32 / v_rcp_f32, 1 ulp each: far below the bf16 rounding that follows) -- the staging is VALU work in front of the MFMAs
-    const float sc0 = rstd * g4.x, sc1 = rstd * g4.y, sc2 = rstd * g4.z, sc3 = rstd * g4.w;
+    const float sc0 = mul1(rstd, g4.x), sc1 = mul1(rstd, g4.y), sc2 = mul1(rstd, g4.z), sc3 = mul1(rstd, g4.w);
     const float sh0 = b4.x - mean * sc0, sh1 = b4.y - mean * sc1, sh2 = b4.z - mean * sc2, sh3 = b4.w - mean * sc3;
     auto silu = [](float y) __attribute__((always_inline)) {
       return y * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));

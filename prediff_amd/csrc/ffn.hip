@@ -38,7 +38,6 @@ struct pd_ffn_args_k {
   int M, Hd, act;
   float eps;
   uint32_t w1_bytes, w2_bytes;
-  int epi_atomic;              // out == x (in place): the epilogue adds acc + b2 INTO the rows with L2 float atomics (no residual re-read)
   unsigned long long* trace;   // profiling only: per-slot clock stamps of waves 0 and 4 of workgroup 300 (null in production)
   int dbg;   // profiling ablations: 1 no weight DMA after chunk 0, 2 no GEMM-1, 4 no activation + H store, 8 no GEMM-2,
              // 16 no LN loads, 32 no residual loads, 64 no stores
@@ -444,21 +443,6 @@ __global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ff
     }
   }
 
-  if (p.epi_atomic) {
-    // in place (out == x): x += acc + b2 as one fire-and-forget L2 float atomic per element (see csrc/attn_block.hip); a row belongs
-    // to one workgroup, (acc + b) + x is the same fp32 sum as the load/store form
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int n = t * 128 + wn * 32 + lrow;
-      const float bv = p.b2[n];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-        if (m < p.M && !(p.dbg & 64)) unsafeAtomicAdd(p.out + (int64_t)m * C + n, acc2[t][r] + bv);
-      }
-    }
-    return;
-  }
   // ---- epilogue: acc2 -> per-wave LDS slab [32][64] fp32 -> + b2 + x -> out ----
   constexpr int WN = 64;                           // columns per wave: 2 pieces of 32
   constexpr int LPR = WN / 4, RPP = 64 / LPR, NPASS = 32 / RPP;
@@ -548,13 +532,8 @@ extern "C" int pd_ffn_fused(const float* x, float* out, const float* gamma, cons
   a.w2_bytes = (uint32_t)((int64_t)C * Hd * 2);
   a.dbg = pd_ffn_debug_flags;
   a.trace = pd_ffn_trace;
-  extern int pd_fused_opts;        // csrc/attn_block.hip: bit 0 atomic in-place epilogue, bit 1 deep weight ring for small grids
-  a.epi_atomic = (x == out && (pd_fused_opts & 1)) ? 1 : 0;
-  // at most one workgroup per CU anyway (<= 256 tiles of 64 rows): the four-slot ring, one 140 KB workgroup per CU
-  const bool deep = (pd_fused_opts & 2) && (M + 63) / 64 <= 256 && Hd * 4 + 4 * 32768 + 8192 <= 160 * 1024;
   hipStream_t s = (hipStream_t)stream;
 #define PD_FFN(ACT)                                  \
-  if (C == 256 && pd_ffn_use_64 && deep) return launch_ffn64<ACT, 4>(a, s);   \
   if (C == 256 && pd_ffn_use_64 && Hd * 4 + 2 * 32768 + 8192 <= 80 * 1024) return launch_ffn64<ACT>(a, s);   \
   if (C == 256) return launch_ffn<256, ACT>(a, s);   \
   if (C == 128) return launch_ffn<128, ACT>(a, s);   \

@@ -332,7 +332,9 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
       pd_set_error("pd_igemm: fp8 operands are built for row-wise linear layers and stride-1, un-upsampled Conv3d launches only");
       return PD_ERR_UNSUPPORTED;
     }
-    const int ks = (a.tile == 0 && !pd_igemm_disable_256) ? pd_igemm256_ksplit(a, kind) : 0;     // small grids: K-slices as extra workgroups
+    // small grids: K-slices as extra workgroups -- never with an e4m3 OUTPUT: the split-K reduce kernel stores 2-byte bf16 rows, which
+    // would overrun the caller's 1-byte e4m3 buffer (the un-split epilogue is the only e4m3 producer)
+    const int ks = (a.tile == 0 && !pd_igemm_disable_256 && a.out_fp8_log2 <= 0) ? pd_igemm256_ksplit(a, kind) : 0;
     if (ks >= 2) {
       a.ksplit = ks;
       return pd_igemm256_launch_splitk(a, kind, s);

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   // so 2 of 13 tiles drop 9 of their 27 taps -- the zero-padding taps are left out of both DMA streams and of the MFMA loop instead of
   // being streamed as zero rows (bit `tap` of tap_skip; debug_flags bit 8 keeps the dense loop for A/B runs).
   uint32_t tap_skip = 0;
-  if (KIND == 2 && !SK && p.KT > 1 && p.taps <= 32 && khw < 32 && !(p.debug_flags & 8)) {
+  if (KIND == 2 && !SK && p.KT > 1 && p.taps < 32 && khw < 32 && !(p.debug_flags & 8)) {   // (< 32: `tap_skip >> taps` stays a defined shift)
     const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
     const int m_last = min(p.M, m0 + BM) - 1;
     const int b_first = m0 / thw_o;
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   auto next_a = [&]() {
     if (++a_kc == kchunks) {
       a_kc = 0;
-      do { ++a_tap; } while ((tap_skip >> a_tap) & 1u);    // (a_tap <= taps <= 32 > every set bit: the loop stops at the end)
+      do { ++a_tap; } while ((tap_skip >> a_tap) & 1u);    // (a_tap <= taps < 32 and bit `taps` is never set: the loop stops at the end)
     }
   };
   auto issue_w = [&](int buf) {            // both W halves of the W stream's current K-tile

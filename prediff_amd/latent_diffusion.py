@@ -15,17 +15,16 @@ Same constructor keywords and call conventions; what changes:
 The knowledge-alignment hook (`set_alignment`) is honoured with the reference semantics; its gradient stays in
 PyTorch autograd (north_star) and therefore runs outside the captured graph.
 """
-from contextlib import contextmanager
 from typing import Any, Callable, Dict, Optional, Sequence, Union
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
 from .distributions import DiagonalGaussianDistribution
 from .ema import LitEma
+from .loss_eval import LossEvaluationMixin
 from .schedule import make_beta_schedule, make_ddim_sampling_parameters, make_ddim_timesteps, schedule_tables
 
 
@@ -91,7 +90,7 @@ def _on_own_device(fn):
     return wrapped
 
 
-class LatentDiffusion(_module_base()):
+class LatentDiffusion(LossEvaluationMixin, _module_base()):
 
     def __init__(self, torch_nn_module: nn.Module, layout: str = "NTHWC", data_shape: Sequence[int] = (10, 128, 128, 4),
                  timesteps=1000, beta_schedule="linear", loss_type="l2", monitor="val/loss", use_ema=True,
@@ -298,101 +297,7 @@ class LatentDiffusion(_module_base()):
         raise NotImplementedError("get_input is dataset dependent: re-implement it in the subclass "
                                   "(e.g. train_sevirlr_prediff.py:733-759)")
 
-    # ------------------------------------------------------------------------------------------------ loss evaluation, EMA
-    # The engine has no backward pass (the denoiser runs on HIP kernels outside autograd), so what is reusable of the training side is
-    # everything that does NOT need a gradient: the noising q_sample, the loss of a batch (`forward` / `p_losses`: validation losses,
-    # loss curves of a checkpoint), the EMA shadow weights and `validation_step`'s with / without-EMA evaluation.
-    @contextmanager
-    def ema_scope(self, context=None):
-        """latent_diffusion.py:280-293: run the body with the EMA weights swapped into the denoiser (a no-op without use_ema)."""
-        if self.use_ema:
-            self.model_ema.store(self.torch_nn_module.parameters())
-            self.model_ema.copy_to(self.torch_nn_module)
-            if context is not None:
-                print(f"{context}: Switched to EMA weights")
-        try:
-            yield None
-        finally:
-            if self.use_ema:
-                self.model_ema.restore(self.torch_nn_module.parameters())
-                if context is not None:
-                    print(f"{context}: Restored training weights")
-
-    def on_train_batch_end(self, *args, **kwargs):
-        if self.use_ema:
-            self.model_ema(self.torch_nn_module)
-
-    def get_loss(self, pred, target, mean=True):
-        """latent_diffusion.py:502-515"""
-        if self.loss_type == "l1":
-            loss = (target - pred).abs()
-            return loss.mean() if mean else loss
-        if self.loss_type == "l2":
-            return F.mse_loss(target, pred) if mean else F.mse_loss(target, pred, reduction="none")
-        raise NotImplementedError(f"unknown loss type '{self.loss_type}'")
-
-    @torch.no_grad()
-    def p_losses(self, x_start, cond, t, noise=None):
-        """latent_diffusion.py:517-551: (loss, loss_dict) of the noise-prediction objective for latents x_start at steps t -- values only
-        (no autograd graph: the denoiser forward runs on the HIP kernels)."""
-        noise = torch.randn_like(x_start) if noise is None else noise
-        x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
-        model_output = self.apply_model(x_noisy, t, cond)
-        prefix = "train" if self.training else "val"
-        if self.parameterization == "x0":
-            target = x_start
-        elif self.parameterization == "eps":
-            target = noise
-        else:
-            raise NotImplementedError()
-        loss_dict = {}
-        loss_simple = self.get_loss(model_output, target, mean=False).mean(dim=self.loss_mean_dim)
-        loss_dict[f"{prefix}/loss_simple"] = loss_simple.mean()
-        logvar_t = self.logvar[t]
-        loss = loss_simple / torch.exp(logvar_t) + logvar_t
-        if self.learn_logvar:
-            loss_dict[f"{prefix}/loss_gamma"] = loss.mean()
-            loss_dict["logvar"] = self.logvar.data.mean()
-        loss = self.l_simple_weight * loss.mean()
-        loss_vlb = self.get_loss(model_output, target, mean=False).mean(dim=self.loss_mean_dim)
-        loss_vlb = (self.lvlb_weights[t] * loss_vlb).mean()
-        loss_dict[f"{prefix}/loss_vlb"] = loss_vlb
-        loss = loss + self.original_elbo_weight * loss_vlb
-        loss_dict[f"{prefix}/loss"] = loss
-        return loss, loss_dict
-
-    @torch.no_grad()
-    @_on_own_device
-    def forward(self, batch, verbose=False):
-        """latent_diffusion.py:447-476: (loss, loss_dict) of one batch -- get_input (dataset dependent, subclass), VAE-encode the target,
-        draw t, encode the condition, p_losses.  Loss VALUES: see p_losses."""
-        x, c = self.get_input(batch)[:2]
-        device = self.betas.device
-        x = x.to(device)
-        B = x.shape[self.batch_axis]
-        z = self._from_frames(self.encode_first_stage(self._to_frames(x)), B) if self.first_stage_model is not None else x
-        t = torch.randint(0, self.num_timesteps, (B,), device=device).long()
-        if self.cond_stage_model is not None:
-            assert c is not None
-            zc = self.cond_stage_forward(c)
-        else:
-            zc = c if isinstance(c, torch.Tensor) else c.get("y", None)
-        return self.p_losses(z, zc, t, noise=None)
-
-    def training_step(self, batch, batch_idx):
-        raise NotImplementedError("prediff_amd.LatentDiffusion evaluates losses (forward / validation_step) but cannot train: the "
-                                  "denoiser forward runs on HIP kernels outside autograd (no backward pass)")
-
-    @torch.no_grad()
-    def validation_step(self, batch, batch_idx):
-        """latent_diffusion.py:487-495: the losses of a batch with the current and with the EMA weights."""
-        _, loss_dict_no_ema = self(batch)
-        with self.ema_scope():
-            _, loss_dict_ema = self(batch)
-            loss_dict_ema = {key + "_ema": v for key, v in loss_dict_ema.items()}
-        self.log_dict(loss_dict_no_ema, prog_bar=False, logger=True, on_step=False, on_epoch=True)
-        self.log_dict(loss_dict_ema, prog_bar=False, logger=True, on_step=False, on_epoch=True)
-        return {**loss_dict_no_ema, **loss_dict_ema}
+    # loss evaluation / EMA / validation_step: loss_eval.LossEvaluationMixin
 
     def apply_model(self, x_noisy, t, cond):
         out = self.torch_nn_module(x_noisy, t, cond)

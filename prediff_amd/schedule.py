@@ -50,25 +50,23 @@ def schedule_tables(betas: np.ndarray, v_posterior: float = 0.0) -> Dict[str, np
 
 
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=False) -> np.ndarray:
+    """The DDPM indices a DDIM run visits, each shifted up by one (so that the last one reaches the final alpha).  `verbose` is
+    accepted for signature compatibility and ignored."""
+    T, S = int(num_ddpm_timesteps), int(num_ddim_timesteps)
     if ddim_discr_method == "uniform":
-        c = num_ddpm_timesteps // num_ddim_timesteps
-        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+        picked = np.arange(0, T, T // S)                          # every (T // S)-th training step
     elif ddim_discr_method == "quad":
-        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * 0.8), num_ddim_timesteps)) ** 2).astype(int)
+        picked = np.square(np.linspace(0.0, np.sqrt(0.8 * T), S)).astype(int)   # quadratic spacing over the first 80 %
     else:
-        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
-    steps_out = ddim_timesteps + 1      # "+1 to get the final alpha values right"
-    if verbose:
-        print(f"Selected timesteps for ddim sampler: {steps_out}")
-    return steps_out
+        raise NotImplementedError(f"unknown ddim discretization method '{ddim_discr_method}' (uniform | quad)")
+    return picked + 1
 
 
 def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=False):
-    alphacums = np.asarray(alphacums)
-    alphas = alphacums[ddim_timesteps]
-    alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
-    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
-    if verbose:
-        print(f"Selected alphas for ddim sampler: a_t: {alphas}; a_(t-1): {alphas_prev}")
-        print(f"For the chosen value of eta, which is {eta}, this results in the following sigma_t schedule {sigmas}")
-    return sigmas, alphas, alphas_prev
+    """(sigma_t, alpha_bar_t, alpha_bar_{t-1}) on the DDIM grid; the step before the first grid point is training step 0."""
+    ac = np.asarray(alphacums)
+    steps = np.asarray(ddim_timesteps)
+    a_t = ac[steps]
+    a_before = np.concatenate([ac[:1], ac[steps[:-1]]])
+    sigma = eta * np.sqrt((1 - a_before) / (1 - a_t) * (1 - a_t / a_before))
+    return sigma, a_t, a_before

@@ -568,9 +568,8 @@ def test_attn_block_fused_vs_oracle(golden, case):
 @pytest.mark.parametrize("shape,cuboid,Cn,heads,B", [((13, 16, 16), (13, 1, 1), 256, 4, 2), ((13, 16, 16), (1, 16, 1), 256, 4, 6),
                                                       ((13, 16, 16), (1, 1, 16), 256, 4, 1), ((5, 8, 8), (1, 8, 1), 128, 2, 3)])
 def test_fused_engine_switches(shape, cuboid, Cn, heads, B):
-    """pd_fused_opts: the in-place atomic epilogue (bit 0), the deep weight ring of launches with at most one workgroup per CU
-    (bit 1; B = 6 at the v1 grid is 312 workgroups: the two-per-CU ring) and the arithmetic token ids (bit 2) change the schedule,
-    not the arithmetic: every combination gives bit-identical rows, for the attention block and for the FFN."""
+    """pd_fused_opts bit 2 (arithmetic token ids instead of the table load) changes the address path, not the arithmetic: bit-identical
+    rows for the attention block; the FFN (no switch) is deterministic across repeats."""
     from prediff_amd.cuboid_geometry import attention_tables
     T, H, W = shape
     ntok = T * H * W
@@ -592,7 +591,7 @@ def test_fused_engine_switches(shape, cuboid, Cn, heads, B):
     res = {}
     old = L.fused_opts()
     try:
-        for opts in (0, 1, 2, 4, 7):
+        for opts in (0, 4):
             L.fused_opts(opts)
             xa = x.clone()
             L.attn_block_fused(xa, xa, gamma, beta, wq_p, None, wp_p, bp, tok, bias, None, B, ntok, Cn, heads, nc, vol, (Cn // heads) ** -0.5,
@@ -604,7 +603,7 @@ def test_fused_engine_switches(shape, cuboid, Cn, heads, B):
     finally:
         L.fused_opts(old)
     assert bool(torch.isfinite(res[0][0]).all()) and not torch.equal(res[0][0], x)
-    for opts in (1, 2, 4, 7):
+    for opts in (4,):
         assert torch.equal(res[opts][0], res[0][0]), f"attention block: pd_fused_opts = {opts} changes the result"
         assert torch.equal(res[opts][1], res[0][1]), f"FFN: pd_fused_opts = {opts} changes the result"
 

@@ -97,6 +97,15 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(so, name), f"{name} declared in prediff_hip.h but not exported"
     assert declared == set(L.EXPORTED_SYMBOLS), declared ^ set(L.EXPORTED_SYMBOLS)
+    # exported DATA symbols (diagnostic / tuning globals): declared in the header <=> exported by the library
+    data_decl = set(re.findall(r"^extern\s+[a-z ]+\*?\s*(pd_[a-z0-9_]+);", hdr, flags=re.M))
+    assert len(data_decl) >= 11, data_decl
+    for name in data_decl:
+        ctypes.c_int.in_dll(so, name)          # ValueError if the library does not export it
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
+    exported_data = {ln.split()[-1] for ln in nm.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "BDd" and ln.split()[-1].startswith("pd_")}
+    assert exported_data == data_decl, exported_data ^ data_decl
     assert L.lib().pd_abi_version() == 1
     assert ctypes.sizeof(L.IgemmArgs) % 8 == 0
 
@@ -145,3 +154,21 @@ def test_conv2d_gn_silu_supported_predicate():
     assert not L.conv2d_gn_silu_supported(16, 24, 128, 128, 32)        # W % 16
     assert not L.conv2d_gn_silu_supported(16, 16, 128, 64, 32)         # Cout % 128
     assert not L.conv2d_gn_silu_supported(16, 16, 64, 128, 32)         # (Cin / G) % 4
+
+
+def test_product_ddim_helpers_against_reference_golden(golden):
+    """The PRODUCT's make_ddim_timesteps / make_ddim_sampling_parameters (prediff_amd/schedule.py) against what the imported
+    reference recorded (tests/golden/gen_golden.py:246-254; reference diffusion/utils.py:42-70) -- not through the oracle."""
+    from prediff_amd import schedule as S
+    g = golden("schedule")
+    ac = np.cumprod(1.0 - S.make_beta_schedule("linear", 1000)).astype(np.float32).astype(np.float64)
+    for n in (10, 50, 100):
+        steps = S.make_ddim_timesteps("uniform", n, 1000)
+        assert steps.dtype == g[f"ddim_steps_{n}"].dtype and np.array_equal(steps, g[f"ddim_steps_{n}"])
+        for eta in (0.0, 1.0):
+            sig, a, ap = S.make_ddim_sampling_parameters(ac, np.minimum(steps, 999), eta)
+            assert np.allclose(sig, g[f"ddim_sigma_{n}_{int(eta)}"], rtol=1e-12, atol=0)
+            assert np.allclose(a, g[f"ddim_a_{n}"], rtol=1e-12, atol=0) and np.allclose(ap, g[f"ddim_aprev_{n}"], rtol=1e-12, atol=0)
+    assert np.array_equal(S.make_ddim_timesteps("quad", 20, 1000), g["ddim_steps_quad_20"])
+    with pytest.raises(NotImplementedError):
+        S.make_ddim_timesteps("cubic", 10, 1000)
