@@ -237,6 +237,21 @@ int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const
                            const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias, const uint8_t* mask,
                            int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps, const int32_t* tok_affine,
                            pd_stream_t stream);
+/* One (CuboidSelfAttentionLayer, PositionwiseFFN) pair of StackCuboidSelfAttentionBlock.forward (cuboid_transformer.py:1147-1156:
+ * x = x + attn(x); x = ffn(x) with the FFN's own residual; attention :812-966, FFN :182-208) in ONE launch, bf16 engine, for units 256,
+ * 4 heads of 64, hidden 1024, GELU, cuboid volume <= 16, no qkv bias, no attention mask (every level-0 axial layer of the SEVIR-LR
+ * denoiser); in place allowed.  The rows of two cuboids stay in the registers of one wave from the first LayerNorm to the last
+ * residual: x is read once and written once (csrc/pair_block.hip).
+ *   wstream: 48 chunks of 32 KB = the four weight matrices as bf16 MFMA fragments in consumption order (prediff_amd/packing.py:
+ *            pack_pair_block documents the layout);  vecs: 3584 floats = LN1 gamma, beta, proj bias, LN2 gamma, beta, FFN-2 bias
+ *            (256 each), FFN-1 bias (1024), relative-position bias zero padded to (4, 16, 16)  (pack_pair_vecs).
+ *   tok_index [nc][vol] / tok_affine (HOST pointer, 4 ints, or NULL): as for pd_attn_block_fused_ex; one of them is required.
+ *   parts: 1 = attention + residual only, 2 = FFN only (row-wise: nc, vol and the token map are ignored), 3 = the pair. */
+int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol, int act);
+int pd_attn_ffn_pair(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
+                     const int32_t* tok_affine, int B, int ntok, int nc, int vol, float scale, float eps_attn, float eps_ffn,
+                     int parts, pd_stream_t stream);
+
 /* ---- Diagnostic / tuning globals (exported DATA symbols; bench.py, scripts/ and tests poke them through ctypes.in_dll for A/B
  * measurements -- production callers leave them alone).  Every one is process-global and read at launch time. */
 extern int pd_fused_opts;              /* bit 2: arithmetic token ids for affine cuboid tables in pd_attn_block_fused_ex (default 4 = on) */
@@ -250,6 +265,7 @@ extern int pd_ffn_debug_flags;         /* profiling ablations of the fused FFN (
 extern int pd_attn_block_debug_flags;  /* profiling ablations of the fused attention block (scripts/bench_attn_block.py) */
 extern unsigned long long* pd_ffn_trace;         /* device buffer for per-phase clock stamps, or NULL (production) */
 extern unsigned long long* pd_attn_block_trace;  /* likewise */
+extern unsigned long long* pd_pair_trace;        /* likewise (pd_attn_ffn_pair; reserved) */
 
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
  * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]

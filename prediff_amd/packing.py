@@ -83,3 +83,63 @@ def pack_linear_fp8(weight: torch.Tensor, k_pad: Optional[int] = None):
     w[:, :K] = weight.detach().float()
     s = fp8_weight_scale(w)
     return to_fp8(w, s), s
+
+
+# ---------------------------------------------------------------------------------------------------- (attention, FFN) pair kernel
+PAIR_CHUNK_BYTES = 32768          # csrc/pair_block.hip: 32 fragments of 1 KB
+PAIR_VEC_FLOATS = 3584
+
+
+def _mfma_frags(w: torch.Tensor) -> torch.Tensor:
+    """bf16 (N, K) -> (N/16, K/32, 64 lanes, 8) fragments of v_mfma_f32_16x16x32_bf16 with the k order of pd_attn_ffn_pair:
+    lane = 16 * kg + f holds W[16 F + f][32 KB + 16 (j >> 2) + 4 kg + (j & 3)], j = 0..7 -- the order in which the PREVIOUS stage's
+    accumulator registers (lane = (token, 4 consecutive features per 16-feature tile)) line up as the other MFMA operand."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0
+    v = w.reshape(N // 16, 16, K // 32, 2, 4, 4)          # F, f, KB, jh, kg, jl   (k = 32 KB + 16 jh + 4 kg + jl)
+    v = v.permute(0, 2, 4, 1, 3, 5)                        # F, KB, kg, f, jh, jl
+    return v.reshape(N // 16, K // 32, 64, 8).contiguous()
+
+
+def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """The weight stream of pd_attn_ffn_pair (units 256, 4 heads, hidden 1024): 48 chunks of 32 KB in consumption order --
+    per head h: Wq_h, Wk_h, Wv_h ([64 x 256]: fragment i = 4 ks + dt), Wproj[:, 64 h : 64 h + 64] ([256 x 64]: i = 16 st + nt);
+    then W1_0, (W1_{j+1}, W2_j) for j = 0..14, W2_15 (W1_j = rows 64 j .. of (1024, 256); W2_j = columns 64 j .. of (256, 1024))."""
+    assert tuple(wqkv.shape) == (768, 256) and tuple(wproj.shape) == (256, 256) and tuple(w1.shape) == (1024, 256) and tuple(w2.shape) == (256, 1024)
+    bf = lambda t: t.detach().to(torch.bfloat16)
+    fq, fp, f1, f2 = _mfma_frags(bf(wqkv)), _mfma_frags(bf(wproj)), _mfma_frags(bf(w1)), _mfma_frags(bf(w2))
+
+    def rows_chunk(fr, F0):                                # [64 features x 256 k]: i = 4 ks + dt
+        return fr[F0:F0 + 4].permute(1, 0, 2, 3).reshape(32, 64, 8)
+
+    def cols_chunk(fr, KB0):                               # [256 features x 64 k]: i = 16 st + nt
+        return fr[:, KB0:KB0 + 2].permute(1, 0, 2, 3).reshape(32, 64, 8)
+
+    chunks = []
+    for h in range(4):
+        for kind in range(3):
+            chunks.append(rows_chunk(fq, (kind * 256 + 64 * h) // 16))
+        chunks.append(cols_chunk(fp, 2 * h))
+    chunks.append(rows_chunk(f1, 0))
+    for j in range(16):
+        if j + 1 < 16:
+            chunks.append(rows_chunk(f1, 4 * (j + 1)))
+        chunks.append(cols_chunk(f2, 2 * j))
+    out = torch.stack(chunks).contiguous()
+    assert out.numel() * 2 == 48 * PAIR_CHUNK_BYTES
+    return out
+
+
+def pack_pair_vecs(ln1_g, ln1_b, bproj, ln2_g, ln2_b, b2, b1, rel_bias) -> torch.Tensor:
+    """fp32 tables of pd_attn_ffn_pair: LN1 gamma, beta, proj bias, LN2 gamma, beta, FFN-2 bias (256 each), FFN-1 bias (1024),
+    relative-position bias (4 heads, vol, vol) zero padded to (4, 16, 16)."""
+    dev = ln1_g.device
+    z256 = torch.zeros(256, device=dev)
+    rb = torch.zeros(4, 16, 16, device=dev)
+    vol = rel_bias.shape[-1]
+    rb[:, :vol, :vol] = rel_bias.detach().float()
+    parts = [ln1_g, ln1_b, bproj if bproj is not None else z256, ln2_g, ln2_b, b2 if b2 is not None else z256,
+             b1 if b1 is not None else torch.zeros(1024, device=dev), rb.reshape(-1)]
+    v = torch.cat([t.detach().float().reshape(-1).to(dev) for t in parts]).contiguous()
+    assert v.numel() == PAIR_VEC_FLOATS
+    return v

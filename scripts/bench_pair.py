@@ -1,0 +1,87 @@
+"""pd_attn_ffn_pair (csrc/pair_block.hip) at the v1 level-0 shapes against the two round-3 kernels it replaces (pd_attn_block_fused +
+pd_ffn_fused): agreement and time.  Run on the GPU box:  python scripts/bench_pair.py [B]"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from prediff_amd import _lib as L
+from prediff_amd.cuboid_geometry import attention_tables
+from prediff_amd.packing import pack_linear, pack_pair_block, pack_pair_vecs
+
+DEV = "cuda"
+LLL = ("l", "l", "l")
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    shape, Cn, heads, Hd = (13, 16, 16), 256, 4, 1024
+    ntok = shape[0] * shape[1] * shape[2]
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = (torch.randn(B, ntok, Cn, generator=g) * 1.5 + 0.2).to(DEV)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    g1, b1n, g2, b2n = 1 + r(Cn, sc=0.1), r(Cn, sc=0.1), 1 + r(Cn, sc=0.1), r(Cn, sc=0.1)
+    wqkv, wp = r(3 * Cn, Cn, sc=1 / math.sqrt(Cn)), r(Cn, Cn, sc=1 / math.sqrt(Cn))
+    w1, w2 = r(Hd, Cn, sc=1 / math.sqrt(Cn)), r(Cn, Hd, sc=1 / math.sqrt(Hd))
+    bp, fb1, fb2 = r(Cn, sc=0.1), r(Hd, sc=0.1), r(Cn, sc=0.1)
+    wq_p, wp_p, w1_p, w2_p = (pack_linear(w, False)[0] for w in (wqkv, wp, w1, w2))
+    ws = pack_pair_block(wqkv, wp, w1, w2)
+    scale = (Cn // heads) ** -0.5
+    for cuboid in ((13, 1, 1), (1, 16, 1), (1, 1, 16)):
+        tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+        vol, nc = tabs["vol"], tabs["nc"]
+        bias = r(heads, vol, vol, sc=0.5)
+        tok = tabs["tok_index"].to(DEV)
+        vecs = pack_pair_vecs(g1, b1n, bp, g2, b2n, fb2, fb1, bias)
+        assert L.attn_ffn_pair_supported(Cn, heads, Hd, vol)
+
+        def old_attn(t):
+            L.attn_block_fused(t, t, g1, b1n, wq_p, None, wp_p, bp, tok, bias, None, B, ntok, Cn, heads, nc, vol, scale, tok_affine=tabs["affine"])
+
+        def old_ffn(t):
+            L.ffn_fused(t, t, g2, b2n, w1_p, fb1, w2_p, fb2, B * ntok, Cn, Hd, act="gelu")
+
+        def new(t, parts, aff=True):
+            L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"] if aff else None, parts=parts)
+
+        ref_a = x.clone(); old_attn(ref_a)
+        ref_f = x.clone(); old_ffn(ref_f)
+        ref_p = ref_a.clone(); old_ffn(ref_p)
+        res = {}
+        for parts, ref in ((2, ref_f), (1, ref_a), (3, ref_p)):
+            t = x.clone(); new(t, parts); torch.cuda.synchronize()
+            res[parts] = t
+            print(f"cuboid {cuboid} parts {parts}: rel-L2 of the update vs the round-3 kernels {rel(t - x, ref - x):.3e}   finite {bool(torch.isfinite(t).all())}")
+        t2 = x.clone(); new(t2, 3, aff=False); torch.cuda.synchronize()
+        print(f"   table-driven token ids == affine: {torch.equal(t2, res[3])};  repeat bit-equal: ", end="")
+        t3 = x.clone(); new(t3, 3); torch.cuda.synchronize(); print(torch.equal(t3, res[3]))
+        buf = x.clone()
+        ta, tf = timeit(lambda: old_attn(buf)), timeit(lambda: old_ffn(buf))
+        buf = x.clone()
+        tn = {p: timeit(lambda: new(buf, p)) for p in (1, 2, 3)}
+        gf_a, gf_f = B * 1.7965e9, B * 3.4897e9 * 1.0
+        print(f"   B={B}: round-3 attention {ta:.1f} us + FFN {tf:.1f} us = {ta + tf:.1f} us;  pair kernel: attention-only {tn[1]:.1f}, FFN-only {tn[2]:.1f}, "
+              f"pair {tn[3]:.1f} us  ({(gf_a + gf_f) / tn[3] / 1e6:.0f} TFLOP/s, {(gf_a + gf_f) / tn[3] / 1e6 / 2500:.3f} of peak)")
+
+
+if __name__ == "__main__":
+    main()
