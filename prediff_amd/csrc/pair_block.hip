@@ -36,8 +36,10 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 namespace pairk {
 constexpr int C = 256, HEADS = 4, HID = 1024;
-constexpr int PF = 4, PFN = PF + 1;                // weight fragments in flight (LDS latency ~ 4 x 32 MFMA clocks)
+constexpr int PF = 6, PFN = 8;                     // weight fragments in flight (LDS latency ~ 4 x 32 MFMA clocks) / register slots: the slot of
+                                                   // fragment i is i % PFN in EVERY chunk, so PFN must divide the 32 fragments of a chunk
 constexpr int CHUNK = 32768, NSLOT = 4, NFRAG = 32;
+static_assert(NFRAG % PFN == 0 && PF + 2 <= PFN && PF % 2 == 0 && PF + 4 <= 15, "fragment pipeline geometry");
 constexpr int DMA_PER_WAVE = CHUNK / 4 / 1024;     // 8 x 1 KB per wave per chunk
 // fp32 tables in LDS (float offsets) == layout of the `vecs` argument
 constexpr int T_LN1G = 0, T_LN1B = 256, T_BP = 512, T_LN2G = 768, T_LN2B = 1024, T_B2 = 1280, T_B1 = 1536, T_RB = 2560, T_FLOATS = 3584;
@@ -58,6 +60,8 @@ struct pd_pair_args_k {
   int ntiles;
   uint32_t wbytes;
   unsigned long long* trace;
+  float* dbg_buf;             // PD_PAIR_DEBUG builds only: [rows][256] dump of one intermediate of head 0 (dbg_stage)
+  int dbg_stage;
 };
 
 __device__ __forceinline__ float pk_rows4_max(float v) {
@@ -72,13 +76,16 @@ __device__ __forceinline__ float pk_rows4_sum(float v) {
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// fp32 -> bf16 (RNE) through the compiler's own v_cvt_pk_bf16_f32 (NOT common.h's inline-asm form: hipcc pads no hazard wait states
+// around an asm statement, and here the conversions sit directly between MFMAs -- an asm v_cvt reading a fresh MFMA result, or an MFMA
+// reading a fresh asm v_cvt result, gets stale registers; measured: wrong O tiles / NaNs in the first build of this kernel)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 __device__ __forceinline__ bf16x8 pk_pack8(const f32x4& a, const f32x4& b) {
-  u32x4 r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
-  return __builtin_bit_cast(bf16x8, r);
+  const bf16x4 lo = __builtin_convertvector(a, bf16x4), hi = __builtin_convertvector(b, bf16x4);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
-  u32x2 r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
-  return __builtin_bit_cast(s16x4, r);
+  return __builtin_bit_cast(s16x4, __builtin_convertvector(a, bf16x4));
 }
 // GELU as x * sigmoid(x (a + b x^2 + c x^4)), x^2 clamped where the sigmoid is saturated (the quartic term would turn the polynomial
 // over at |x| ~ 11).  Coefficients: minimax fit against 0.5 x (1 + erf(x / sqrt 2)) on [-9, 9], max abs error 2.5e-5; pre-multiplied by
@@ -92,12 +99,28 @@ __device__ __forceinline__ float pk_gelu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// the argument of exp2 in pk_gelu (first stage of the software-pipelined form)
+__device__ __forceinline__ float pk_gelu_arg(float x) {
+  constexpr float L2E = -1.4426950408889634f;
+  const float x2 = fminf(x * x, 52.0f);
+  float pl = fmaf(x2, L2E * -7.03034059e-04f, L2E * 7.40112943e-02f);
+  pl = fmaf(x2, pl, L2E * 1.59501577f);
+  return x * pl;
+}
+
 #define PK_WLD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 // wait until at most N LDS operations are outstanding; the fragment about to be consumed is tied to the wait (in / out operand), so
 // that no MFMA reading it can be moved in front of the wait
 #define PK_WAIT_FRAG(frag, N) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N))
 #define PK_LDS_F4(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+#define PK_LANDED(v) asm volatile("" : "+v"(v))
+#define PK_DRAIN()                                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), \
+               "+v"(w[7]))
 
+#ifndef PD_PAIR_DEBUG
+#define PD_PAIR_DEBUG 0
+#endif
 // PARTS: bit 0 attention, bit 1 FFN
 template <int PARTS>
 __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
@@ -135,39 +158,72 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   const uint32_t vtab = (uint32_t)(uintptr_t)smem + (uint32_t)g * 16u;                     // fp32 tables: 4 floats at column 4 g
   const uint32_t vrb = (uint32_t)(uintptr_t)smem + (uint32_t)((T_RB + q * 16 + 4 * g) * 4);
 
+#if PD_PAIR_DEBUG
+  int tr_n = 0;
+#define PK_TRACE() do { if (p.trace && blockIdx.x == 7 && tid == 0 && tr_n < 256) p.trace[tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
+#else
+#define PK_TRACE() do {} while (0)
+#endif
   int cc = 0;                                       // chunks consumed by this workgroup
-  bf16x8 w[PFN];                                    // fragment pipeline (runs on across chunks, tiles and phases)
+  int vm_extra = 0;                                 // mid-chunk syncs that still have the 32 row loads of the next tile in flight
+  bf16x8 w[PFN] = {};                               // fragment pipeline (runs on across chunks, tiles and phases)
 
-  // in the middle of chunk cc: chunk cc+1 has landed for everybody, everybody is past chunk cc-1 -> its slot takes chunk cc+3
+  // In the middle of chunk cc: chunk cc+1 has landed for everybody, everybody is past chunk cc-1 -> its slot takes chunk cc+3.
+  // The counted wait allows the 8 DMA instructions of chunk cc+2 (and, right after the next tile's rows were requested, those 32
+  // loads, which are younger than the chunk waited for) to stay in flight.  Only loads are in flight here (the row stores of a
+  // tile are drained before its successor's first chunk), and loads retire in order.
   auto mid_sync = [&]() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
+    if (vm_extra > 0) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + 32) : "memory");
+      --vm_extra;
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
+    }
     issue_next();
   };
-  // One chunk = 32 fragments.  extra(): NEXTRA other LDS reads issued at the start (they land before iteration PF).
-  // body(i, frag): the MFMAs of fragment i (+ interleaved VALU work).
-#define PK_CHUNK(NEXTRA, EXTRA_STMT, BODY_STMT)                                                   \
+  // One chunk = 32 fragments = 16 groups of two.  Per group: two fragment reads three groups ahead, ONE counted wait, the four MFMAs
+  // of the group's two fragments (BODY_STMT, once per fragment: `i`, `wf`) and HOOK_STMT (`gi`): independent VALU work for their shadow.
+  // EXTRA_STMT: NEXTRA other LDS reads issued at the start; they have landed at group PF / 2, where LANDED_STMT re-defines their
+  // destinations (PK_LANDED).
+  // RULE for every asynchronous (inline-asm) LDS read in this kernel: its destination must not live long BEFORE its wait -- the
+  // compiler believes the register is valid from the asm statement on and may park a long-lived value in an AGPR at once, i.e. copy
+  // it before the data has arrived.  So: fragments are consumed three groups after their read; table values are re-defined
+  // (PK_LANDED, no instruction) right after the wait that covers them and only that new value lives on; and wherever more than a few
+  // instructions separate two chunk loops the fragments in flight are drained first (PK_DRAIN).  scripts/check_async_lds.py replays
+  // the LDS queue over the generated ISA and fails the build if any instruction touches a destination that is still in flight.
+#define PK_RD(i_)                                                                                 \
+  if ((i_) < NFRAG) PK_WLD(w[(i_) % PFN], va_, (i_) * 1024);                                       \
+  else PK_WLD(w[(i_) % PFN], vn_, ((i_) - NFRAG) * 1024)
+#define PK_CHUNK(NEXTRA, EXTRA_STMT, LANDED_STMT, BODY_STMT, HOOK_STMT)                           \
   {                                                                                               \
     const uint32_t va_ = vbase + (uint32_t)(cc & (NSLOT - 1)) * CHUNK;                            \
     const uint32_t vn_ = vbase + (uint32_t)((cc + 1) & (NSLOT - 1)) * CHUNK;                      \
-    _Pragma("unroll") for (int i = 0; i < NFRAG; ++i) {                                           \
-      if (i == 0) { EXTRA_STMT; }                                                                 \
-      if (i == NFRAG / 2) mid_sync();                                                             \
-      if (i + PF < NFRAG) PK_WLD(w[(i + PF) % PFN], va_, (i + PF) * 1024);                        \
-      else PK_WLD(w[(i + PF) % PFN], vn_, (i + PF - NFRAG) * 1024);                               \
-      PK_WAIT_FRAG(w[i % PFN], PF + (i < PF ? (NEXTRA) : 0));                                     \
+    _Pragma("unroll") for (int gi = 0; gi < NFRAG / 2; ++gi) {                                    \
+      if (gi == 0) { EXTRA_STMT; }                                                                \
+      if (gi == NFRAG / 4) mid_sync();                                                            \
+      PK_RD(2 * gi + PF);                                                                         \
+      PK_RD(2 * gi + PF + 1);                                                                     \
+      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[(2 * gi) % PFN]), "+v"(w[(2 * gi + 1) % PFN]) \
+                   : "n"(PF + (2 * gi < PF ? (NEXTRA) : 0)));                                     \
+      if (gi == PF / 2) { LANDED_STMT; }                                                          \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-      { const bf16x8 wf = w[i % PFN]; BODY_STMT; }                                                \
+      { const int i = 2 * gi; const bf16x8 wf = w[i % PFN]; BODY_STMT; }                          \
+      { const int i = 2 * gi + 1; const bf16x8 wf = w[i % PFN]; BODY_STMT; }                      \
+      { HOOK_STMT; }                                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
     ++cc;                                                                                         \
   }
+#define PK_MFMA_T(ACC, AF) /* transposed product on a [64 features x 256 k] chunk: fragment i = 4 ks + dt */ \
+  ACC[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[0][i >> 2], ACC[0][i & 3], 0, 0, 0);    \
+  ACC[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[1][i >> 2], ACC[1][i & 3], 0, 0, 0)
+#define PK_MFMA_OUT(OF) /* x^T += W[256 outputs x 64 k] act^T: fragment i = 16 st + nt */                      \
+  acc[0][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[0][i >> 4], acc[0][i & 15], 0, 0, 0);      \
+  acc[1][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[1][i >> 4], acc[1][i & 15], 0, 0, 0)
 
-  bool first = true;
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    // ---- rows of this wave's two cuboids: lane = (slot q, column group g) ----
-    const float* xrow[2];
-    float* orow[2];
-    bool valid[2];
+  // rows of a tile's cuboids for this lane = (slot q, column group g); an invalid slot reads row 0 (always 32 load instructions: the
+  // counted waits above rely on it) and stores nothing
+  auto tile_rows = [&](int tile, int64_t (&off)[2], bool (&valid)[2]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int64_t gc = (int64_t)tile * 8 + wave * 2 + c;
@@ -179,27 +235,51 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
         if (tok >= 0 && tok < p.ntok) row = b * p.ntok + tok;
       }
       valid[c] = row >= 0;
-      xrow[c] = p.x + (int64_t)(row < 0 ? 0 : row) * C + 4 * g;
-      orow[c] = p.out + (int64_t)(row < 0 ? 0 : row) * C + 4 * g;
+      off[c] = (int64_t)(row < 0 ? 0 : row) * C + 4 * g;
     }
-    // ---- x rows -> acc[c][nt] = x[row][16 nt + 4 g .. +3]: the MFMA C layout of every transposed product below ----
-    f32x4 acc[2][16];
+  };
+  f32x4 xn[2][16];                                  // the rows of the NEXT tile (requested while the current one is in its last chunks)
+  auto load_rows = [&](const int64_t (&off)[2]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int nt = 0; nt < 16; ++nt) {
-        acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (valid[c]) acc[c][nt] = *(const f32x4*)(xrow[c] + nt * 16);
-      }
-    if (first) {
-      // chunks 0..2 landed (the x loads above are younger: the compiler's own wait for them covers the DMA), visible to every wave
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-#pragma unroll
-      for (int i = 0; i < PF; ++i) PK_WLD(w[i], vbase, i * 1024);
-      first = false;
-    }
+      for (int nt = 0; nt < 16; ++nt) xn[c][nt] = *(const f32x4*)(p.x + off[c] + nt * 16);
+  };
 
+  int64_t roff[2], noff[2];
+  bool rvalid[2], nvalid[2];
+  tile_rows(blockIdx.x, noff, nvalid);
+  load_rows(noff);
+  // chunks 0..2 landed (the row loads above are younger: this wait covers both), visible to every wave; fragment prologue
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < PF; ++i) PK_WLD(w[i], vbase, i * 1024);
+  PK_DRAIN();
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    PK_TRACE();   // tile start
+    // ---- acc[c][nt] = x[row][16 nt + 4 g .. +3]: the MFMA C layout of every transposed product below ----
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      roff[c] = noff[c];
+      rvalid[c] = nvalid[c];
+#pragma unroll
+      for (int nt = 0; nt < 16; ++nt) acc[c][nt] = xn[c][nt];
+    }
+    const bool has_next = tile + (int)gridDim.x < p.ntiles;
+    if (has_next) tile_rows(tile + gridDim.x, noff, nvalid);
+    PK_TRACE();   // rows in registers
+
+#if PD_PAIR_DEBUG
+    auto dump4 = [&](int stage, int c, const f32x4& a, const f32x4& b, const f32x4& cc4, const f32x4& d) {
+      if (p.dbg_buf && p.dbg_stage == stage && rvalid[c]) {
+        float* o = p.dbg_buf + roff[c];
+        *(f32x4*)(o) = a; *(f32x4*)(o + 16) = b; *(f32x4*)(o + 32) = cc4; *(f32x4*)(o + 48) = d;
+      }
+    };
+#endif
     bf16x8 af[2][8];                                // LayerNorm output as B-operand fragments: [cuboid][k-step of 32]
     // LayerNorm over the 256 columns of a row (64 in this lane, the rest in lanes q + 16 g'), -> af
     auto layer_norm = [&](int t_gamma, int t_beta, float eps) {
@@ -261,10 +341,17 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
           for (int c = 0; c < 2; ++c) acc[c][half * 8 + i] += bv[i];
       }
     };
+    bool at_tile_start = true;   // the row stores of the previous tile may still be in flight: drained in front of the first chunk
+    auto enter_chunks = [&]() {
+      if (at_tile_start) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      at_tile_start = false;
+    };
 
     if constexpr (DO_ATTN) {
       layer_norm(T_LN1G, T_LN1B, p.eps1);
       add_vec(T_BP);
+      enter_chunks();
+      PK_TRACE();   // LN1 done
 #pragma unroll 1
       for (int h = 0; h < HEADS; ++h) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -277,10 +364,10 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
-        PK_CHUNK(0, (void)0, {
-          t[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][i >> 2], t[0][i & 3], 0, 0, 0);
-          t[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][i >> 2], t[1][i & 3], 0, 0, 0);
-        })
+        PK_CHUNK(0, (void)0, (void)0, PK_MFMA_T(t, af), (void)0)
+#if PD_PAIR_DEBUG
+        if (h == 0) { dump4(1, 0, t[0][0], t[0][1], t[0][2], t[0][3]); dump4(1, 1, t[1][0], t[1][1], t[1][2], t[1][3]); }
+#endif
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           qf[c][0] = pk_pack8(t[c][0], t[c][1]);
@@ -288,15 +375,18 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
         }
+        PK_TRACE();   // q done
         // ---------------- k^T = Wk_h a^T ----------------
-        PK_CHUNK(1, PK_LDS_F4(rb, vrb_h, 0), {
-          t[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][i >> 2], t[0][i & 3], 0, 0, 0);
-          t[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][i >> 2], t[1][i & 3], 0, 0, 0);
-        })
+        PK_CHUNK(1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), (void)0)
+        PK_DRAIN();
+        PK_TRACE();   // k done
         // ---------------- S^T = K Q^T, softmax over the keys (registers + two row swaps) ----------------
         s16x4 pf[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+#if PD_PAIR_DEBUG
+          if (h == 0) dump4(2, c, t[c][0], t[c][1], t[c][2], t[c][3]);
+#endif
           kf[c][0] = pk_pack8(t[c][0], t[c][1]);
           kf[c][1] = pk_pack8(t[c][2], t[c][3]);
           f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][0], qf[c][0], z4, 0, 0, 0);
@@ -309,6 +399,9 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
             sc[r] = v;
             mx = fmaxf(mx, v);
           }
+#if PD_PAIR_DEBUG
+          if (h == 0) dump4(3, c, s4, f32x4{sc[0], sc[1], sc[2], sc[3]}, rb, z4);
+#endif
           mx = pk_rows4_max(mx);
           float sum = 0.f;
 #pragma unroll
@@ -319,96 +412,154 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
           sum = pk_rows4_sum(sum);
           const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;
           pf[c] = pk_pack4(f32x4{sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv});
+#if PD_PAIR_DEBUG
+          if (h == 0) dump4(4, c, f32x4{sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv}, f32x4{mx, sum, inv, 0.f}, z4, z4);
+#endif
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
         }
+        PK_TRACE();   // softmax done
         // ---------------- v = a Wv_h^T (plain product: lane = feature, 4 consecutive tokens -> the A operand of O^T = V^T P^T) -------
-        PK_CHUNK(0, (void)0, {
+        PK_CHUNK(0, (void)0, (void)0, {
           t[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i >> 2], wf, t[0][i & 3], 0, 0, 0);
           t[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i >> 2], wf, t[1][i & 3], 0, 0, 0);
-        })
+        }, (void)0)
+        PK_DRAIN();
         bf16x8 of[2][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           f32x4 o[4];
+#if PD_PAIR_DEBUG
+          if (h == 0) dump4(5, c, t[c][0], t[c][1], t[c][2], t[c][3]);
+#endif
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk_pack4(t[c][dt]), pf[c], z4, 0, 0, 0);
+#if PD_PAIR_DEBUG
+          if (h == 0) dump4(6, c, o[0], o[1], o[2], o[3]);
+#endif
           of[c][0] = pk_pack8(o[0], o[1]);
           of[c][1] = pk_pack8(o[2], o[3]);
         }
+        PK_TRACE();   // v + PV done
         // ---------------- x^T += Wp[:, head h] O_h^T ----------------
-        PK_CHUNK(0, (void)0, {
-          acc[0][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, of[0][i >> 4], acc[0][i & 15], 0, 0, 0);
-          acc[1][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, of[1][i >> 4], acc[1][i & 15], 0, 0, 0);
-        })
+        PK_CHUNK(0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
       }
+      PK_DRAIN();                                   // (a LayerNorm or the row stores follow)
+      PK_TRACE();   // attention done
     }
 
     if constexpr (DO_FFN) {
       layer_norm(T_LN2G, T_LN2B, p.eps2);
       add_vec(T_B2);
+      enter_chunks();
+      PK_TRACE();   // LN2 done
+      // Chunk order: W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0..13, W2_14, W2_15.  gelu(h_j) has the two chunks between W1_j and W2_j to
+      // itself, as three software-pipelined stages (polynomial | exp, +1 | rcp, mul) of one value per fragment group: independent
+      // short chains beside the MFMAs instead of one 9-deep dependent chain per value (a lone wave hides no VALU latency).
       const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4);
       f32x4 hc[2][4], hn[2][4], b1n[4];
+      float ga[32], gd[32];
+#define PK_HV(H, v) H[(v) >> 4][((v) >> 2) & 3][(v) & 3]
+#define PK_GELU_GROUP(H, VB, NPER, GI)                                                                                    \
+  _Pragma("unroll") for (int u_ = 0; u_ < (NPER); ++u_) {                                                                 \
+    if ((GI) < 16) { const int v_ = (VB) + (GI) * (NPER) + u_; ga[v_] = pk_gelu_arg(PK_HV(H, v_)); }                      \
+    if ((GI) >= 1 && (GI) < 17) { const int v_ = (VB) + ((GI) - 1) * (NPER) + u_; gd[v_] = 1.0f + __builtin_amdgcn_exp2f(ga[v_]); } \
+    if ((GI) >= 2 && (GI) < 18) { const int v_ = (VB) + ((GI) - 2) * (NPER) + u_; PK_HV(H, v_) = PK_HV(H, v_) * __builtin_amdgcn_rcpf(gd[v_]); } \
+  }
+#define PK_B1_FETCH(ADDR) { PK_LDS_F4(b1n[0], ADDR, 0); PK_LDS_F4(b1n[1], ADDR, 64); PK_LDS_F4(b1n[2], ADDR, 128); PK_LDS_F4(b1n[3], ADDR, 192); }
+#define PK_B1_LANDED() { PK_LANDED(b1n[0]); PK_LANDED(b1n[1]); PK_LANDED(b1n[2]); PK_LANDED(b1n[3]); }
       // b1 of chunk 0: plain wait (the fragment prologue in flight is older and simply lands first)
-#pragma unroll
-      for (int ht = 0; ht < 4; ++ht) PK_LDS_F4(b1n[ht], vb1, ht * 64);
+      PK_B1_FETCH(vb1)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1n[0]), "+v"(b1n[1]), "+v"(b1n[2]), "+v"(b1n[3]));
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
-      // ---------------- h_0^T = W1_0 a^T + b1 ; the loads in its shadow fetch b1 of chunk 1 ----------------
-      PK_CHUNK(4, { PK_LDS_F4(b1n[0], vb1, 256); PK_LDS_F4(b1n[1], vb1, 256 + 64); PK_LDS_F4(b1n[2], vb1, 256 + 128); PK_LDS_F4(b1n[3], vb1, 256 + 192); }, {
-        hc[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][i >> 2], hc[0][i & 3], 0, 0, 0);
-        hc[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][i >> 2], hc[1][i & 3], 0, 0, 0);
-      })
+      const uint32_t vb1_1 = vb1 + 256u;
+      // ---------------- h_0^T = W1_0 a^T + b1 (in its shadow: b1 of chunk 1) ----------------
+      PK_CHUNK(4, PK_B1_FETCH(vb1_1), PK_B1_LANDED(), PK_MFMA_T(hc, af), (void)0)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) hn[c][ht] = b1n[ht];
+      PK_TRACE();   // W1_0 done
+      // ---------------- h_1 beside the whole of gelu(h_0) (two values per group); b1 of chunk 2 ----------------
+      const uint32_t vb1_2 = vb1 + 512u;
+      PK_CHUNK(4, PK_B1_FETCH(vb1_2), PK_B1_LANDED(), PK_MFMA_T(hn, af), PK_GELU_GROUP(hc, 0, 2, gi))
+      PK_GELU_GROUP(hc, 0, 2, 16)
+      PK_GELU_GROUP(hc, 0, 2, 17)
+      bf16x8 hfr[2][2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        hfr[c][0] = pk_pack8(hc[c][0], hc[c][1]);
+        hfr[c][1] = pk_pack8(hc[c][2], hc[c][3]);
+      }
+      PK_TRACE();   // W1_1 done
+      // invariant: hfr = gelu(h_j) as fragments, hn = h_{j+1} (pre-activation), b1n = b1 of chunk j + 2
 #pragma unroll 1
-      for (int j = 0; j < HID / 64; ++j) {
-        bf16x8 hfr[2][2];
-        if (j + 1 < HID / 64) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht) hn[c][ht] = b1n[ht];
-          // W1_{j+1} (MFMA) beside gelu(h_j) (VALU), one value per fragment; b1 of chunk j+2 fetched in its shadow
-          const uint32_t vb1n = vb1 + (uint32_t)(j + 2 < HID / 64 ? j + 2 : 0) * 256u;
-          PK_CHUNK(4, { PK_LDS_F4(b1n[0], vb1n, 0); PK_LDS_F4(b1n[1], vb1n, 64); PK_LDS_F4(b1n[2], vb1n, 128); PK_LDS_F4(b1n[3], vb1n, 192); }, {
-            hn[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][i >> 2], hn[0][i & 3], 0, 0, 0);
-            hn[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][i >> 2], hn[1][i & 3], 0, 0, 0);
-            hc[i >> 4][(i >> 2) & 3][i & 3] = pk_gelu(hc[i >> 4][(i >> 2) & 3][i & 3]);
-          })
-        } else {
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) hc[c][ht][r] = pk_gelu(hc[c][ht][r]);
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          hfr[c][0] = pk_pack8(hc[c][0], hc[c][1]);
-          hfr[c][1] = pk_pack8(hc[c][2], hc[c][3]);
-        }
-        // ---------------- x^T += W2[:, chunk j] gelu(h_j)^T ----------------
-        PK_CHUNK(0, (void)0, {
-          acc[0][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hfr[0][i >> 4], acc[0][i & 15], 0, 0, 0);
-          acc[1][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hfr[1][i >> 4], acc[1][i & 15], 0, 0, 0);
-        })
+      for (int j = 0; j < HID / 64 - 2; ++j) {
+        if (j < 2) PK_TRACE();   // FFN iteration start
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int ht = 0; ht < 4; ++ht) hc[c][ht] = hn[c][ht];
+          for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
+        const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < HID / 64 ? j + 3 : 0) * 256u;
+        // x^T += W2[:, chunk j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (cuboid 0)
+        PK_CHUNK(0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 1, gi))
+        PK_GELU_GROUP(hn, 0, 1, 16)
+        PK_GELU_GROUP(hn, 0, 1, 17)
+        if (j < 2) PK_TRACE();
+        // h_{j+2}^T = W1_{j+2} a^T + b1   beside the second half of gelu(h_{j+1}); b1 of chunk j + 3
+        PK_CHUNK(4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 16, 1, gi))
+        PK_GELU_GROUP(hn, 16, 1, 16)
+        PK_GELU_GROUP(hn, 16, 1, 17)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
+          hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
+#pragma unroll
+          for (int ht = 0; ht < 4; ++ht) hn[c][ht] = hc[c][ht];
+        }
       }
+      PK_TRACE();   // FFN loop done
+      // the LayerNorm fragments are dead: their registers take the rows of this workgroup's next tile, requested now so that the
+      // HBM round trip hides behind the last two chunks
+      if (has_next) {
+        load_rows(noff);
+        vm_extra = 2;
+      } else {
+        // (defined on both paths: otherwise the compiler keeps the previous tile's 128 registers alive through the whole loop body)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int nt = 0; nt < 16; ++nt) xn[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      // W2_14 beside the whole of gelu(h_15), then W2_15
+      PK_CHUNK(0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 2, gi))
+      PK_GELU_GROUP(hn, 0, 2, 16)
+      PK_GELU_GROUP(hn, 0, 2, 17)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
+        hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
+      }
+      PK_CHUNK(0, (void)0, (void)0, PK_MFMA_OUT(hfr), (void)0)
+      PK_DRAIN();                                   // (the row stores and the next tile's LayerNorm follow)
+      PK_TRACE();   // FFN done
     }
 
     // ---- the rows go back (same lane -> (row, columns) map as the load) ----
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-      if (valid[c]) {
+      if (rvalid[c]) {
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt) *(f32x4*)(orow[c] + nt * 16) = acc[c][nt];
+        for (int nt = 0; nt < 16; ++nt) *(f32x4*)(p.out + roff[c] + nt * 16) = acc[c][nt];
       }
+    if constexpr (!DO_FFN) {
+      load_rows(noff);                              // (attention alone: no window in which the fragments are dead; exposed.  Without a
+                                                    //  next tile noff still names this tile's rows: a harmless re-read)
+    }
+    PK_TRACE();   // stores issued
   }
   // nothing of this workgroup may still be writing LDS when its allocation is handed to the next one
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -437,6 +588,8 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
 }
 
 extern "C" unsigned long long* pd_pair_trace = nullptr;
+extern "C" float* pd_pair_dbg_buf = nullptr;    // (PD_PAIR_DEBUG builds)
+extern "C" int pd_pair_dbg_stage = 0;
 
 extern "C" int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol, int act) {
   return C == 256 && heads == 4 && hidden == 1024 && vol >= 1 && vol <= 16 && act == PD_ACT_GELU;
@@ -454,6 +607,8 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   a.scale = scale; a.eps1 = eps_attn; a.eps2 = eps_ffn;
   a.wbytes = (uint32_t)(CH_ALL * CHUNK);
   a.trace = pd_pair_trace;
+  a.dbg_buf = pd_pair_dbg_buf;
+  a.dbg_stage = pd_pair_dbg_stage;
   if (parts & 1) {
     PD_CHECK_ARG(nc > 0 && vol >= 1 && vol <= 16, "pd_attn_ffn_pair: cuboid volume %d not in 1..16", vol);
     PD_CHECK_ARG(tok_index || (tok_affine && tok_affine[0] > 0), "pd_attn_ffn_pair: neither a token table nor its affine form");

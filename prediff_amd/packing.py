@@ -104,7 +104,8 @@ def _mfma_frags(w: torch.Tensor) -> torch.Tensor:
 def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     """The weight stream of pd_attn_ffn_pair (units 256, 4 heads, hidden 1024): 48 chunks of 32 KB in consumption order --
     per head h: Wq_h, Wk_h, Wv_h ([64 x 256]: fragment i = 4 ks + dt), Wproj[:, 64 h : 64 h + 64] ([256 x 64]: i = 16 st + nt);
-    then W1_0, (W1_{j+1}, W2_j) for j = 0..14, W2_15 (W1_j = rows 64 j .. of (1024, 256); W2_j = columns 64 j .. of (256, 1024))."""
+    then W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0..13, W2_14, W2_15 (W1_j = rows 64 j .. of (1024, 256); W2_j = columns 64 j .. of
+    (256, 1024)): gelu(h_j) runs beside the two chunks between W1_j and W2_j."""
     assert tuple(wqkv.shape) == (768, 256) and tuple(wproj.shape) == (256, 256) and tuple(w1.shape) == (1024, 256) and tuple(w2.shape) == (256, 1024)
     bf = lambda t: t.detach().to(torch.bfloat16)
     fq, fp, f1, f2 = _mfma_frags(bf(wqkv)), _mfma_frags(bf(wproj)), _mfma_frags(bf(w1)), _mfma_frags(bf(w2))
@@ -121,10 +122,11 @@ def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w
             chunks.append(rows_chunk(fq, (kind * 256 + 64 * h) // 16))
         chunks.append(cols_chunk(fp, 2 * h))
     chunks.append(rows_chunk(f1, 0))
+    chunks.append(rows_chunk(f1, 4))
     for j in range(16):
-        if j + 1 < 16:
-            chunks.append(rows_chunk(f1, 4 * (j + 1)))
         chunks.append(cols_chunk(f2, 2 * j))
+        if j + 2 < 16:
+            chunks.append(rows_chunk(f1, 4 * (j + 2)))
     out = torch.stack(chunks).contiguous()
     assert out.numel() * 2 == 48 * PAIR_CHUNK_BYTES
     return out

@@ -83,5 +83,36 @@ def main():
               f"pair {tn[3]:.1f} us  ({(gf_a + gf_f) / tn[3] / 1e6:.0f} TFLOP/s, {(gf_a + gf_f) / tn[3] / 1e6 / 2500:.3f} of peak)")
 
 
+
+
+def trace(B=32):
+    """PD_PAIR_DEBUG build: phase clock stamps of wave 0 of workgroup 7 (s_memtime, 100 MHz constant clock on gfx950? printed raw)."""
+    import ctypes
+    shape, Cn, heads, Hd = (13, 16, 16), 256, 4, 1024
+    ntok = 13 * 256
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(B, ntok, Cn, generator=g).to(DEV)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    ws = pack_pair_block(r(768, 256, sc=1 / 16), r(256, 256, sc=1 / 16), r(1024, 256, sc=1 / 16), r(256, 1024, sc=1 / 32))
+    tabs = attention_tables(shape, (1, 16, 1), (0, 0, 0), LLL, "zeros")
+    vecs = pack_pair_vecs(1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), 1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), r(1024, sc=.1), r(4, 16, 16, sc=.5))
+    tok = tabs["tok_index"].to(DEV)
+    tr = torch.zeros(256, dtype=torch.int64, device=DEV)
+    for _ in range(3):
+        L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"], parts=3)
+    ctypes.c_void_p.in_dll(L.lib(), "pd_pair_trace").value = tr.data_ptr()
+    L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"], parts=3)
+    torch.cuda.synchronize()
+    ctypes.c_void_p.in_dll(L.lib(), "pd_pair_trace").value = None
+    t = tr.cpu().tolist()
+    n = max(i for i, v in enumerate(t) if v) + 1
+    d = [t[i + 1] - t[i] for i in range(n - 1)]
+    print("stamps", n, "deltas (s_memtime ticks):", d)
+    print("total", t[n - 1] - t[0])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[2] == "trace":
+        trace(int(sys.argv[1]))
+    else:
+        main()
