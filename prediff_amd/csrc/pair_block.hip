@@ -143,6 +143,9 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   int n_issued = 0, kid = CH_FIRST;
   const uint32_t dma_voff = (uint32_t)lane * 16u;
   auto issue_next = [&]() {
+#if PD_PAIR_ABLATE & 1
+    if (n_issued >= 3) { ++n_issued; return; }
+#endif
     char* d = smem + RING_OFF + (n_issued & (NSLOT - 1)) * CHUNK + wave * (DMA_PER_WAVE * 1024);
     const uint32_t so = (uint32_t)kid * CHUNK + (uint32_t)wave * (DMA_PER_WAVE * 1024);
 #pragma unroll
@@ -191,9 +194,18 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // (PK_LANDED, no instruction) right after the wait that covers them and only that new value lives on; and wherever more than a few
   // instructions separate two chunk loops the fragments in flight are drained first (PK_DRAIN).  scripts/check_async_lds.py replays
   // the LDS queue over the generated ISA and fails the build if any instruction touches a destination that is still in flight.
+// compile-time ablations for profiling builds (-DPD_PAIR_ABLATE=bits): 1 no weight DMA after the prologue, 2 no fragment reads,
+// 4 no MFMAs in the chunk bodies, 8 no GELU work in the chunk hooks
+#ifndef PD_PAIR_ABLATE
+#define PD_PAIR_ABLATE 0
+#endif
+#define PK_RD_ON (!(PD_PAIR_ABLATE & 2))
+#define PK_MFMA_ON (!(PD_PAIR_ABLATE & 4))
 #define PK_RD(i_)                                                                                 \
-  if ((i_) < NFRAG) PK_WLD(w[(i_) % PFN], va_, (i_) * 1024);                                       \
-  else PK_WLD(w[(i_) % PFN], vn_, ((i_) - NFRAG) * 1024)
+  if (PK_RD_ON) {                                                                                 \
+    if ((i_) < NFRAG) PK_WLD(w[(i_) % PFN], va_, (i_) * 1024);                                     \
+    else PK_WLD(w[(i_) % PFN], vn_, ((i_) - NFRAG) * 1024);                                        \
+  }
 #define PK_CHUNK(NEXTRA, EXTRA_STMT, LANDED_STMT, BODY_STMT, HOOK_STMT)                           \
   {                                                                                               \
     const uint32_t va_ = vbase + (uint32_t)(cc & (NSLOT - 1)) * CHUNK;                            \
@@ -215,11 +227,15 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     ++cc;                                                                                         \
   }
 #define PK_MFMA_T(ACC, AF) /* transposed product on a [64 features x 256 k] chunk: fragment i = 4 ks + dt */ \
-  ACC[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[0][i >> 2], ACC[0][i & 3], 0, 0, 0);    \
-  ACC[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[1][i >> 2], ACC[1][i & 3], 0, 0, 0)
+  if (PK_MFMA_ON) {                                                                                        \
+    ACC[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[0][i >> 2], ACC[0][i & 3], 0, 0, 0);    \
+    ACC[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[1][i >> 2], ACC[1][i & 3], 0, 0, 0);    \
+  }
 #define PK_MFMA_OUT(OF) /* x^T += W[256 outputs x 64 k] act^T: fragment i = 16 st + nt */                      \
-  acc[0][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[0][i >> 4], acc[0][i & 15], 0, 0, 0);      \
-  acc[1][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[1][i >> 4], acc[1][i & 15], 0, 0, 0)
+  if (PK_MFMA_ON) {                                                                                            \
+    acc[0][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[0][i >> 4], acc[0][i & 15], 0, 0, 0);      \
+    acc[1][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[1][i >> 4], acc[1][i & 15], 0, 0, 0);      \
+  }
 
   // rows of a tile's cuboids for this lane = (slot q, column group g); an invalid slot reads row 0 (always 32 load instructions: the
   // counted waits above rely on it) and stores nothing
@@ -461,7 +477,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       float ga[32], gd[32];
 #define PK_HV(H, v) H[(v) >> 4][((v) >> 2) & 3][(v) & 3]
 #define PK_GELU_GROUP(H, VB, NPER, GI)                                                                                    \
-  _Pragma("unroll") for (int u_ = 0; u_ < (NPER); ++u_) {                                                                 \
+  if (!(PD_PAIR_ABLATE & 8)) _Pragma("unroll") for (int u_ = 0; u_ < (NPER); ++u_) {                                                                 \
     if ((GI) < 16) { const int v_ = (VB) + (GI) * (NPER) + u_; ga[v_] = pk_gelu_arg(PK_HV(H, v_)); }                      \
     if ((GI) >= 1 && (GI) < 17) { const int v_ = (VB) + ((GI) - 1) * (NPER) + u_; gd[v_] = 1.0f + __builtin_amdgcn_exp2f(ga[v_]); } \
     if ((GI) >= 2 && (GI) < 18) { const int v_ = (VB) + ((GI) - 2) * (NPER) + u_; PK_HV(H, v_) = PK_HV(H, v_) * __builtin_amdgcn_rcpf(gd[v_]); } \
@@ -588,8 +604,10 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
 }
 
 extern "C" unsigned long long* pd_pair_trace = nullptr;
-extern "C" float* pd_pair_dbg_buf = nullptr;    // (PD_PAIR_DEBUG builds)
+#if PD_PAIR_DEBUG
+extern "C" float* pd_pair_dbg_buf = nullptr;    // (profiling / debugging builds only: scripts/debug_pair.py)
 extern "C" int pd_pair_dbg_stage = 0;
+#endif
 
 extern "C" int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol, int act) {
   return C == 256 && heads == 4 && hidden == 1024 && vol >= 1 && vol <= 16 && act == PD_ACT_GELU;
@@ -607,8 +625,13 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   a.scale = scale; a.eps1 = eps_attn; a.eps2 = eps_ffn;
   a.wbytes = (uint32_t)(CH_ALL * CHUNK);
   a.trace = pd_pair_trace;
+#if PD_PAIR_DEBUG
   a.dbg_buf = pd_pair_dbg_buf;
   a.dbg_stage = pd_pair_dbg_stage;
+#else
+  a.dbg_buf = nullptr;
+  a.dbg_stage = 0;
+#endif
   if (parts & 1) {
     PD_CHECK_ARG(nc > 0 && vol >= 1 && vol <= 16, "pd_attn_ffn_pair: cuboid volume %d not in 1..16", vol);
     PD_CHECK_ARG(tok_index || (tok_affine && tok_affine[0] > 0), "pd_attn_ffn_pair: neither a token table nor its affine form");

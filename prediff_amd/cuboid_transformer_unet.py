@@ -19,6 +19,7 @@ What is different is *how* the forward runs (inference only, no autograd):
     throughput mode the benchmark quotes.
 """
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -26,7 +27,7 @@ from torch import nn
 
 from . import _lib as L
 from .cuboid_geometry import attention_tables, relative_position_bias, relative_position_index
-from .packing import pack_conv, pack_conv_fp8, pack_linear, pack_linear_fp8, pad64
+from .packing import pack_conv, pack_conv_fp8, pack_linear, pack_linear_fp8, pack_pair_block, pack_pair_vecs, pad64
 from .patterns import CuboidSelfAttentionPatterns
 
 
@@ -340,6 +341,11 @@ class CuboidTransformerUNet(nn.Module):
         self.precision = "bf16" if self.fp8_conv else precision
         self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
         self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 64)
+        # bf16 mode: one launch per (attention, FFN) pair with the rows register resident (csrc/pair_block.hip) where the block has the
+        # level-0 geometry of the SEVIR-LR denoiser (units 256, 4 heads, hidden 1024, GELU, cuboid volume <= 16, no mask, no qkv bias)
+        # and the launch has at least `pair_min_tiles` tiles of 128 rows (below that the two 64-row kernels fill more CUs)
+        self.fuse_pair = os.environ.get("PD_FUSE_PAIR", "1") != "0"
+        self.pair_min_tiles = int(os.environ.get("PD_PAIR_MIN_TILES", "160"))
         self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)
@@ -556,6 +562,18 @@ class CuboidTransformerUNet(nn.Module):
                 norm(n + ".ln", ff.layer_norm); lin(n + ".fc1", ff.ffn_1, fp8_ok=not ff.gated); lin(n + ".fc2", ff.ffn_2, fp8_ok=not ff.gated)
                 if ff.gated:
                     lin(n + ".gate", ff.ffn_1_gate)
+            if self.precision == "bf16" and blk.use_inter_ffn:
+                for a, (at, ff) in enumerate(zip(blk.attn_l, blk.ffn_l)):
+                    geo = self._geom[level][a]
+                    if (at.dim == 256 and ff.ffn_1.out_features == 1024 and not ff.gated and at.use_final_proj and at.qkv.bias is None
+                            and geo["mask"] is None and not any(geo["pad"])
+                            and L.attn_ffn_pair_supported(at.dim, at.num_heads, ff.ffn_1.out_features, geo["vol"], ff.activation_name)):
+                        na, nf = f"{name}.attn{a}", f"{name}.ffn{a}"
+                        P[f"{name}.pair{a}"] = (
+                            pack_pair_block(at.qkv.weight.to(device), at.proj.weight.to(device), ff.ffn_1.weight.to(device), ff.ffn_2.weight.to(device)),
+                            pack_pair_vecs(P[na + ".ln.g"], P[na + ".ln.beta"], P[na + ".proj.b"], P[nf + ".ln.g"], P[nf + ".ln.beta"],
+                                           P[nf + ".fc2.b"], P[nf + ".fc1.b"], P[na + ".bias"]),
+                            float(at.norm.eps), float(ff.layer_norm.eps))
 
         resblock("first", self.first_proj)
         T, H, W, _ = self.data_shape
@@ -798,6 +816,13 @@ class CuboidTransformerUNet(nn.Module):
         """StackCuboidSelfAttentionBlock.forward, eval branch (cuboid_transformer.py:1147-1156 / 1176-1186)."""
         tabs = self._tables_dev[dev][level]
         for a, at in enumerate(blk.attn_l):
+            pair = P.get(f"{name}.pair{a}") if (self.fuse_pair and self.fuse_attn and self.fuse_ffn) else None
+            geo = self._geom[level][a]
+            if pair is not None and (B * geo["nc"] + 7) // 8 >= self.pair_min_tiles:
+                # x += attn(x); x = ffn(x) in one launch, rows register resident (csrc/pair_block.hip)
+                L.attn_ffn_pair(x, x, pair[0], pair[1], tabs[a]["tok"], B, S, geo["nc"], geo["vol"], float(at.scale), eps_attn=pair[2],
+                                eps_ffn=pair[3], tok_affine=geo.get("affine"))
+                continue
             self._attention(P, f"{name}.attn{a}", at, x, B, S, C, tabs[a], self._geom[level][a], dev)
             if blk.use_inter_ffn:
                 self._ffn(P, f"{name}.ffn{a}", blk.ffn_l[a], x, B, S, C, dev)

@@ -111,8 +111,29 @@ def trace(B=32):
     print("total", t[n - 1] - t[0])
 
 
+def ablate(B=32):
+    """Time of the pair launch in whatever library PD_LIB_PATH names (scripts/ablate_pair.sh builds -DPD_PAIR_ABLATE variants)."""
+    shape, Cn = (13, 16, 16), 256
+    ntok = 13 * 256
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(B, ntok, Cn, generator=g).to(DEV)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    ws = pack_pair_block(r(768, 256, sc=1 / 16), r(256, 256, sc=1 / 16), r(1024, 256, sc=1 / 16), r(256, 1024, sc=1 / 32))
+    tabs = attention_tables(shape, (1, 16, 1), (0, 0, 0), LLL, "zeros")
+    vecs = pack_pair_vecs(1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), 1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), r(1024, sc=.1), r(4, 16, 16, sc=.5))
+    tok = tabs["tok_index"].to(DEV)
+    out = []
+    for parts in (3, 2, 1):
+        t = timeit(lambda: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"], parts=parts))
+        x.normal_()
+        out.append(f"parts {parts}: {t:.1f} us")
+    print(os.environ.get("PD_LIB_PATH", "default"), " | ".join(out))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "trace":
+    if len(sys.argv) > 2 and sys.argv[2] == "ablate":
+        ablate(int(sys.argv[1]))
+    elif len(sys.argv) > 2 and sys.argv[2] == "trace":
         trace(int(sys.argv[1]))
     else:
         main()
