@@ -245,12 +245,11 @@ int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const
  *   wstream: 48 chunks of 32 KB = the four weight matrices as bf16 MFMA fragments in consumption order (prediff_amd/packing.py:
  *            pack_pair_block documents the layout);  vecs: 3584 floats = LN1 gamma, beta, proj bias, LN2 gamma, beta, FFN-2 bias
  *            (256 each), FFN-1 bias (1024), relative-position bias zero padded to (4, 16, 16)  (pack_pair_vecs).
- *   tok_index [nc][vol] / tok_affine (HOST pointer, 4 ints, or NULL): as for pd_attn_block_fused_ex; one of them is required.
- *   parts: 1 = attention + residual only, 2 = FFN only (row-wise: nc, vol and the token map are ignored), 3 = the pair. */
+ *   tok_index [nc][vol] / tok_affine (HOST pointer, 4 ints, or NULL): as for pd_attn_block_fused_ex; one of them is required. */
 int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol, int act);
 int pd_attn_ffn_pair(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
                      const int32_t* tok_affine, int B, int ntok, int nc, int vol, float scale, float eps_attn, float eps_ffn,
-                     int parts, pd_stream_t stream);
+                     pd_stream_t stream);
 
 /* ---- Diagnostic / tuning globals (exported DATA symbols; bench.py, scripts/ and tests poke them through ctypes.in_dll for A/B
  * measurements -- production callers leave them alone).  Every one is process-global and read at launch time. */

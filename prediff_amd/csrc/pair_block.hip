@@ -26,6 +26,7 @@
 // evaluated as x * sigmoid(x (a + b x^2 + c x^4)) (max abs deviation from the erf form 2.5e-5, below the bf16 rounding of the hidden
 // activations that follows; 9 VALU instructions instead of 16).
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 #define BLDS16(rsrc, ldsptr, voff, soff) \
@@ -45,7 +46,7 @@ constexpr int DMA_PER_WAVE = CHUNK / 4 / 1024;     // 8 x 1 KB per wave per chun
 constexpr int T_LN1G = 0, T_LN1B = 256, T_BP = 512, T_LN2G = 768, T_LN2B = 1024, T_B2 = 1280, T_B1 = 1536, T_RB = 2560, T_FLOATS = 3584;
 constexpr int RING_OFF = 16384;
 constexpr int LDS_BYTES = RING_OFF + NSLOT * CHUNK;   // 147456
-constexpr int CH_ATTN = 16, CH_ALL = 48;           // chunks per tile: 4 heads x (q, k, v, proj); + 16 x (W1_j, W2_j)
+constexpr int CH_ALL = 48;                         // chunks per tile: 4 heads x (q, k, v, proj) + 16 x (W1_j, W2_j)
 }  // namespace pairk
 
 struct pd_pair_args_k {
@@ -58,7 +59,7 @@ struct pd_pair_args_k {
   float scale, eps1, eps2;
   int aff_on, aff_ninner, aff_outer, aff_inner, aff_slot;
   int ntiles;
-  uint32_t wbytes;
+  uint32_t wbytes, xbytes;
   unsigned long long* trace;
   float* dbg_buf;             // PD_PAIR_DEBUG builds only: [rows][256] dump of one intermediate of head 0 (dbg_stage)
   int dbg_stage;
@@ -121,13 +122,15 @@ __device__ __forceinline__ float pk_gelu_arg(float x) {
 #ifndef PD_PAIR_DEBUG
 #define PD_PAIR_DEBUG 0
 #endif
-// PARTS: bit 0 attention, bit 1 FFN
-template <int PARTS>
+// compile-time ablations for profiling builds (-DPD_PAIR_ABLATE=bits, scripts/ablate_pair.sh): 1 no weight DMA after the prologue,
+// 2 no fragment reads, 4 no MFMAs in the chunk bodies, 8 no GELU work in the chunk hooks, 16 no row loads / stores in the chunk hooks
+#ifndef PD_PAIR_ABLATE
+#define PD_PAIR_ABLATE 0
+#endif
+
 __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace pairk;
-  constexpr bool DO_ATTN = (PARTS & 1) != 0, DO_FFN = (PARTS & 2) != 0;
-  constexpr int CH_FIRST = DO_ATTN ? 0 : CH_ATTN, CH_END = DO_FFN ? CH_ALL : CH_ATTN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -138,9 +141,9 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   for (int i = tid; i < T_FLOATS; i += 256) ((float*)smem)[i] = p.vecs[i];
   __syncthreads();
 
-  // ---- weight stream: chunk ids CH_FIRST .. CH_END-1 cyclically, chunk number n -> ring slot n & 3 ----
+  // ---- weight stream: chunk ids 0 .. CH_ALL-1 cyclically, chunk number n -> ring slot n & 3 ----
   const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, p.wbytes, 0x00020000);
-  int n_issued = 0, kid = CH_FIRST;
+  int n_issued = 0, kid = 0;
   const uint32_t dma_voff = (uint32_t)lane * 16u;
   auto issue_next = [&]() {
 #if PD_PAIR_ABLATE & 1
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) BLDS16(rW, d + i * 1024, dma_voff, so + i * 1024);
     ++n_issued;
-    kid = (kid + 1 == CH_END) ? CH_FIRST : kid + 1;
+    kid = (kid + 1 == CH_ALL) ? 0 : kid + 1;
   };
   issue_next();
   issue_next();
@@ -168,24 +171,15 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #define PK_TRACE() do {} while (0)
 #endif
   int cc = 0;                                       // chunks consumed by this workgroup
-  int vm_extra = 0;                                 // mid-chunk syncs that still have the 32 row loads of the next tile in flight
   bf16x8 w[PFN] = {};                               // fragment pipeline (runs on across chunks, tiles and phases)
 
-  // In the middle of chunk cc: chunk cc+1 has landed for everybody, everybody is past chunk cc-1 -> its slot takes chunk cc+3.
-  // The counted wait allows the 8 DMA instructions of chunk cc+2 (and, right after the next tile's rows were requested, those 32
-  // loads, which are younger than the chunk waited for) to stay in flight.  Only loads are in flight here (the row stores of a
-  // tile are drained before its successor's first chunk), and loads retire in order.
-  auto mid_sync = [&]() {
-    if (vm_extra > 0) {
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + 32) : "memory");
-      --vm_extra;
-    } else {
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
-    }
-    issue_next();
-  };
   // One chunk = 32 fragments = 16 groups of two.  Per group: two fragment reads three groups ahead, ONE counted wait, the four MFMAs
-  // of the group's two fragments (BODY_STMT, once per fragment: `i`, `wf`) and HOOK_STMT (`gi`): independent VALU work for their shadow.
+  // of the group's two fragments (BODY_STMT, once per fragment: `i`, `wf`) and HOOK_STMT (`gi`): independent work for their shadow
+  // (GELU stages, ONE row load or store).
+  // In the middle of chunk cc (group 8): chunk cc+1 has landed for everybody and everybody is past chunk cc-1, whose slot takes chunk
+  // cc+3.  VMC = the VMEM instructions younger than chunk cc+1's DMA that may stay in flight: the 8 DMA pieces of chunk cc+2 plus
+  // the row loads / stores the hooks issued since (a fixed schedule: the constants are derived at the tile loop).  Loads and
+  // stores retire in order (one vmcnt queue on gfx9-class hardware), and every hook instruction is issued unconditionally.
   // EXTRA_STMT: NEXTRA other LDS reads issued at the start; they have landed at group PF / 2, where LANDED_STMT re-defines their
   // destinations (PK_LANDED).
   // RULE for every asynchronous (inline-asm) LDS read in this kernel: its destination must not live long BEFORE its wait -- the
@@ -194,11 +188,6 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // (PK_LANDED, no instruction) right after the wait that covers them and only that new value lives on; and wherever more than a few
   // instructions separate two chunk loops the fragments in flight are drained first (PK_DRAIN).  scripts/check_async_lds.py replays
   // the LDS queue over the generated ISA and fails the build if any instruction touches a destination that is still in flight.
-// compile-time ablations for profiling builds (-DPD_PAIR_ABLATE=bits): 1 no weight DMA after the prologue, 2 no fragment reads,
-// 4 no MFMAs in the chunk bodies, 8 no GELU work in the chunk hooks
-#ifndef PD_PAIR_ABLATE
-#define PD_PAIR_ABLATE 0
-#endif
 #define PK_RD_ON (!(PD_PAIR_ABLATE & 2))
 #define PK_MFMA_ON (!(PD_PAIR_ABLATE & 4))
 #define PK_RD(i_)                                                                                 \
@@ -206,13 +195,16 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     if ((i_) < NFRAG) PK_WLD(w[(i_) % PFN], va_, (i_) * 1024);                                     \
     else PK_WLD(w[(i_) % PFN], vn_, ((i_) - NFRAG) * 1024);                                        \
   }
-#define PK_CHUNK(NEXTRA, EXTRA_STMT, LANDED_STMT, BODY_STMT, HOOK_STMT)                           \
+#define PK_CHUNK(VMC, NEXTRA, EXTRA_STMT, LANDED_STMT, BODY_STMT, HOOK_STMT)                      \
   {                                                                                               \
     const uint32_t va_ = vbase + (uint32_t)(cc & (NSLOT - 1)) * CHUNK;                            \
     const uint32_t vn_ = vbase + (uint32_t)((cc + 1) & (NSLOT - 1)) * CHUNK;                      \
     _Pragma("unroll") for (int gi = 0; gi < NFRAG / 2; ++gi) {                                    \
       if (gi == 0) { EXTRA_STMT; }                                                                \
-      if (gi == NFRAG / 4) mid_sync();                                                            \
+      if (gi == NFRAG / 4) {                                                                      \
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VMC) : "memory");                   \
+        issue_next();                                                                             \
+      }                                                                                           \
       PK_RD(2 * gi + PF);                                                                         \
       PK_RD(2 * gi + PF + 1);                                                                     \
       asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[(2 * gi) % PFN]), "+v"(w[(2 * gi + 1) % PFN]) \
@@ -237,9 +229,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     acc[1][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[1][i >> 4], acc[1][i & 15], 0, 0, 0);      \
   }
 
-  // rows of a tile's cuboids for this lane = (slot q, column group g); an invalid slot reads row 0 (always 32 load instructions: the
-  // counted waits above rely on it) and stores nothing
-  auto tile_rows = [&](int tile, int64_t (&off)[2], bool (&valid)[2]) {
+  // rows of a tile's cuboids for this lane = (slot q, column group g), as byte offsets into x / out.  An invalid slot gets an offset
+  // beyond the buffers: its loads return 0 and its stores are dropped by the descriptor's bounds check -- ALWAYS exactly 32 load and
+  // 32 store instructions per tile, no lane ever branches.
+  const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+  const auto rO = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.xbytes, 0x00020000);
+  constexpr uint32_t OOB = 0xFFFFF000u;
+  auto tile_rows = [&](int tile, uint32_t (&off)[2]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int64_t gc = (int64_t)tile * 8 + wave * 2 + c;
@@ -250,22 +246,33 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
                                  : p.tok_index[cu * p.vol + q];
         if (tok >= 0 && tok < p.ntok) row = b * p.ntok + tok;
       }
-      valid[c] = row >= 0;
-      off[c] = (int64_t)(row < 0 ? 0 : row) * C + 4 * g;
+      off[c] = row < 0 ? OOB : (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)g * 16u;
     }
   };
-  f32x4 xn[2][16];                                  // the rows of the NEXT tile (requested while the current one is in its last chunks)
-  auto load_rows = [&](const int64_t (&off)[2]) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int nt = 0; nt < 16; ++nt) xn[c][nt] = *(const f32x4*)(p.x + off[c] + nt * 16);
-  };
+#ifndef PD_PAIR_AUX_LD
+#define PD_PAIR_AUX_LD 0
+#endif
+#ifndef PD_PAIR_AUX_ST
+#define PD_PAIR_AUX_ST 0
+#endif
+#define PK_ROW_LD(OFF, NT) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (OFF) + (uint32_t)((NT) * 64), 0, PD_PAIR_AUX_LD))
+#define PK_ROW_ST(V, OFF, NT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), rO, (OFF) + (uint32_t)((NT) * 64), 0, PD_PAIR_AUX_ST)
+#define PK_HOOK_IO (!(PD_PAIR_ABLATE & 16))
 
-  int64_t roff[2], noff[2];
-  bool rvalid[2], nvalid[2];
-  tile_rows(blockIdx.x, noff, nvalid);
-  load_rows(noff);
+  // acc: the rows in flight (x -> x + attn -> x + attn + ffn), lane = (token q, columns 16 nt + 4 g .. +3): the MFMA C layout of every
+  // transposed product.  xn: the rows of the NEXT tile.  The tile boundary is software pipelined: xn is requested one row-instruction
+  // per fragment group during the last two chunks of a tile, the finished rows (acc) leave one row-instruction per group during the
+  // first two chunks of the next tile (whose LayerNorm and q / k / v products read xn), and only then acc <- xn + b_proj.
+  f32x4 acc[2][16], xn[2][16];
+  uint32_t roff[2] = {OOB, OOB}, noff[2], ooff[2] = {OOB, OOB};
+  tile_rows(blockIdx.x, noff);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+      xn[c][nt] = PK_ROW_LD(noff[c], nt);
+      acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};       // (the first tile has no predecessor: its hook stores go to OOB offsets)
+    }
   // chunks 0..2 landed (the row loads above are younger: this wait covers both), visible to every wave; fragment prologue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -275,41 +282,32 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     PK_TRACE();   // tile start
-    // ---- acc[c][nt] = x[row][16 nt + 4 g .. +3]: the MFMA C layout of every transposed product below ----
-    f32x4 acc[2][16];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      roff[c] = noff[c];
-      rvalid[c] = nvalid[c];
-#pragma unroll
-      for (int nt = 0; nt < 16; ++nt) acc[c][nt] = xn[c][nt];
-    }
-    const bool has_next = tile + (int)gridDim.x < p.ntiles;
-    if (has_next) tile_rows(tile + gridDim.x, noff, nvalid);
-    PK_TRACE();   // rows in registers
-
+    ooff[0] = roff[0]; ooff[1] = roff[1];
+    roff[0] = noff[0]; roff[1] = noff[1];
+    noff[0] = noff[1] = OOB;
+    if (tile + (int)gridDim.x < p.ntiles) tile_rows(tile + gridDim.x, noff);
 #if PD_PAIR_DEBUG
     auto dump4 = [&](int stage, int c, const f32x4& a, const f32x4& b, const f32x4& cc4, const f32x4& d) {
-      if (p.dbg_buf && p.dbg_stage == stage && rvalid[c]) {
-        float* o = p.dbg_buf + roff[c];
+      if (p.dbg_buf && p.dbg_stage == stage && roff[c] != OOB) {
+        float* o = p.dbg_buf + roff[c] / 4;
         *(f32x4*)(o) = a; *(f32x4*)(o + 16) = b; *(f32x4*)(o + 32) = cc4; *(f32x4*)(o + 48) = d;
       }
     };
 #endif
     bf16x8 af[2][8];                                // LayerNorm output as B-operand fragments: [cuboid][k-step of 32]
     // LayerNorm over the 256 columns of a row (64 in this lane, the rest in lanes q + 16 g'), -> af
-    auto layer_norm = [&](int t_gamma, int t_beta, float eps) {
+    auto layer_norm = [&](const f32x4 (&src)[2][16], int t_gamma, int t_beta, float eps) {
       float mean[2], rstd[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         float s = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt) s += (acc[c][nt][0] + acc[c][nt][1]) + (acc[c][nt][2] + acc[c][nt][3]);
+        for (int nt = 0; nt < 16; ++nt) s += (src[c][nt][0] + src[c][nt][1]) + (src[c][nt][2] + src[c][nt][3]);
         mean[c] = pk_rows4_sum(s) * (1.0f / C);
         float v = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
-          const float d0 = acc[c][nt][0] - mean[c], d1 = acc[c][nt][1] - mean[c], d2 = acc[c][nt][2] - mean[c], d3 = acc[c][nt][3] - mean[c];
+          const float d0 = src[c][nt][0] - mean[c], d1 = src[c][nt][1] - mean[c], d2 = src[c][nt][2] - mean[c], d3 = src[c][nt][3] - mean[c];
           v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
         rstd[c] = rsqrtf(pk_rows4_sum(v) * (1.0f / C) + eps);
@@ -338,13 +336,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
           for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              y[hf][r] = (acc[c][2 * ks + hf][r] - mean[c]) * rstd[c] * gb[ks & 1][hf][r] + gb[ks & 1][2 + hf][r];
+              y[hf][r] = (src[c][2 * ks + hf][r] - mean[c]) * rstd[c] * gb[ks & 1][hf][r] + gb[ks & 1][2 + hf][r];
           af[c][ks] = pk_pack8(y[0], y[1]);
         }
       }
     };
-    // acc[c][nt] += table[16 nt + 4 g .. +3]  (proj / FFN-2 bias: the accumulator starts from residual + bias)
-    auto add_vec = [&](int t_off) {
+    // acc[c][nt] = src[c][nt] + table[16 nt + 4 g .. +3]  (proj / FFN-2 bias: the accumulator starts from residual + bias)
+    auto add_vec = [&](const f32x4 (&src)[2][16], int t_off) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         f32x4 bv[8];
@@ -354,241 +352,219 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc[c][half * 8 + i] += bv[i];
+          for (int c = 0; c < 2; ++c) acc[c][half * 8 + i] = src[c][half * 8 + i] + bv[i];
       }
     };
-    bool at_tile_start = true;   // the row stores of the previous tile may still be in flight: drained in front of the first chunk
-    auto enter_chunks = [&]() {
-      if (at_tile_start) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      at_tile_start = false;
-    };
 
-    if constexpr (DO_ATTN) {
-      layer_norm(T_LN1G, T_LN1B, p.eps1);
-      add_vec(T_BP);
-      enter_chunks();
-      PK_TRACE();   // LN1 done
-#pragma unroll 1
-      for (int h = 0; h < HEADS; ++h) {
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 t[2][4];
-        bf16x8 qf[2][2], kf[2][2];
-        f32x4 rb;                                   // relative-position bias of (head h, query q, keys 4 g .. 4 g + 3)
-        const uint32_t vrb_h = vrb + (uint32_t)h * 1024u;
-        // ---------------- q^T = Wq_h a^T ----------------
+    // ================= attention: x += proj(attn(LN1(x))) =================
+    layer_norm(xn, T_LN1G, T_LN1B, p.eps1);
+    PK_TRACE();   // LN1 done
+    // VMEM schedule around a tile boundary (chunk c = consumption order; hooks issue one row instruction per group):
+    //   W2_14 (c46): 16 loads, W2_15 (c47): 16 loads, Q_0 (c48): 16 stores, K_0 (c49): 16 stores; everything else none.
+    //   VMC(c) = 8 + hook instructions issued in [second half of c-2, first half of c]:
+    //   c46: 8 + 8 = 16;  c47: 8 + 16 + 8 = 32;  c48: 8 + 8 + 16 + 8 = 40;  c49: 40;  c50 (V_0): 8 + 8 + 16 = 32;  c51 (P_0): 8 + 8 = 16.
+    auto head = [&](auto first_tag, int h) __attribute__((always_inline)) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 t[2][4];
+      bf16x8 qf[2][2], kf[2][2];
+      f32x4 rb;                                     // relative-position bias of (head h, query q, keys 4 g .. 4 g + 3)
+      const uint32_t vrb_h = vrb + (uint32_t)h * 1024u;
+      // ---------------- q^T = Wq_h a^T  (head 0: the previous tile's rows of cuboid 0 leave in its shadow) ----------------
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
-        PK_CHUNK(0, (void)0, (void)0, PK_MFMA_T(t, af), (void)0)
+        for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
+      PK_CHUNK(FIRST ? 40 : 8, 0, (void)0, (void)0, PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[0][gi], ooff[0], gi); })
 #if PD_PAIR_DEBUG
-        if (h == 0) { dump4(1, 0, t[0][0], t[0][1], t[0][2], t[0][3]); dump4(1, 1, t[1][0], t[1][1], t[1][2], t[1][3]); }
+      if (h == 0) { dump4(1, 0, t[0][0], t[0][1], t[0][2], t[0][3]); dump4(1, 1, t[1][0], t[1][1], t[1][2], t[1][3]); }
 #endif
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          qf[c][0] = pk_pack8(t[c][0], t[c][1]);
-          qf[c][1] = pk_pack8(t[c][2], t[c][3]);
+      for (int c = 0; c < 2; ++c) {
+        qf[c][0] = pk_pack8(t[c][0], t[c][1]);
+        qf[c][1] = pk_pack8(t[c][2], t[c][3]);
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
+        for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
+      }
+      PK_TRACE();   // q done
+      // ---------------- k^T = Wk_h a^T  (head 0: ... and those of cuboid 1) ----------------
+      PK_CHUNK(FIRST ? 40 : 8, 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[1][gi], ooff[1], gi); })
+      PK_DRAIN();
+      PK_TRACE();   // k done
+      // ---------------- S^T = K Q^T, softmax over the keys (registers + two row swaps) ----------------
+      s16x4 pf[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#if PD_PAIR_DEBUG
+        if (h == 0) dump4(2, c, t[c][0], t[c][1], t[c][2], t[c][3]);
+#endif
+        kf[c][0] = pk_pack8(t[c][0], t[c][1]);
+        kf[c][1] = pk_pack8(t[c][2], t[c][3]);
+        f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][0], qf[c][0], z4, 0, 0, 0);
+        s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][1], qf[c][1], s4, 0, 0, 0);
+        float sc[4], mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = -INFINITY;
+          if (4 * g + r < p.vol && q < p.vol) v = s4[r] * p.scale + rb[r];
+          sc[r] = v;
+          mx = fmaxf(mx, v);
         }
-        PK_TRACE();   // q done
-        // ---------------- k^T = Wk_h a^T ----------------
-        PK_CHUNK(1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), (void)0)
-        PK_DRAIN();
-        PK_TRACE();   // k done
-        // ---------------- S^T = K Q^T, softmax over the keys (registers + two row swaps) ----------------
-        s16x4 pf[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
 #if PD_PAIR_DEBUG
-          if (h == 0) dump4(2, c, t[c][0], t[c][1], t[c][2], t[c][3]);
+        if (h == 0) dump4(3, c, s4, f32x4{sc[0], sc[1], sc[2], sc[3]}, rb, z4);
 #endif
-          kf[c][0] = pk_pack8(t[c][0], t[c][1]);
-          kf[c][1] = pk_pack8(t[c][2], t[c][3]);
-          f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][0], qf[c][0], z4, 0, 0, 0);
-          s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][1], qf[c][1], s4, 0, 0, 0);
-          float sc[4], mx = -3.0e38f;
+        mx = pk_rows4_max(mx);
+        float sum = 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = -INFINITY;
-            if (4 * g + r < p.vol && q < p.vol) v = s4[r] * p.scale + rb[r];
-            sc[r] = v;
-            mx = fmaxf(mx, v);
-          }
-#if PD_PAIR_DEBUG
-          if (h == 0) dump4(3, c, s4, f32x4{sc[0], sc[1], sc[2], sc[3]}, rb, z4);
-#endif
-          mx = pk_rows4_max(mx);
-          float sum = 0.f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * 1.4426950408889634f);   // exp(-inf) = 0 for non-existent keys
-            sum += sc[r];
-          }
-          sum = pk_rows4_sum(sum);
-          const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;
-          pf[c] = pk_pack4(f32x4{sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv});
-#if PD_PAIR_DEBUG
-          if (h == 0) dump4(4, c, f32x4{sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv}, f32x4{mx, sum, inv, 0.f}, z4, z4);
-#endif
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
+        for (int r = 0; r < 4; ++r) {
+          sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * 1.4426950408889634f);   // exp(-inf) = 0 for non-existent keys
+          sum += sc[r];
         }
-        PK_TRACE();   // softmax done
-        // ---------------- v = a Wv_h^T (plain product: lane = feature, 4 consecutive tokens -> the A operand of O^T = V^T P^T) -------
-        PK_CHUNK(0, (void)0, (void)0, {
+        sum = pk_rows4_sum(sum);
+        const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;
+        pf[c] = pk_pack4(f32x4{sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv});
+#if PD_PAIR_DEBUG
+        if (h == 0) dump4(4, c, f32x4{sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv}, f32x4{mx, sum, inv, 0.f}, z4, z4);
+#endif
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
+      }
+      PK_TRACE();   // softmax done
+      // ---------------- v = a Wv_h^T (plain product: lane = feature, 4 consecutive tokens -> the A operand of O^T = V^T P^T) -------
+      PK_CHUNK(FIRST ? 32 : 8, 0, (void)0, (void)0, {
+        if (PK_MFMA_ON) {
           t[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i >> 2], wf, t[0][i & 3], 0, 0, 0);
           t[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i >> 2], wf, t[1][i & 3], 0, 0, 0);
-        }, (void)0)
-        PK_DRAIN();
-        bf16x8 of[2][2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          f32x4 o[4];
-#if PD_PAIR_DEBUG
-          if (h == 0) dump4(5, c, t[c][0], t[c][1], t[c][2], t[c][3]);
-#endif
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk_pack4(t[c][dt]), pf[c], z4, 0, 0, 0);
-#if PD_PAIR_DEBUG
-          if (h == 0) dump4(6, c, o[0], o[1], o[2], o[3]);
-#endif
-          of[c][0] = pk_pack8(o[0], o[1]);
-          of[c][1] = pk_pack8(o[2], o[3]);
         }
-        PK_TRACE();   // v + PV done
-        // ---------------- x^T += Wp[:, head h] O_h^T ----------------
-        PK_CHUNK(0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
+      }, (void)0)
+      PK_DRAIN();
+      bf16x8 of[2][2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f32x4 o[4];
+#if PD_PAIR_DEBUG
+        if (h == 0) dump4(5, c, t[c][0], t[c][1], t[c][2], t[c][3]);
+#endif
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk_pack4(t[c][dt]), pf[c], z4, 0, 0, 0);
+#if PD_PAIR_DEBUG
+        if (h == 0) dump4(6, c, o[0], o[1], o[2], o[3]);
+#endif
+        of[c][0] = pk_pack8(o[0], o[1]);
+        of[c][1] = pk_pack8(o[2], o[3]);
       }
-      PK_DRAIN();                                   // (a LayerNorm or the row stores follow)
-      PK_TRACE();   // attention done
-    }
+      if constexpr (FIRST) add_vec(xn, T_BP);       // the finished rows have left: acc <- x + b_proj, the accumulator of every head's proj
+      PK_TRACE();   // v + PV done
+      // ---------------- x^T += Wp[:, head h] O_h^T ----------------
+      PK_CHUNK(FIRST ? 16 : 8, 0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
+    };
+    head(std::true_type{}, 0);
+#pragma unroll 1
+    for (int h = 1; h < HEADS; ++h) head(std::false_type{}, h);
+    PK_DRAIN();                                     // (a LayerNorm follows)
+    PK_TRACE();   // attention done
 
-    if constexpr (DO_FFN) {
-      layer_norm(T_LN2G, T_LN2B, p.eps2);
-      add_vec(T_B2);
-      enter_chunks();
-      PK_TRACE();   // LN2 done
-      // Chunk order: W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0..13, W2_14, W2_15.  gelu(h_j) has the two chunks between W1_j and W2_j to
-      // itself, as three software-pipelined stages (polynomial | exp, +1 | rcp, mul) of one value per fragment group: independent
-      // short chains beside the MFMAs instead of one 9-deep dependent chain per value (a lone wave hides no VALU latency).
-      const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4);
-      f32x4 hc[2][4], hn[2][4], b1n[4];
-      float ga[32], gd[32];
+    // ================= FFN: x += W2 gelu(W1 LN2(x) + b1) + b2 =================
+    layer_norm(acc, T_LN2G, T_LN2B, p.eps2);
+    add_vec(acc, T_B2);
+    PK_TRACE();   // LN2 done
+    // Chunk order: W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0..13, W2_14, W2_15.  gelu(h_j) has the two chunks between W1_j and W2_j to
+    // itself, as three software-pipelined stages (polynomial | exp, +1 | rcp, mul) of one value per fragment group: independent
+    // short chains beside the MFMAs instead of one 9-deep dependent chain per value (a lone wave hides no VALU latency).
+    const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4);
+    f32x4 hc[2][4], hn[2][4], b1n[4];
+    float ga[32], gd[32];
 #define PK_HV(H, v) H[(v) >> 4][((v) >> 2) & 3][(v) & 3]
 #define PK_GELU_GROUP(H, VB, NPER, GI)                                                                                    \
-  if (!(PD_PAIR_ABLATE & 8)) _Pragma("unroll") for (int u_ = 0; u_ < (NPER); ++u_) {                                                                 \
+  if (!(PD_PAIR_ABLATE & 8)) _Pragma("unroll") for (int u_ = 0; u_ < (NPER); ++u_) {                                      \
     if ((GI) < 16) { const int v_ = (VB) + (GI) * (NPER) + u_; ga[v_] = pk_gelu_arg(PK_HV(H, v_)); }                      \
     if ((GI) >= 1 && (GI) < 17) { const int v_ = (VB) + ((GI) - 1) * (NPER) + u_; gd[v_] = 1.0f + __builtin_amdgcn_exp2f(ga[v_]); } \
     if ((GI) >= 2 && (GI) < 18) { const int v_ = (VB) + ((GI) - 2) * (NPER) + u_; PK_HV(H, v_) = PK_HV(H, v_) * __builtin_amdgcn_rcpf(gd[v_]); } \
   }
 #define PK_B1_FETCH(ADDR) { PK_LDS_F4(b1n[0], ADDR, 0); PK_LDS_F4(b1n[1], ADDR, 64); PK_LDS_F4(b1n[2], ADDR, 128); PK_LDS_F4(b1n[3], ADDR, 192); }
 #define PK_B1_LANDED() { PK_LANDED(b1n[0]); PK_LANDED(b1n[1]); PK_LANDED(b1n[2]); PK_LANDED(b1n[3]); }
-      // b1 of chunk 0: plain wait (the fragment prologue in flight is older and simply lands first)
-      PK_B1_FETCH(vb1)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1n[0]), "+v"(b1n[1]), "+v"(b1n[2]), "+v"(b1n[3]));
+    // b1 of chunk 0: plain wait (the fragment prologue in flight is older and simply lands first)
+    PK_B1_FETCH(vb1)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1n[0]), "+v"(b1n[1]), "+v"(b1n[2]), "+v"(b1n[3]));
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
+    const uint32_t vb1_1 = vb1 + 256u;
+    // ---------------- h_0^T = W1_0 a^T + b1 (in its shadow: b1 of chunk 1) ----------------
+    PK_CHUNK(8, 4, PK_B1_FETCH(vb1_1), PK_B1_LANDED(), PK_MFMA_T(hc, af), (void)0)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht) hn[c][ht] = b1n[ht];
+    PK_TRACE();   // W1_0 done
+    // ---------------- h_1 beside the whole of gelu(h_0) (two values per group); b1 of chunk 2 ----------------
+    const uint32_t vb1_2 = vb1 + 512u;
+    PK_CHUNK(8, 4, PK_B1_FETCH(vb1_2), PK_B1_LANDED(), PK_MFMA_T(hn, af), PK_GELU_GROUP(hc, 0, 2, gi))
+    PK_GELU_GROUP(hc, 0, 2, 16)
+    PK_GELU_GROUP(hc, 0, 2, 17)
+    bf16x8 hfr[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      hfr[c][0] = pk_pack8(hc[c][0], hc[c][1]);
+      hfr[c][1] = pk_pack8(hc[c][2], hc[c][3]);
+    }
+    PK_TRACE();   // W1_1 done
+    // invariant: hfr = gelu(h_j) as fragments, hn = h_{j+1} (pre-activation), b1n = b1 of chunk j + 2
+#pragma unroll 1
+    for (int j = 0; j < HID / 64 - 2; ++j) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
-      const uint32_t vb1_1 = vb1 + 256u;
-      // ---------------- h_0^T = W1_0 a^T + b1 (in its shadow: b1 of chunk 1) ----------------
-      PK_CHUNK(4, PK_B1_FETCH(vb1_1), PK_B1_LANDED(), PK_MFMA_T(hc, af), (void)0)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int ht = 0; ht < 4; ++ht) hn[c][ht] = b1n[ht];
-      PK_TRACE();   // W1_0 done
-      // ---------------- h_1 beside the whole of gelu(h_0) (two values per group); b1 of chunk 2 ----------------
-      const uint32_t vb1_2 = vb1 + 512u;
-      PK_CHUNK(4, PK_B1_FETCH(vb1_2), PK_B1_LANDED(), PK_MFMA_T(hn, af), PK_GELU_GROUP(hc, 0, 2, gi))
-      PK_GELU_GROUP(hc, 0, 2, 16)
-      PK_GELU_GROUP(hc, 0, 2, 17)
-      bf16x8 hfr[2][2];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        hfr[c][0] = pk_pack8(hc[c][0], hc[c][1]);
-        hfr[c][1] = pk_pack8(hc[c][2], hc[c][3]);
-      }
-      PK_TRACE();   // W1_1 done
-      // invariant: hfr = gelu(h_j) as fragments, hn = h_{j+1} (pre-activation), b1n = b1 of chunk j + 2
-#pragma unroll 1
-      for (int j = 0; j < HID / 64 - 2; ++j) {
-        if (j < 2) PK_TRACE();   // FFN iteration start
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
-        const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < HID / 64 ? j + 3 : 0) * 256u;
-        // x^T += W2[:, chunk j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (cuboid 0)
-        PK_CHUNK(0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 1, gi))
-        PK_GELU_GROUP(hn, 0, 1, 16)
-        PK_GELU_GROUP(hn, 0, 1, 17)
-        if (j < 2) PK_TRACE();
-        // h_{j+2}^T = W1_{j+2} a^T + b1   beside the second half of gelu(h_{j+1}); b1 of chunk j + 3
-        PK_CHUNK(4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 16, 1, gi))
-        PK_GELU_GROUP(hn, 16, 1, 16)
-        PK_GELU_GROUP(hn, 16, 1, 17)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
-          hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
-#pragma unroll
-          for (int ht = 0; ht < 4; ++ht) hn[c][ht] = hc[c][ht];
-        }
-      }
-      PK_TRACE();   // FFN loop done
-      // the LayerNorm fragments are dead: their registers take the rows of this workgroup's next tile, requested now so that the
-      // HBM round trip hides behind the last two chunks
-      if (has_next) {
-        load_rows(noff);
-        vm_extra = 2;
-      } else {
-        // (defined on both paths: otherwise the compiler keeps the previous tile's 128 registers alive through the whole loop body)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int nt = 0; nt < 16; ++nt) xn[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      // W2_14 beside the whole of gelu(h_15), then W2_15
-      PK_CHUNK(0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 2, gi))
-      PK_GELU_GROUP(hn, 0, 2, 16)
-      PK_GELU_GROUP(hn, 0, 2, 17)
+      const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < HID / 64 ? j + 3 : 0) * 256u;
+      // x^T += W2[:, chunk j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (cuboid 0)
+      PK_CHUNK(8, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 1, gi))
+      PK_GELU_GROUP(hn, 0, 1, 16)
+      PK_GELU_GROUP(hn, 0, 1, 17)
+      // h_{j+2}^T = W1_{j+2} a^T + b1   beside the second half of gelu(h_{j+1}); b1 of chunk j + 3
+      PK_CHUNK(8, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 16, 1, gi))
+      PK_GELU_GROUP(hn, 16, 1, 16)
+      PK_GELU_GROUP(hn, 16, 1, 17)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
         hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
-      }
-      PK_CHUNK(0, (void)0, (void)0, PK_MFMA_OUT(hfr), (void)0)
-      PK_DRAIN();                                   // (the row stores and the next tile's LayerNorm follow)
-      PK_TRACE();   // FFN done
-    }
-
-    // ---- the rows go back (same lane -> (row, columns) map as the load) ----
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-      if (rvalid[c]) {
-#pragma unroll
-        for (int nt = 0; nt < 16; ++nt) *(f32x4*)(p.out + roff[c] + nt * 16) = acc[c][nt];
+        for (int ht = 0; ht < 4; ++ht) hn[c][ht] = hc[c][ht];
       }
-    if constexpr (!DO_FFN) {
-      load_rows(noff);                              // (attention alone: no window in which the fragments are dead; exposed.  Without a
-                                                    //  next tile noff still names this tile's rows: a harmless re-read)
     }
-    PK_TRACE();   // stores issued
+    PK_TRACE();   // FFN loop done
+    // W2_14 beside the whole of gelu(h_15) and the next tile's rows of cuboid 0, then W2_15 beside those of cuboid 1
+    // (the LayerNorm fragments are dead: xn takes their registers)
+    PK_CHUNK(16, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { PK_GELU_GROUP(hn, 0, 2, gi) if (PK_HOOK_IO) xn[0][gi] = PK_ROW_LD(noff[0], gi); })
+    PK_GELU_GROUP(hn, 0, 2, 16)
+    PK_GELU_GROUP(hn, 0, 2, 17)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
+      hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
+    }
+    PK_CHUNK(32, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { if (PK_HOOK_IO) xn[1][gi] = PK_ROW_LD(noff[1], gi); })
+    PK_DRAIN();                                     // (the next tile's LayerNorm follows)
+    PK_TRACE();   // FFN done
   }
+  // ---- the last tile's rows ----
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) PK_ROW_ST(acc[c][nt], roff[c], nt);
   // nothing of this workgroup may still be writing LDS when its allocation is handed to the next one
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
 
-template <int PARTS>
 static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   using namespace pairk;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<PARTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_ffn_pair: hipFuncSetAttribute(%d) failed: %s", LDS_BYTES, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -598,7 +574,7 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   // persistent: every workgroup takes the same number of tiles (the last few one less), one workgroup per CU
   const int per_wg = (a.ntiles + 255) / 256;
   const int grid = (a.ntiles + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL((pair_kernel<PARTS>), dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(pair_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -615,15 +591,18 @@ extern "C" int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol,
 
 extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
                                 const int32_t* tok_affine, int B, int ntok, int nc, int vol, float scale, float eps_attn, float eps_ffn,
-                                int parts, pd_stream_t stream) {
+                                pd_stream_t stream) {
   using namespace pairk;
   PD_CHECK_ARG(x && out && wstream && vecs, "pd_attn_ffn_pair: null pointer");
-  PD_CHECK_ARG(parts >= 1 && parts <= 3, "pd_attn_ffn_pair: parts must be 1 (attention), 2 (FFN) or 3 (both)");
   PD_CHECK_ARG(B > 0 && ntok > 0 && (int64_t)B * ntok < (1ll << 31), "pd_attn_ffn_pair: bad sizes");
+  PD_CHECK_ARG(nc > 0 && vol >= 1 && vol <= 16, "pd_attn_ffn_pair: cuboid volume %d not in 1..16", vol);
+  PD_CHECK_ARG(tok_index || (tok_affine && tok_affine[0] > 0), "pd_attn_ffn_pair: neither a token table nor its affine form");
+  PD_CHECK_ARG((int64_t)B * ntok * (C * 4) < 0xFFFFF000ll, "pd_attn_ffn_pair: x larger than a 4 GiB buffer descriptor");
   pd_pair_args_k a;
   a.x = x; a.out = out; a.wstream = wstream; a.vecs = vecs; a.tok_index = tok_index;
   a.scale = scale; a.eps1 = eps_attn; a.eps2 = eps_ffn;
   a.wbytes = (uint32_t)(CH_ALL * CHUNK);
+  a.xbytes = (uint32_t)((int64_t)B * ntok * (C * 4));
   a.trace = pd_pair_trace;
 #if PD_PAIR_DEBUG
   a.dbg_buf = pd_pair_dbg_buf;
@@ -632,25 +611,12 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   a.dbg_buf = nullptr;
   a.dbg_stage = 0;
 #endif
-  if (parts & 1) {
-    PD_CHECK_ARG(nc > 0 && vol >= 1 && vol <= 16, "pd_attn_ffn_pair: cuboid volume %d not in 1..16", vol);
-    PD_CHECK_ARG(tok_index || (tok_affine && tok_affine[0] > 0), "pd_attn_ffn_pair: neither a token table nor its affine form");
-    a.B = B; a.ntok = ntok; a.nc = nc; a.vol = vol;
-    a.aff_on = (tok_affine && tok_affine[0] > 0) ? 1 : 0;
-    a.aff_ninner = a.aff_on ? tok_affine[0] : 1;
-    a.aff_outer = a.aff_on ? tok_affine[1] : 0;
-    a.aff_inner = a.aff_on ? tok_affine[2] : 0;
-    a.aff_slot = a.aff_on ? tok_affine[3] : 0;
-  } else {
-    // FFN alone is row-wise: "cuboids" of 16 consecutive rows
-    const int64_t M = (int64_t)B * ntok;
-    a.B = 1; a.ntok = (int)M; a.nc = (int)((M + 15) / 16); a.vol = 16;
-    a.aff_on = 1; a.aff_ninner = a.nc; a.aff_outer = 0; a.aff_inner = 16; a.aff_slot = 1;
-  }
-  const int64_t cuboids = (int64_t)a.B * a.nc;
-  a.ntiles = (int)((cuboids + 7) / 8);
-  hipStream_t s = (hipStream_t)stream;
-  if (parts == 3) return launch_pair<3>(a, s);
-  if (parts == 1) return launch_pair<1>(a, s);
-  return launch_pair<2>(a, s);
+  a.B = B; a.ntok = ntok; a.nc = nc; a.vol = vol;
+  a.aff_on = (tok_affine && tok_affine[0] > 0) ? 1 : 0;
+  a.aff_ninner = a.aff_on ? tok_affine[0] : 1;
+  a.aff_outer = a.aff_on ? tok_affine[1] : 0;
+  a.aff_inner = a.aff_on ? tok_affine[2] : 0;
+  a.aff_slot = a.aff_on ? tok_affine[3] : 0;
+  a.ntiles = (int)(((int64_t)B * nc + 7) / 8);
+  return launch_pair(a, (hipStream_t)stream);
 }

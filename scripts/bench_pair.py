@@ -60,27 +60,24 @@ def main():
         def old_ffn(t):
             L.ffn_fused(t, t, g2, b2n, w1_p, fb1, w2_p, fb2, B * ntok, Cn, Hd, act="gelu")
 
-        def new(t, parts, aff=True):
-            L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"] if aff else None, parts=parts)
+        def new(t, aff=True):
+            L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"] if aff else None)
 
         ref_a = x.clone(); old_attn(ref_a)
         ref_f = x.clone(); old_ffn(ref_f)
         ref_p = ref_a.clone(); old_ffn(ref_p)
-        res = {}
-        for parts, ref in ((2, ref_f), (1, ref_a), (3, ref_p)):
-            t = x.clone(); new(t, parts); torch.cuda.synchronize()
-            res[parts] = t
-            print(f"cuboid {cuboid} parts {parts}: rel-L2 of the update vs the round-3 kernels {rel(t - x, ref - x):.3e}   finite {bool(torch.isfinite(t).all())}")
-        t2 = x.clone(); new(t2, 3, aff=False); torch.cuda.synchronize()
-        print(f"   table-driven token ids == affine: {torch.equal(t2, res[3])};  repeat bit-equal: ", end="")
-        t3 = x.clone(); new(t3, 3); torch.cuda.synchronize(); print(torch.equal(t3, res[3]))
+        t = x.clone(); new(t); torch.cuda.synchronize()
+        print(f"cuboid {cuboid}: rel-L2 of the update vs the round-3 kernels {rel(t - x, ref_p - x):.3e}   finite {bool(torch.isfinite(t).all())}")
+        t2 = x.clone(); new(t2, aff=False); torch.cuda.synchronize()
+        print(f"   table-driven token ids == affine: {torch.equal(t2, t)};  repeat bit-equal: ", end="")
+        t3 = x.clone(); new(t3); torch.cuda.synchronize(); print(torch.equal(t3, t))
         buf = x.clone()
         ta, tf = timeit(lambda: old_attn(buf)), timeit(lambda: old_ffn(buf))
         buf = x.clone()
-        tn = {p: timeit(lambda: new(buf, p)) for p in (1, 2, 3)}
+        tn = timeit(lambda: new(buf))
         gf_a, gf_f = B * 1.7965e9, B * 3.4897e9 * 1.0
-        print(f"   B={B}: round-3 attention {ta:.1f} us + FFN {tf:.1f} us = {ta + tf:.1f} us;  pair kernel: attention-only {tn[1]:.1f}, FFN-only {tn[2]:.1f}, "
-              f"pair {tn[3]:.1f} us  ({(gf_a + gf_f) / tn[3] / 1e6:.0f} TFLOP/s, {(gf_a + gf_f) / tn[3] / 1e6 / 2500:.3f} of peak)")
+        print(f"   B={B}: round-3 attention {ta:.1f} us + FFN {tf:.1f} us = {ta + tf:.1f} us;  pair kernel {tn:.1f} us  "
+              f"({(gf_a + gf_f) / tn / 1e6:.0f} TFLOP/s, {(gf_a + gf_f) / tn / 1e6 / 2500:.3f} of peak)")
 
 
 
@@ -99,9 +96,9 @@ def trace(B=32):
     tok = tabs["tok_index"].to(DEV)
     tr = torch.zeros(256, dtype=torch.int64, device=DEV)
     for _ in range(3):
-        L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"], parts=3)
+        L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"])
     ctypes.c_void_p.in_dll(L.lib(), "pd_pair_trace").value = tr.data_ptr()
-    L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"], parts=3)
+    L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"])
     torch.cuda.synchronize()
     ctypes.c_void_p.in_dll(L.lib(), "pd_pair_trace").value = None
     t = tr.cpu().tolist()
@@ -123,10 +120,10 @@ def ablate(B=32):
     vecs = pack_pair_vecs(1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), 1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), r(1024, sc=.1), r(4, 16, 16, sc=.5))
     tok = tabs["tok_index"].to(DEV)
     out = []
-    for parts in (3, 2, 1):
-        t = timeit(lambda: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"], parts=parts))
+    for rep in range(3):
+        t = timeit(lambda: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"]))
         x.normal_()
-        out.append(f"parts {parts}: {t:.1f} us")
+        out.append(f"{t:.1f} us")
     print(os.environ.get("PD_LIB_PATH", "default"), " | ".join(out))
 
 

@@ -37,7 +37,7 @@ for stage in range(1, 7):
     dbg.zero_()
     ctypes.c_int.in_dll(lib, "pd_pair_dbg_stage").value = stage
     t = x.clone()
-    L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, 64 ** -0.5, tok_affine=tabs["affine"], parts=1)
+    L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, 64 ** -0.5, tok_affine=tabs["affine"])
     torch.cuda.synchronize()
     d = dbg[rows]              # [16 tokens][256]
     if stage == 1: print("q", float((d[:, :64] - q0).abs().max()), float(q0.abs().max()))
