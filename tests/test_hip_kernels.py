@@ -893,3 +893,89 @@ def test_conv2d_gn_silu_two_workgroups_per_cu(N, H, W, Cin, Cout, res):
             first = out
         else:
             assert torch.equal(out, first), k
+
+
+# ------------------------------------------------------------------------------------------------ (attention, FFN) pair kernel
+PAIR_CASES = {
+    # name: (shape, cuboid, B)  -- units 256, 4 heads, hidden 1024 (the level-0 blocks of the SEVIR-LR denoiser)
+    "t13": ((13, 16, 16), (13, 1, 1), 2),      # axial T: 13 of 16 slots per cuboid, 64 tiles of 8 cuboids
+    "h16": ((13, 16, 16), (1, 16, 1), 1),      # axial H
+    "w16": ((13, 16, 16), (1, 1, 16), 1),      # axial W
+    "tail": ((3, 6, 7), (1, 6, 1), 3),         # 63 cuboids of 6 slots: 7 full tiles + one of 7 cuboids; 3 workgroups' worth of empty slots
+    "one": ((2, 5, 3), (2, 1, 1), 1),          # 15 cuboids of 2 slots: two tiles, the second one cuboid short
+}
+
+
+def _pair_case(name):
+    import _templates as TP
+    from _weights import seeded_input, seeded_state_dict
+    shape, cuboid, B = PAIR_CASES[name]
+    Cn, heads, Hd = 256, 4, 1024
+    seed = 300 + sum(map(ord, name))
+    sd_a = seeded_state_dict(TP.attn_layer(Cn, heads, cuboid), seed)
+    sd_f = seeded_state_dict(TP.ffn(Cn, Hd), seed + 1)
+    x = seeded_input("pair" + name, (B,) + shape + (Cn,), 1)
+    return shape, cuboid, B, Cn, heads, Hd, sd_a, sd_f, x
+
+
+@pytest.mark.parametrize("name", list(PAIR_CASES))
+def test_attn_ffn_pair_vs_oracle(name):
+    """pd_attn_ffn_pair (csrc/pair_block.hip) against the oracle's statement of one (CuboidSelfAttentionLayer, PositionwiseFFN) pair
+    of StackCuboidSelfAttentionBlock (reference cuboid_transformer.py:1147-1156: x = x + attn(x); x = ffn(x)), against the two round-3
+    kernels it replaces, with the token ids from the table and from its affine form, and twice (bit-equal).  bf16 operands, fp32
+    accumulation: <= 6e-3 rel-L2 on the update, as for the attention block alone."""
+    from oracle import unet as OU
+    from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
+    from prediff_amd.packing import pack_pair_block, pack_pair_vecs
+    shape, cuboid, B, Cn, heads, Hd, sd_a, sd_f, x = _pair_case(name)
+    y1 = x + OU.cuboid_self_attention(sd_a, "", x, heads, cuboid, (0, 0, 0), LLL, "zeros")
+    y_ref = OU.positionwise_ffn(sd_f, "", y1, "gelu")
+    tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+    vol, nc = tabs["vol"], tabs["nc"]
+    assert tabs["mask"] is None and tabs["affine"] is not None and L.attn_ffn_pair_supported(Cn, heads, Hd, vol)
+    d = lambda t: t.to(DEV)
+    bias = relative_position_bias(sd_a["relative_position_bias_table"], sd_a["relative_position_index"], vol).to(DEV)
+    ws = pack_pair_block(d(sd_a["qkv.weight"]), d(sd_a["proj.weight"]), d(sd_f["ffn_1.weight"]), d(sd_f["ffn_2.weight"]))
+    vecs = pack_pair_vecs(d(sd_a["norm.weight"]), d(sd_a["norm.bias"]), d(sd_a["proj.bias"]), d(sd_f["layer_norm.weight"]),
+                          d(sd_f["layer_norm.bias"]), d(sd_f["ffn_2.bias"]), d(sd_f["ffn_1.bias"]), bias)
+    ntok = shape[0] * shape[1] * shape[2]
+    xd = x.reshape(B, ntok, Cn).to(DEV).contiguous()
+    tok = tabs["tok_index"].to(DEV)
+    scale = (Cn // heads) ** -0.5
+    out = torch.full_like(xd, float("nan"))
+    L.attn_ffn_pair(xd, out, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()), "a row was not written (or written with garbage)"
+    e = rel_l2((out - xd).reshape(x.shape).cpu(), y_ref - x)
+    print(f"[attn_ffn_pair {name}] update rel-L2 vs oracle {e:.3e}")
+    assert e < 6e-3
+    assert rel_l2(out.reshape(x.shape).cpu(), y_ref) < 6e-3          # the pair's result (the FFN update is as large as x itself)
+    # in place, token ids from the table instead of the affine form, and a repeat: bit-identical
+    for aff in (None, tabs["affine"], tabs["affine"]):
+        t = xd.clone()
+        L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=aff)
+        torch.cuda.synchronize()
+        assert torch.equal(t, out)
+    # the two launches it replaces (same bf16 operands; erf GELU there, the 2.5e-5 sigmoid form here; another summation order)
+    wq_p, _ = pack_linear(d(sd_a["qkv.weight"]), False)
+    wp_p, _ = pack_linear(d(sd_a["proj.weight"]), False)
+    w1_p, _ = pack_linear(d(sd_f["ffn_1.weight"]), False)
+    w2_p, _ = pack_linear(d(sd_f["ffn_2.weight"]), False)
+    t = xd.clone()
+    L.attn_block_fused(t, t, d(sd_a["norm.weight"]), d(sd_a["norm.bias"]), wq_p, None, wp_p, d(sd_a["proj.bias"]), tok, bias, None,
+                       B, ntok, Cn, heads, nc, vol, scale)
+    L.ffn_fused(t, t, d(sd_f["layer_norm.weight"]), d(sd_f["layer_norm.bias"]), w1_p, d(sd_f["ffn_1.bias"]), w2_p, d(sd_f["ffn_2.bias"]),
+                B * ntok, Cn, Hd, act="gelu")
+    torch.cuda.synchronize()
+    e3 = rel_l2(out - xd, t - xd)
+    print(f"[attn_ffn_pair {name}] update rel-L2 vs pd_attn_block_fused + pd_ffn_fused {e3:.3e}")
+    assert e3 < 1.5e-3
+
+
+def test_attn_ffn_pair_rejects_what_it_does_not_run():
+    assert not L.attn_ffn_pair_supported(128, 2, 512, 16)
+    assert not L.attn_ffn_pair_supported(256, 4, 1024, 25)
+    assert not L.attn_ffn_pair_supported(256, 4, 1024, 16, act="leaky")
+    x = torch.zeros(1, 32, 256, device=DEV)
+    with pytest.raises(L.PrediffHipError):
+        L.attn_ffn_pair(x, x, x, x, None, 1, 32, 2, 16, 0.125)        # neither a token table nor its affine form

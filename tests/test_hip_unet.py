@@ -123,3 +123,40 @@ def test_v1_forward_repeats_bit_equal_at_full_occupancy(precision):
     for k in range(9):
         out = net(x, t, cond)
         assert torch.equal(out, first), f"repeat {k + 1} differs: max |d| {float((out - first).abs().max()):.3e}"
+
+
+def test_v1_forward_b32_vs_oracle_with_pair_kernel():
+    """The occupancy the benchmark runs at -- 32 trajectories per launch, bf16 engine, the level-0 (attention, FFN) pairs on
+    pd_attn_ffn_pair (csrc/pair_block.hip: 832 tiles of 128 rows, four per workgroup) -- against the oracle's CPU forward of the
+    same 32 samples with 32 different timesteps (not a self-comparison), and against the engine with the pair kernel switched off
+    (the two round-3 kernels per pair)."""
+    from prediff_amd import _lib as L
+    sd = seeded_state_dict(TP.unet_template(V1_UNET_CFG, "v1_unet_schema.json"), 1234)
+    net = CuboidTransformerUNet(**V1_UNET_CFG, precision="bf16")
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    B = 32
+    x = seeded_input("b32x", (B, 6, 16, 16, 64), 2)
+    cond = seeded_input("b32c", (B, 7, 16, 16, 64), 3)
+    t = (torch.arange(B) * 31 + 5) % 1000
+    calls = []
+    real = L.attn_ffn_pair
+    L.attn_ffn_pair = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        assert net.fuse_pair and (B * 256 + 7) // 8 >= net.pair_min_tiles
+        out = net(x.cuda(), t.cuda(), cond.cuda())
+        n_pair = len(calls)
+        net.fuse_pair = False
+        out_r3 = net(x.cuda(), t.cuda(), cond.cuda())
+        assert len(calls) == n_pair
+    finally:
+        L.attn_ffn_pair = real
+    assert n_pair == 24, f"{n_pair} pair launches (expected the 24 level-0 pairs of depth [4, 4] x down / up x 3 axes)"
+    ref = OU.unet_forward(sd, V1_UNET_CFG, x, t, cond)
+    e, e3 = rel_l2(out, ref), rel_l2(out_r3, ref)
+    e_ab = rel_l2(out, out_r3.cpu())
+    print(f"[v1 bf16 B=32] rel-L2 vs oracle: pair kernel {e:.3e}, round-3 kernels {e3:.3e}; between the two {e_ab:.3e}")
+    assert e < TOL["bf16"] and e3 < TOL["bf16"]
+    assert e_ab < TOL["bf16"]
+    per_sample = [rel_l2(out[i], ref[i]) for i in range(B)]
+    assert max(per_sample) < 2 * TOL["bf16"], per_sample
