@@ -20,7 +20,8 @@ Two extra objects on the JSON line:
   roofline     - the dominant kernel (Conv3d 3x3x3 implicit GEMM: igemm256_kernel<2,8> where pd_igemm's heuristic picks the
                  256x256 tile, else igemm_kernel<128,128,64,2,false,2,...>): algorithmic FLOPs per launch / its average launch
                  duration measured here with HIP events, against the dense bf16 MFMA peak.
-  attention_block - the fused level-0 cuboid-attention block kernel, same measurement (second half of BASELINE.json's metric).
+  attention_block - the level-0 cuboid-attention scope, same measurement (second half of BASELINE.json's metric): the (attention, FFN)
+                 pair kernel where it runs (FLOPs of both parts over its launch time), with the round-3 attention-block kernel alone beside it.
   cpu_baseline - the oracle (CPU restatement of the reference forward) timed on this box's host cores on a bounded
                  sample of the same workload (kind "port").
 """
@@ -68,15 +69,17 @@ def v1_model(precision, device, workload="v1"):
 
 
 def kernel_times(ldm, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
-    """Average duration (s) of (a) the Conv3d implicit-GEMM launches and (b) the fused level-0 cuboid-attention block launches of
-    one denoiser forward, measured with HIP events on the launch stream (eager mode: one event pair per launch)."""
+    """Average duration (s) of (a) the Conv3d implicit-GEMM launches, (b) the level-0 (attention, FFN) pair launches (pd_attn_ffn_pair)
+    and (c) the round-3 fused attention-block launches (pd_attn_block_fused: what runs when the pair kernel does not -- measured with
+    the pair kernel switched off) of one denoiser forward, with HIP events on the launch stream (eager mode: one event pair per launch).
+    Returns (conv_s, conv_launches, attn_s, attn_launches, pair_s, pair_launches)."""
     from prediff_amd import _lib as L
     net = ldm.torch_nn_module
     z = torch.randn(ldm.get_batch_latent_shape(B), device=device)
     zc = torch.randn((B,) + tuple(cond_shape), device=device)
     t = torch.full((B,), 500, dtype=torch.long, device=device)
-    orig_igemm, orig_attn = L.igemm, L.attn_block_fused
-    conv_pairs, attn_pairs = [], []
+    orig_igemm, orig_attn, orig_pair = L.igemm, L.attn_block_fused, L.attn_ffn_pair
+    conv_pairs, attn_pairs, pair_pairs = [], [], []
 
     def bracket(fn, store, a, k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -93,17 +96,28 @@ def kernel_times(ldm, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
 
     def timed_attn(*a, **k):
         bracket(orig_attn, attn_pairs, a, k)
+
+    def timed_pair(*a, **k):
+        bracket(orig_pair, pair_pairs, a, k)
     net(z, t, zc)
-    L.igemm, L.attn_block_fused = timed_igemm, timed_attn
+    L.igemm, L.attn_block_fused, L.attn_ffn_pair = timed_igemm, timed_attn, timed_pair
+    fuse_pair = getattr(net, "fuse_pair", False)
     try:
         for _ in range(reps):
             net(z, t, zc)
+        if pair_pairs:                       # the attention block alone, as the round-3 engine ran it
+            L.igemm = orig_igemm
+            net.fuse_pair = False
+            attn_pairs.clear()
+            for _ in range(reps):
+                net(z, t, zc)
     finally:
-        L.igemm, L.attn_block_fused = orig_igemm, orig_attn
+        L.igemm, L.attn_block_fused, L.attn_ffn_pair = orig_igemm, orig_attn, orig_pair
+        if hasattr(net, "fuse_pair"):
+            net.fuse_pair = fuse_pair
     torch.cuda.synchronize(device)
-    conv_s = sum(a.elapsed_time(b) for a, b in conv_pairs) * 1e-3 / max(1, len(conv_pairs))
-    attn_s = sum(a.elapsed_time(b) for a, b in attn_pairs) * 1e-3 / max(1, len(attn_pairs)) if attn_pairs else None
-    return conv_s, len(conv_pairs) // reps, attn_s, len(attn_pairs) // reps
+    avg = lambda ps: sum(a.elapsed_time(b) for a, b in ps) * 1e-3 / len(ps) if ps else None
+    return avg(conv_pairs), len(conv_pairs) // reps, avg(attn_pairs), len(attn_pairs) // reps, avg(pair_pairs), len(pair_pairs) // reps
 
 
 def kernel_times_two_lanes(ldm_a, ldm_b, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
@@ -276,6 +290,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-ffn", action="store_true")
     ap.add_argument("--no-fused-attn", action="store_true")
+    ap.add_argument("--no-pair", action="store_true", help="A/B: the level-0 (attention, FFN) pairs as the two round-3 launches instead of pd_attn_ffn_pair")
     ap.add_argument("--igemm-debug", type=int, default=0, help="A/B: OR-ed into every pd_igemm launch's debug_flags")
     ap.add_argument("--min-k-256", type=int, default=-1, help="A/B: shortest K (taps * Cin) the auto tile choice gives to the 256x256 kernel")
     ap.add_argument("--splitk-max-tiles", type=int, default=-1, help="A/B: split-K Conv3d only for launches of at most this many 256x256 tiles (0 = off)")
@@ -341,6 +356,8 @@ def main():
     ldm = v1_model(args.precision, device, args.config)
     ldm.torch_nn_module.fuse_ffn = not args.no_fused_ffn
     ldm.torch_nn_module.fuse_attn = not args.no_fused_attn
+    if args.no_pair:
+        ldm.torch_nn_module.fuse_pair = False
     shape = ldm.get_batch_latent_shape(B)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     zc = torch.randn((B,) + WL["cond"], generator=g).to(device)
@@ -456,7 +473,7 @@ def main():
         n_gpus = world
         value = n_gpus * B * args.steps / elapsed
         ldm.num_streams = S
-        ker_s, launches, attn_s, attn_launches = kernel_times(ldm, Bl, device, cond_shape=WL["cond"])     # the kernels as launched: one lane's sub-batch
+        ker_s, launches, attn_s, attn_launches, pair_s, pair_launches = kernel_times(ldm, Bl, device, cond_shape=WL["cond"])     # the kernels as launched: one lane's sub-batch
         flops_per_launch = WL["conv3d_gflop"] * 1e9 * Bl / CONV3D_LAUNCHES_PER_STEP
         achieved = flops_per_launch / ker_s / 1e12
         traffic = None
@@ -501,13 +518,31 @@ def main():
             line["roofline"]["in_situ"] = {"what": "average launch duration with both lanes active (two streams, HIP events per launch)",
                                            "avg_launch_us": round(ker2_s * 1e6, 2), "achieved": round(ach2, 2),
                                            "frac": round(ach2 / conv_peak, 4), "launches_timed": n2}
-        if attn_s and args.config == "v1":
-            # level-0 block: LN -> QKV (2*S*3C*C) -> core (4*S*vol*C) -> proj (2*S*C*C), S = 3328 tokens, C = 256, vol 13 or 16
-            gf = Bl * (2 * 3328 * 768 * 256 + 2 * 3328 * 256 * 256 + 4 * 3328 * 15 * 256) / 1e9
-            line["attention_block"] = {"kernel": "attn_block_kernel<256> (LN -> QKV -> cuboid attention -> proj -> +x, level 0)",
-                                       "achieved": round(gf / attn_s / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": round(gf / attn_s / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(attn_s * 1e6, 2),
-                                       "launches_per_step": attn_launches * S, "gflop_per_launch": round(gf, 3)}
+        if (attn_s or pair_s) and args.config == "v1":
+            # level-0 block: LN -> QKV (2*S*3C*C) -> core (4*S*vol*C) -> proj (2*S*C*C), S = 3328 tokens, C = 256, vol 13 or 16;
+            # its FFN: 2 * 2*S*C*4C.  
+            gf_attn = Bl * (2 * 3328 * 768 * 256 + 2 * 3328 * 256 * 256 + 4 * 3328 * 15 * 256) / 1e9
+            gf_ffn = Bl * (2 * 2 * 3328 * 256 * 1024) / 1e9
+            attn_alone = None
+            if attn_s:
+                attn_alone = {"kernel": "attn_block_kernel<256> (LN -> QKV -> cuboid attention -> proj -> +x, level 0; the round-3 kernel, "
+                                        "measured with the pair kernel switched off)" if pair_s else
+                                        "attn_block_kernel<256> (LN -> QKV -> cuboid attention -> proj -> +x, level 0)",
+                              "achieved": round(gf_attn / attn_s / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(gf_attn / attn_s / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(attn_s * 1e6, 2),
+                              "launches_per_step": attn_launches * S, "gflop_per_launch": round(gf_attn, 3)}
+            if pair_s:
+                gf = gf_attn + gf_ffn
+                line["attention_block"] = {
+                    "kernel": "pair_kernel (csrc/pair_block.hip): LN -> QKV -> cuboid attention -> proj -> +x -> LN -> FFN-1 -> GELU -> FFN-2 -> +x "
+                              "of one level-0 (attention, FFN) pair in ONE launch, rows register resident",
+                    "achieved": round(gf / pair_s / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(gf / pair_s / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(pair_s * 1e6, 2),
+                    "launches_per_step": pair_launches * S, "gflop_per_launch": round(gf, 3),
+                    "gflop_attention_part": round(gf_attn, 3), "gflop_ffn_part": round(gf_ffn, 3),
+                    "attention_block_alone_round3_kernel": attn_alone}
+            else:
+                line["attention_block"] = attn_alone
         if strong is not None:
             line["ensemble_strong_scaling"] = strong      # BASELINE configs[2]: ensemble=32 over the node's GPUs
         if small:
