@@ -507,10 +507,10 @@ class CuboidTransformerUNet(nn.Module):
     def _params_key(self, device):
         return (str(device), self.precision, self.fp8_conv, self.fp8_linear) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def _pack(self, device):
-        """fp32 checkpoint tensors -> K-contiguous bf16 (hi[/lo]) operands + fp32 epilogue vectors (once per weight version)."""
+    def _packers(self, P: Dict[str, object], device):
+        """The per-module packing functions (writing into P): lin, conv, norm, resblock, stack.  `_pack` runs them over the whole
+        denoiser; the module-level GPU tests run one of them on a stand-alone layer and then call `_resblock` / `_ffn` / ... on it."""
         split = self.precision == "fp32"
-        P: Dict[str, object] = {}
 
         def f32(t):
             return t.detach().float().contiguous().to(device)
@@ -575,6 +575,13 @@ class CuboidTransformerUNet(nn.Module):
                                            P[nf + ".fc2.b"], P[nf + ".fc1.b"], P[na + ".bias"]),
                             float(at.norm.eps), float(ff.layer_norm.eps))
 
+        return dict(f32=f32, lin=lin, conv=conv, norm=norm, resblock=resblock, stack=stack)
+
+    def _pack(self, device):
+        """fp32 checkpoint tensors -> K-contiguous bf16 (hi[/lo]) operands + fp32 epilogue vectors (once per weight version)."""
+        P: Dict[str, object] = {}
+        pk = self._packers(P, device)
+        f32, lin, conv, norm, resblock, stack = (pk[k] for k in ("f32", "lin", "conv", "norm", "resblock", "stack"))
         resblock("first", self.first_proj)
         T, H, W, _ = self.data_shape
         P["pos"] = self.pos_embed.table(T, H, W).to(device)
@@ -716,6 +723,34 @@ class CuboidTransformerUNet(nn.Module):
             L.igemm(a2, w2, A_lo=a2lo, W_lo=w2lo, M=B * S, N=Cout, Cin=ldo, taps=27, w_tap_stride=Cout * ldo, geom=geom,
                     bias=P[name + ".conv2.b"], residual=res, out_f32=out, splitk_ws=ws)
         return out
+
+    def _patch_merge(self, P, name, dl: PatchMerging3D, x, B, thw, Cp, Cout, ds, out, dev):
+        """PatchMerging3D.forward (cuboid_transformer.py:261-296): gather the ds-neighbourhood (zero padded), LayerNorm, reduction Linear."""
+        Tp, Hp, Wp = thw
+        if dl.padding_type == "nearest" and (Hp % ds[1] or Wp % ds[2] or Tp % ds[0]):
+            raise NotImplementedError("PatchMerging3D padding_type='nearest' on a non-divisible shape")
+        So = -(-Tp // ds[0]) * -(-Hp // ds[1]) * -(-Wp // ds[2])
+        Km = Cp * ds[0] * ds[1] * ds[2]
+        ldm = pad64(Km)
+        a, alo = self._bf("pm.a", B * So, ldm, dev)
+        L.patch_merge_layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B, Tp, Hp, Wp, Cp, ds, ldm)
+        wr, wrlo = P[name + ".red.w"]
+        L.igemm(a, wr, A_lo=alo, W_lo=wrlo, M=B * So, N=Cout, Cin=ldm, out_f32=out)
+
+    def _upsample(self, P, name, x, B, thw, Ci, out_hw, Cn, k, res, out, dev):
+        """Upsample3DLayer.forward (cuboid_transformer.py:299-373): nearest x2 in (H, W) + Conv2d k x k per frame [+ fp32 residual]."""
+        Ti, Hi, Wi = thw
+        Hn, Wn = out_hw
+        if not (Hi == (Hn + 1) // 2 and Wi == (Wn + 1) // 2):
+            raise NotImplementedError("Upsample3DLayer: only x2 nearest up-sampling is implemented")
+        Si = Ti * Hi * Wi
+        ldc = pad64(Ci)
+        a, alo = self._bf("up.a", B * Si, ldc, dev)
+        L.cast_rows(x, a, alo, B, Si, 0, Si, Ci, Ci, ldc)
+        geom = L.conv_geom(B * Ti, (1, Hi, Wi), (1, k, k), pad=(0, k // 2, k // 2), up=(1, 2, 2), out_thw=(1, Hn, Wn), virt_thw=(1, Hn, Wn))
+        wu, wulo = P[name + ".conv.w"]
+        L.igemm(a, wu, A_lo=alo, W_lo=wulo, M=B * Ti * Hn * Wn, N=Cn, Cin=ldc, taps=k * k, w_tap_stride=Cn * ldc, geom=geom,
+                bias=P[name + ".conv.b"], residual=res, out_f32=out)
 
     def _attention(self, P, name, at: CuboidSelfAttentionLayer, x, B, S, C, tabs, geo, dev):
         """x += CuboidSelfAttentionLayer(x)  (cuboid_transformer.py:812-966, residual of :1151)."""
@@ -886,16 +921,8 @@ class CuboidTransformerUNet(nn.Module):
             Si = Ti * Hi * Wi
             if i > 0:
                 Tp, Hp, Wp, Cp = shapes[i - 1]
-                dl = self.downsample_layers[i - 1]
-                if dl.padding_type == "nearest" and (Hp % self._ds[1] or Wp % self._ds[2] or Tp % self._ds[0]):
-                    raise NotImplementedError("PatchMerging3D padding_type='nearest' on a non-divisible shape")
-                Km = Cp * self._ds[0] * self._ds[1] * self._ds[2]
-                ldm = pad64(Km)
-                a, alo = self._bf("pm.a", B * Si, ldm, dev)
-                L.patch_merge_layernorm(cur, P[f"down{i - 1}.ln.g"], P[f"down{i - 1}.ln.beta"], a, alo, B, Tp, Hp, Wp, Cp, self._ds, ldm)
                 nxt = self._buf(f"X{i}", (B * Si, Ci), torch.float32, dev)
-                wr, wrlo = P[f"down{i - 1}.red.w"]
-                L.igemm(a, wr, A_lo=alo, W_lo=wrlo, M=B * Si, N=Ci, Cin=ldm, out_f32=nxt)
+                self._patch_merge(P, f"down{i - 1}", self.downsample_layers[i - 1], cur, B, (Tp, Hp, Wp), Cp, Ci, self._ds, nxt, dev)
                 cur = nxt
                 if self.hierarchical_pos_embed:
                     L.add_rowtable(cur, P[f"dpos{i - 1}"], B, Si, Ci)
@@ -915,20 +942,10 @@ class CuboidTransformerUNet(nn.Module):
                 self._stack(P, f"us{i}.{d}", self.up_self_blocks[i][d], cur, B, Si, Ci, i, dev)
             if i > 0:
                 Tn, Hn, Wn, Cn = shapes[i - 1]
-                ldc = pad64(Ci)
-                a, alo = self._bf("up.a", B * Si, ldc, dev)
-                L.cast_rows(cur, a, alo, B, Si, 0, Si, Ci, Ci, ldc)
-                k = self.upsample_kernel_size
-                geom = L.conv_geom(B * Ti, (1, Hi, Wi), (1, k, k), pad=(0, k // 2, k // 2), up=(1, 2, 2),
-                                   out_thw=(1, Hn, Wn), virt_thw=(1, Hn, Wn))
-                if not (Hi == (Hn + 1) // 2 and Wi == (Wn + 1) // 2):
-                    raise NotImplementedError("Upsample3DLayer: only x2 nearest up-sampling is implemented")
                 nxt = self._buf(f"X{i - 1}", (B * Tn * Hn * Wn, Cn), torch.float32, dev)
-                wu, wulo = P[f"up{i - 1}.conv.w"]
                 # next level starts with `x = x + skip` (:473-474): fused as the residual of the up-sampling conv
                 res = skips[i - 1] if self.unet_res_connect else None
-                L.igemm(a, wu, A_lo=alo, W_lo=wulo, M=B * Tn * Hn * Wn, N=Cn, Cin=ldc, taps=k * k, w_tap_stride=Cn * ldc,
-                        geom=geom, bias=P[f"up{i - 1}.conv.b"], residual=res, out_f32=nxt)
+                self._upsample(P, f"up{i - 1}", cur, B, (Ti, Hi, Wi), Ci, (Hn, Wn), Cn, self.upsample_kernel_size, res, nxt, dev)
                 cur = nxt
                 if self.hierarchical_pos_embed:
                     L.add_rowtable(cur, P[f"upos{i - 1}"], B, Tn * Hn * Wn, Cn)
