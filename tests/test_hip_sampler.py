@@ -197,3 +197,57 @@ def test_config_front_end_end_to_end():
     assert not torch.equal(out["pred"][0], out["aligned_pred"][0])
     res = score.compute()
     assert set(res.keys()) == {16, 74, 133, 160, 181, 219, "avg"} and 0.0 <= res["avg"]["csi"] <= 1.0
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_config_front_end_vs_oracle_loop(precision, tol):
+    """SURVEY §8 f1 with a parity statement: YAML -> build_prediff -> evaluate_context (the sampling part of the reference test_step,
+    scripts/prediff/sevirlr/train_sevirlr_prediff.py:905-979, unaligned branch) against the ORACLE run of the same loop on one noise
+    tape: VAE-encode the context, 4 ancestral steps, VAE-decode -> decoded frames, then the SEVIRSkillScore counts of those frames."""
+    import os
+    from oracle import diffusion as OD, skill as OS, unet as OU, vae as OV
+    from prediff_amd import config as CFG
+    from prediff_amd.sevir_skill import SEVIRSkillScore
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = CFG.load_config(os.path.join(root, "configs", "prediff_sevirlr_v1.yaml"))
+    cfg["layout"].update(img_height=32, img_width=32)
+    cfg["model"]["vae"].update(block_out_channels=[32, 64, 64], down_block_types=["DownEncoderBlock2D"] * 3,
+                               up_block_types=["UpDecoderBlock2D"] * 3, layers_per_block=1, latent_channels=4, norm_num_groups=8)
+    cfg["model"]["latent_model"].update(input_shape=[7, 8, 8, 4], target_shape=[6, 8, 8, 4], base_units=64, depth=[1, 1], num_heads=2)
+    cfg["model"]["diffusion"].update(data_shape=[6, 32, 32, 1], latent_shape=[6, 8, 8, 4])
+    cfg["model"]["align"]["alignment_type"] = None
+    cfg["eval"] = dict(cfg.get("eval", {}), eval_aligned=False, eval_unaligned=True, num_samples_per_context=1)
+    ldm, _ = CFG.build_prediff(cfg, precision=precision)
+    usd = seeded_state_dict(ldm.torch_nn_module.state_dict(), 1)
+    vsd = seeded_state_dict(ldm.first_stage_model.state_dict(), 2)
+    ldm.torch_nn_module.load_state_dict(usd)
+    ldm.first_stage_model.load_state_dict(vsd)
+    B, steps = 2, 4
+    seq = seeded_input("seqf1", (B, 13, 32, 32, 1), 4, kind="uniform")
+    g = torch.Generator().manual_seed(99)
+    tape = [torch.randn(B, 6, 8, 8, 4, generator=g) for _ in range(steps + 1)]
+    score = SEVIRSkillScore(layout="NTHWC", mode="0")
+    out = CFG.evaluate_context(ldm, seq.cuda(), cfg, score=score, timesteps=steps, noise_tape=torch.stack(tape))
+    pred = out["pred"][0].float().cpu()
+    # ---- the oracle's run of the same loop ----
+    ucfg, vcfg = CFG.unet_kwargs(cfg["model"]["latent_model"]), CFG.vae_kwargs(cfg["model"]["vae"])
+    ctx, tgt = seq[:, :7], seq[:, 7:13]
+    zc = OV.vae_encode_mode(vsd, vcfg, ctx.permute(0, 1, 4, 2, 3).reshape(B * 7, 1, 32, 32))
+    zc = zc.reshape(B, 7, *zc.shape[1:]).permute(0, 1, 3, 4, 2)
+    buf = {k: torch.as_tensor(v) for k, v in OD.schedule_buffers(OD.beta_schedule("linear", 1000)).items()}
+    traj = OD.ddpm_sample_loop(buf, lambda z, t, c: OU.unet_forward(usd, ucfg, z, t, c), zc, tape, steps)
+    z0 = traj[-1]
+    ref = OV.vae_decode(vsd, vcfg, z0.permute(0, 1, 4, 2, 3).reshape(B * 6, -1, 8, 8)).reshape(B, 6, 1, 32, 32).permute(0, 1, 3, 4, 2)
+    e = rel_l2(pred, ref)
+    print(f"[front end {precision}] decoded frames of evaluate_context vs the oracle loop: rel-L2 {e:.3e}")
+    assert pred.shape == ref.shape and e < tol
+    # skill counts: the HIP scorer on the HIP frames == the oracle scorer on the same frames (bit-exact integer work) ...
+    hits, misses, fas = OS.counts(pred.numpy(), tgt.numpy(), t_axis=1, keep_seq=False)           # (mode "0": summed over the sequence)
+    as_i64 = lambda t: t.cpu().numpy().astype(np.int64)
+    assert np.array_equal(as_i64(score.hits), hits) and np.array_equal(as_i64(score.misses), misses) and np.array_equal(as_i64(score.fas), fas)
+    # ... and the counts of the oracle's frames differ from them only where a pixel sits within the engine's error of a threshold
+    h2, m2, f2 = OS.counts(ref.numpy(), tgt.numpy(), t_axis=1, keep_seq=False)
+    npx = pred.numel()
+    drift = (np.abs(hits - h2).sum() + np.abs(misses - m2).sum() + np.abs(fas - f2).sum()) / (npx * hits.shape[0])
+    print(f"[front end {precision}] skill-count drift between the two pipelines: {drift:.2e} of the (pixel, threshold) decisions")
+    assert drift < (1e-3 if precision == "fp32" else 3e-2)
