@@ -264,6 +264,70 @@ def self_launch(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
+def ensemble_e2e(args, ldm, device, rank, world, local_rank, dist):
+    """BASELINE configs[2] end to end: ONE context of 7 frames 128 x 128, `--ensemble` members (member k on rank k mod world, seeds by
+    member id), per rank: VAE-encode the context, DDIM-50 of its members, VAE-decode; then the one all-gather of the decoded frames
+    (prediff_amd/ensemble.py).  `--steps` = repetitions of the whole thing.  value = samples (members) per second, the all-gather alone
+    is timed beside it."""
+    from prediff_amd.autoencoder_kl import AutoencoderKL
+    from prediff_amd.ensemble import all_gather_members, sample_ensemble, shard_members
+    from prediff_amd.presets import V1_VAE_CFG
+    from prediff_amd.seeding import seeded_state_dict
+    if args.config != "v1":
+        sys.exit("bench.py --ensemble-e2e: the v1 configuration only")
+    vae = AutoencoderKL(**V1_VAE_CFG, precision=args.precision if args.precision in ("bf16", "fp32") else "bf16")
+    vae.load_state_dict(seeded_state_dict(vae.state_dict(), 77))
+    ldm.first_stage_model = vae.to(device).eval()
+    E = args.ensemble
+    if E < world:
+        sys.exit(f"bench.py --ensemble-e2e: --ensemble {E} < {world} ranks")
+    y = torch.rand(1, 7, 128, 128, 1, generator=torch.Generator().manual_seed(5)).to(device)
+    mine = len(shard_members(E, rank, world))
+    ldm.num_streams = lanes_for(mine, args)
+    run = lambda: sample_ensemble(ldm, {"y": y}, E, base_seed=1234, sampler="ddim", ddim_steps=50, eta=0.0, force_collective=dist is not None)
+    for _ in range(max(1, min(args.warmup, 2))):
+        out = run()
+    reps = max(1, min(args.steps, 5))
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = run()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    el = time.perf_counter() - t0
+    # the collective alone, on the same payload
+    local = out[rank::world].contiguous()
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    for _ in range(10):
+        all_gather_members(local, E, rank, world, force_collective=dist is not None)
+    torch.cuda.synchronize(device)
+    ag = (time.perf_counter() - t1) / 10
+    if dist is not None:
+        te = torch.tensor([el, ag], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        el, ag = float(te[0]), float(te[1])
+    if rank == 0:
+        assert out.shape == (E, 6, 128, 128, 1) and bool(torch.isfinite(out).all())
+        print(json.dumps({
+            "metric": "ensemble_samples_per_sec", "value": round(E * reps / el, 3), "unit": "samples/s", "n_gpus": world, "steps": reps,
+            "warmup": min(args.warmup, 2), "ms_per_step": round(el / reps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else args.precision,
+            "data": "synthetic (seeded random weights, one uniform-random context of 7 frames 128 x 128)",
+            "config": {"workload": "SEVIR-LR 7->6 x128x128, ONE ensemble sharded over the GPUs, VAE encode + DDIM-50 + VAE decode + all-gather "
+                                   "(BASELINE.json configs[2])", "ensemble": E, "members_per_gpu": mine, "lanes": ldm.num_streams,
+                       "parallelism": f"ensemble-shard x{world}"},
+            "denoising_steps_per_sec": round(E * 50 * reps / el, 1),
+            "all_gather": {"ms": round(ag * 1e3, 4), "payload_bytes_per_rank": int(local.numel() * 4), "backend": "rccl" if dist is not None else "none (one rank)",
+                           "fraction_of_sample": round(ag / (el / reps), 6)}}), flush=True)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
 def lanes_for(batch, args):
     """Lanes for a small per-GPU batch: sub-batches of >= 2 trajectories on concurrent streams (measured, profiles/r02_*sweep*)."""
     if args.small_streams:
@@ -287,6 +351,9 @@ def main():
     ap.add_argument("--ensemble", type=int, default=32, help="members of the ONE ensemble timed as the strong-scaling line (BASELINE config 3)")
     ap.add_argument("--small-streams", type=int, default=0, help="lanes for the small-batch / strong-scaling lines (0 = automatic)")
     ap.add_argument("--no-extra", action="store_true", help="skip the strong-scaling and small-batch lines")
+    ap.add_argument("--ensemble-e2e", action="store_true",
+                    help="instead of the step benchmark: time sample_ensemble end to end (BASELINE config 3: ONE context, --ensemble members sharded over "
+                         "the ranks, VAE encode, DDIM-50, VAE decode, one all-gather of the decoded frames); reports samples/s and the all-gather time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-ffn", action="store_true")
     ap.add_argument("--no-fused-attn", action="store_true")
@@ -315,7 +382,16 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         seen = torch.ones(1)
         dist.all_reduce(seen)
-        if rank == 0:
+        if args.ensemble_e2e:
+            # the sharding + gather logic of the end-to-end line on the gloo world: a stand-in sampler returns each member's id
+            from prediff_amd.ensemble import sample_ensemble
+            E = args.ensemble
+            got = sample_ensemble(None, torch.zeros(1, 7, 4, 4, 1), E, sample_fn=lambda cb, ks: torch.tensor(ks, dtype=torch.float32).reshape(-1, 1, 1, 1, 1).expand(-1, 6, 4, 4, 1))
+            ok = bool(torch.equal(got[:, 0, 0, 0, 0], torch.arange(E, dtype=torch.float32)))
+            if rank == 0:
+                print(json.dumps({"launch_check": True, "ensemble_e2e": True, "n_gpus": world, "ranks_seen": int(seen.item()), "members": E,
+                                  "gathered_in_member_order": ok}), flush=True)
+        elif rank == 0:
             print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(seen.item())}), flush=True)
         dist.destroy_process_group()
         return
@@ -358,6 +434,8 @@ def main():
     ldm.torch_nn_module.fuse_attn = not args.no_fused_attn
     if args.no_pair:
         ldm.torch_nn_module.fuse_pair = False
+    if args.ensemble_e2e:
+        return ensemble_e2e(args, ldm, device, rank, world, local_rank, dist)
     shape = ldm.get_batch_latent_shape(B)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     zc = torch.randn((B,) + WL["cond"], generator=g).to(device)

@@ -40,3 +40,13 @@ def test_self_launch_starts_one_rank_per_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d == {"launch_check": True, "n_gpus": 2, "ranks_seen": 2}
+
+
+def test_ensemble_e2e_sharding_on_a_two_rank_gloo_world():
+    """--ensemble-e2e --launch-check: the end-to-end line's member sharding and its gather (prediff_amd.ensemble.sample_ensemble with a
+    stand-in sampler) on two gloo ranks started by bench.py itself: every member comes back once, in member order."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check", "--ensemble-e2e", "--ensemble", "7"], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env=_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d == {"launch_check": True, "ensemble_e2e": True, "n_gpus": 2, "ranks_seen": 2, "members": 7, "gathered_in_member_order": True}
