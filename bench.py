@@ -277,7 +277,12 @@ def ensemble_e2e(args, ldm, device, rank, world, local_rank, dist):
         sys.exit("bench.py --ensemble-e2e: the v1 configuration only")
     vae = AutoencoderKL(**V1_VAE_CFG, precision=args.precision if args.precision in ("bf16", "fp32") else "bf16")
     vae.load_state_dict(seeded_state_dict(vae.state_dict(), 77))
-    ldm.first_stage_model = vae.to(device).eval()
+    # the same denoiser instance behind a LatentDiffusion with its first stage (context frames are VAE-encoded by the cond stage =
+    # the first stage, as in the reference config: cond_stage_model "__is_first_stage__")
+    from prediff_amd import presets
+    from prediff_amd.latent_diffusion import LatentDiffusion
+    ldm = LatentDiffusion(torch_nn_module=ldm.torch_nn_module, first_stage_model=vae, cond_stage_model="__is_first_stage__",
+                          **presets.V1_LDM_KW).to(device).eval()
     E = args.ensemble
     if E < world:
         sys.exit(f"bench.py --ensemble-e2e: --ensemble {E} < {world} ranks")
