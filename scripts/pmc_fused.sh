@@ -1,10 +1,10 @@
 #!/bin/bash
-# PMC passes (separate runs, kernel-trace only) over the fused level-0 kernels at the v1 shapes, 32 trajectories: where do the wave
+# PMC passes (separate runs, kernel-trace only) over the level-0 kernels (pair_kernel, attn_block_kernel, ffn64_kernel) at the v1 shapes, 32 trajectories: where do the wave
 # cycles go (VALU / MFMA / LDS / VMEM issue, waits)?  -> gpurun_out/pmc_fused.log
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out/pmcf
-CMD="python scripts/bench_fused_opts.py 4"
+CMD="python scripts/bench_pair.py 32"      # pair kernel + the two round-3 kernels at the v1 level-0 shapes, 32 trajectories
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" \
          "SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES SQ_INSTS_VALU_TRANS SQ_BUSY_CU_CYCLES" \
@@ -18,7 +18,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     n = r["Kernel_Name"]
-    if "attn_block" not in n and "ffn64" not in n:
+    if "attn_block" not in n and "ffn64" not in n and "pair_kernel" not in n:
         continue
     key = (n[:40], r.get("Grid_Size", r.get("Grid_Size_X", "")))
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

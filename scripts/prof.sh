@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=${OUT:-prof}
 rm -rf gpurun_out/$OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$OUT -o trace -- python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline ${EXTRA} > gpurun_out/${OUT}_run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$OUT -o trace -- python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-extra ${EXTRA} > gpurun_out/${OUT}_run.log 2>&1
 tail -2 gpurun_out/${OUT}_run.log | head -1 | cut -c1-400
 find gpurun_out/$OUT -type f | head
 f=$(find gpurun_out/$OUT -name "*kernel_stats.csv" | head -1)
