@@ -127,6 +127,11 @@ __device__ __forceinline__ float pk_gelu_arg(float x) {
 #ifndef PD_PAIR_ABLATE
 #define PD_PAIR_ABLATE 0
 #endif
+#ifndef PD_PAIR_GELU_BOTH
+#define PD_PAIR_GELU_BOTH 1           // 1: gelu(h_j) split over the W2 and the W1 chunk between W1_j and W2_j; 0: all of it beside the W1 chunk
+                                      // (A/B on MI355X, 32 trajectories, two rounds: 258-273 us either way -- the FFN iteration's time is a
+                                      // property of the chunk pair, the four waves meet at every chunk's barrier)
+#endif
 
 __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -518,6 +523,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
       const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < HID / 64 ? j + 3 : 0) * 256u;
+#if PD_PAIR_GELU_BOTH
       // x^T += W2[:, chunk j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (cuboid 0)
       PK_CHUNK(8, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 1, gi))
       PK_GELU_GROUP(hn, 0, 1, 16)
@@ -526,6 +532,14 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       PK_CHUNK(8, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 16, 1, gi))
       PK_GELU_GROUP(hn, 16, 1, 16)
       PK_GELU_GROUP(hn, 16, 1, 17)
+#else
+      // x^T += W2[:, chunk j] gelu(h_j)^T
+      PK_CHUNK(8, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), (void)0)
+      // h_{j+2}^T = W1_{j+2} a^T + b1   beside the whole of gelu(h_{j+1}) (two values per group); b1 of chunk j + 3.
+      PK_CHUNK(8, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 0, 2, gi))
+      PK_GELU_GROUP(hn, 0, 2, 16)
+      PK_GELU_GROUP(hn, 0, 2, 17)
+#endif
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
