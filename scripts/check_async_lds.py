@@ -29,6 +29,9 @@ def vregs(text):
 
 def check(path):
     findings, fn, pending, nreads = [], None, [], 0
+    for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", open(path).read()):
+        if int(m.group(1)) != 0:
+            findings.append(f"{path}: a kernel uses {m.group(1)} bytes of scratch per lane (register spills: VMEM traffic the counted waits do not cover)")
     for ln, raw in enumerate(open(path), 1):
         line = raw.split(";")[0].strip()
         if not line:

@@ -172,3 +172,14 @@ def test_product_ddim_helpers_against_reference_golden(golden):
     assert np.array_equal(S.make_ddim_timesteps("quad", 20, 1000), g["ddim_steps_quad_20"])
     with pytest.raises(NotImplementedError):
         S.make_ddim_timesteps("cubic", 10, 1000)
+
+
+def test_pair_kernel_async_lds_check():
+    """scripts/check_async_lds.py (also run by __graft_entry__.build()): the pair kernel's ISA keeps every register with an LDS read in
+    flight untouched until the covering wait, and uses no scratch.  Needs hipcc (cross-compiles without a GPU)."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_async_lds.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "0 finding(s)" in out.stdout
