@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
