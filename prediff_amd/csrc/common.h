@@ -72,6 +72,21 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(1.0f - y, x);
 }
 
+// GELU as x * sigmoid(x (a + b x^2 + c x^4)) -- 9 VALU instructions (2 transcendental) instead of the 16 of the erf form above; minimax fit
+// against 0.5 x (1 + erf(x / sqrt 2)) on [-9, 9]: max abs error 2.5e-5 (x^2 is clamped where the sigmoid is saturated: the quartic term
+// would turn the polynomial over at |x| ~ 11).  Used where the result is rounded to bf16 anyway (bf16 engine: the FFN-1 epilogue of
+// pd_igemm and pd_attn_ffn_pair); the hi/lo (fp32-class) engine keeps the erf form.
+__device__ __forceinline__ float gelu_sigmoid_arg(float x) {   // the argument of exp2 (first stage of the software-pipelined form)
+  constexpr float L2E = -1.4426950408889634f;
+  const float x2 = fminf(x * x, 52.0f);
+  float pl = fmaf(x2, L2E * -7.03034059e-04f, L2E * 7.40112943e-02f);
+  pl = fmaf(x2, pl, L2E * 1.59501577f);
+  return x * pl;
+}
+__device__ __forceinline__ float gelu_sigmoid(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gelu_sigmoid_arg(x)));
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case PD_ACT_GELU: return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));

@@ -46,8 +46,10 @@ __device__ __forceinline__ void igemm_epilogue_rows(const pd_igemm_args& p, cons
         for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(rv + 4 * q); v[4 * q] += t4.x; v[4 * q + 1] += t4.y; v[4 * q + 2] += t4.z; v[4 * q + 3] += t4.w; }
       }
       if (act != 0) {
+        // bf16-only GELU producer (FFN-1 of the bf16 engine: ACT and OL are compile-time here): the 9-instruction sigmoid form, 2.5e-5 from
+        // the erf form and rounded to bf16 right below; every other call site (hi/lo engine included) keeps act_apply
 #pragma unroll
-        for (int e = 0; e < CW; ++e) v[e] = act_apply(v[e], act);
+        for (int e = 0; e < CW; ++e) v[e] = (ACT == PD_ACT_GELU && OL == 0 && OF == 0) ? gelu_sigmoid(v[e]) : act_apply(v[e], act);
       }
       if (has_mu) {
 #pragma unroll

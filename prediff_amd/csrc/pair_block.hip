@@ -88,26 +88,8 @@ __device__ __forceinline__ bf16x8 pk_pack8(const f32x4& a, const f32x4& b) {
 __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
   return __builtin_bit_cast(s16x4, __builtin_convertvector(a, bf16x4));
 }
-// GELU as x * sigmoid(x (a + b x^2 + c x^4)), x^2 clamped where the sigmoid is saturated (the quartic term would turn the polynomial
-// over at |x| ~ 11).  Coefficients: minimax fit against 0.5 x (1 + erf(x / sqrt 2)) on [-9, 9], max abs error 2.5e-5; pre-multiplied by
-// -log2(e) for v_exp_f32.
-__device__ __forceinline__ float pk_gelu(float x) {
-  constexpr float L2E = -1.4426950408889634f;
-  const float x2 = fminf(x * x, 52.0f);
-  float pl = fmaf(x2, L2E * -7.03034059e-04f, L2E * 7.40112943e-02f);
-  pl = fmaf(x2, pl, L2E * 1.59501577f);
-  const float e = __builtin_amdgcn_exp2f(x * pl);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-// the argument of exp2 in pk_gelu (first stage of the software-pipelined form)
-__device__ __forceinline__ float pk_gelu_arg(float x) {
-  constexpr float L2E = -1.4426950408889634f;
-  const float x2 = fminf(x * x, 52.0f);
-  float pl = fmaf(x2, L2E * -7.03034059e-04f, L2E * 7.40112943e-02f);
-  pl = fmaf(x2, pl, L2E * 1.59501577f);
-  return x * pl;
-}
+// GELU: common.h gelu_sigmoid / gelu_sigmoid_arg (x * sigmoid(x (a + b x^2 + c x^4)), 2.5e-5 from the erf form)
+#define pk_gelu_arg gelu_sigmoid_arg
 
 #define PK_WLD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 // wait until at most N LDS operations are outstanding; the fragment about to be consumed is tied to the wait (in / out operand), so
