@@ -37,7 +37,13 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 namespace pairk {
 constexpr int C = 256, HEADS = 4, HID = 1024;
-constexpr int PF = 6, PFN = 8;                     // weight fragments in flight (LDS latency ~ 4 x 32 MFMA clocks) / register slots: the slot of
+#ifndef PD_PAIR_PF
+#define PD_PAIR_PF 4
+#endif
+#ifndef PD_PAIR_DMA_SPREAD
+#define PD_PAIR_DMA_SPREAD 0
+#endif
+constexpr int PF = PD_PAIR_PF, PFN = 8;                     // weight fragments in flight (LDS latency ~ 4 x 32 MFMA clocks) / register slots: the slot of
                                                    // fragment i is i % PFN in EVERY chunk, so PFN must divide the 32 fragments of a chunk
 constexpr int CHUNK = 32768, NSLOT = 4, NFRAG = 32;
 static_assert(NFRAG % PFN == 0 && PF + 2 <= PFN && PF % 2 == 0 && PF + 4 <= 15, "fragment pipeline geometry");
@@ -130,22 +136,27 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 
   // ---- weight stream: chunk ids 0 .. CH_ALL-1 cyclically, chunk number n -> ring slot n & 3 ----
   const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, p.wbytes, 0x00020000);
-  int n_issued = 0, kid = 0;
+  // Every wave copies a quarter of every chunk, as 8 pieces of 1 KB (one DMA instruction each); piece k of a wave belongs to chunk
+  // k / 8.  Default (PD_PAIR_DMA_SPREAD 0): the prologue issues chunks 0..2, then the 8 pieces of chunk c + 3 go out in one burst
+  // behind the mid-chunk barrier of chunk c (everybody is past chunk c - 1, whose slot this is).  PD_PAIR_DMA_SPREAD 1 issues ONE
+  // piece every second fragment group instead (prologue: chunks 0, 1 and half of 2; groups 0..6 of chunk c: second half of chunk c + 2,
+  // groups 8..14: first half of chunk c + 3), the "even interleave" of the 256^2 GEMM kernel -- measured here 3 % SLOWER (275-279 vs
+  // 264-270 us at 32 trajectories, two rounds): with one wave per SIMD every piece costs the wave its own issue slots either way.
+  int n_piece = 0, kid = 0;                        // pieces issued by this wave; stream id of the chunk the next piece belongs to
   const uint32_t dma_voff = (uint32_t)lane * 16u;
-  auto issue_next = [&]() {
+  auto issue_piece = [&]() {
 #if PD_PAIR_ABLATE & 1
-    if (n_issued >= 3) { ++n_issued; return; }
+    if (n_piece >= (PD_PAIR_DMA_SPREAD ? 20 : 24)) { ++n_piece; return; }
 #endif
-    char* d = smem + RING_OFF + (n_issued & (NSLOT - 1)) * CHUNK + wave * (DMA_PER_WAVE * 1024);
-    const uint32_t so = (uint32_t)kid * CHUNK + (uint32_t)wave * (DMA_PER_WAVE * 1024);
-#pragma unroll
-    for (int i = 0; i < DMA_PER_WAVE; ++i) BLDS16(rW, d + i * 1024, dma_voff, so + i * 1024);
-    ++n_issued;
-    kid = (kid + 1 == CH_ALL) ? 0 : kid + 1;
+    const int sub = n_piece & (DMA_PER_WAVE - 1);
+    char* d = smem + RING_OFF + ((n_piece >> 3) & (NSLOT - 1)) * CHUNK + wave * (DMA_PER_WAVE * 1024) + sub * 1024;
+    const uint32_t so = (uint32_t)kid * CHUNK + (uint32_t)wave * (DMA_PER_WAVE * 1024) + (uint32_t)sub * 1024u;
+    BLDS16(rW, d, dma_voff, so);
+    ++n_piece;
+    if (sub == DMA_PER_WAVE - 1) kid = (kid + 1 == CH_ALL) ? 0 : kid + 1;
   };
-  issue_next();
-  issue_next();
-  issue_next();
+#pragma unroll
+  for (int i = 0; i < (PD_PAIR_DMA_SPREAD ? 20 : 24); ++i) issue_piece();
 
   const uint32_t vbase = (uint32_t)(uintptr_t)(smem + RING_OFF) + (uint32_t)lane * 16u;   // fragment reads: lane-linear 16 B
   const uint32_t vtab = (uint32_t)(uintptr_t)smem + (uint32_t)g * 16u;                     // fp32 tables: 4 floats at column 4 g
@@ -164,9 +175,11 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // of the group's two fragments (BODY_STMT, once per fragment: `i`, `wf`) and HOOK_STMT (`gi`): independent work for their shadow
   // (GELU stages, ONE row load or store).
   // In the middle of chunk cc (group 8): chunk cc+1 has landed for everybody and everybody is past chunk cc-1, whose slot takes chunk
-  // cc+3.  VMC = the VMEM instructions younger than chunk cc+1's DMA that may stay in flight: the 8 DMA pieces of chunk cc+2 plus
-  // the row loads / stores the hooks issued since (a fixed schedule: the constants are derived at the tile loop).  Loads and
-  // stores retire in order (one vmcnt queue on gfx9-class hardware), and every hook instruction is issued unconditionally.
+  // cc+3.  The last piece of chunk cc+1 was issued just before the previous mid-chunk sync, so VMC = the VMEM instructions issued
+  // since then that may stay in flight: 8 DMA pieces (4 of chunk cc+2 in the second half of chunk cc-1, 4 in the first half of
+  // chunk cc) plus the row loads / stores the hooks issued in those two half chunks (a fixed schedule: the constants are derived at
+  // the tile loop).  Loads and stores retire in order (one vmcnt queue on gfx9-class hardware), and every hook instruction is
+  // issued unconditionally.
   // EXTRA_STMT: NEXTRA other LDS reads issued at the start; they have landed at group PF / 2, where LANDED_STMT re-defines their
   // destinations (PK_LANDED).
   // RULE for every asynchronous (inline-asm) LDS read in this kernel: its destination must not live long BEFORE its wait -- the
@@ -175,6 +188,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // (PK_LANDED, no instruction) right after the wait that covers them and only that new value lives on; and wherever more than a few
   // instructions separate two chunk loops the fragments in flight are drained first (PK_DRAIN).  scripts/check_async_lds.py replays
   // the LDS queue over the generated ISA and fails the build if any instruction touches a destination that is still in flight.
+#define PK_VMC(BURST, SPREAD) (PD_PAIR_DMA_SPREAD ? (SPREAD) : (BURST))
 #define PK_RD_ON (!(PD_PAIR_ABLATE & 2))
 #define PK_MFMA_ON (!(PD_PAIR_ABLATE & 4))
 #define PK_RD(i_)                                                                                 \
@@ -190,8 +204,9 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       if (gi == 0) { EXTRA_STMT; }                                                                \
       if (gi == NFRAG / 4) {                                                                      \
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VMC) : "memory");                   \
-        issue_next();                                                                             \
+        if (!PD_PAIR_DMA_SPREAD) { _Pragma("unroll") for (int i_ = 0; i_ < DMA_PER_WAVE; ++i_) issue_piece(); } \
       }                                                                                           \
+      if (PD_PAIR_DMA_SPREAD && (gi & 1) == 0) issue_piece();                                     \
       PK_RD(2 * gi + PF);                                                                         \
       PK_RD(2 * gi + PF + 1);                                                                     \
       asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[(2 * gi) % PFN]), "+v"(w[(2 * gi + 1) % PFN]) \
@@ -223,6 +238,11 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   const auto rO = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.xbytes, 0x00020000);
   constexpr uint32_t OOB = 0xFFFFF000u;
   auto tile_rows = [&](int tile, uint32_t (&off)[2]) {
+    // (the lane id is re-derived here, opaquely: q and g kept alive across the whole tile loop were the two registers this kernel
+    //  did not have -- they went to scratch, and a scratch reload drains every DMA piece in flight)
+    uint32_t l2;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+    const int q = (int)(l2 & 15u), g = (int)(l2 >> 4);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int64_t gc = (int64_t)tile * 8 + wave * 2 + c;
@@ -260,7 +280,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       xn[c][nt] = PK_ROW_LD(noff[c], nt);
       acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};       // (the first tile has no predecessor: its hook stores go to OOB offsets)
     }
-  // chunks 0..2 landed (the row loads above are younger: this wait covers both), visible to every wave; fragment prologue
+  // chunks 0, 1 and half of 2 landed (the row loads above are younger: this wait covers both), visible to every wave; fragment prologue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -348,8 +368,11 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     PK_TRACE();   // LN1 done
     // VMEM schedule around a tile boundary (chunk c = consumption order; hooks issue one row instruction per group):
     //   W2_14 (c46): 16 loads, W2_15 (c47): 16 loads, Q_0 (c48): 16 stores, K_0 (c49): 16 stores; everything else none.
-    //   VMC(c) = 8 + hook instructions issued in [second half of c-2, first half of c]:
-    //   c46: 8 + 8 = 16;  c47: 8 + 16 + 8 = 32;  c48: 8 + 8 + 16 + 8 = 40;  c49: 40;  c50 (V_0): 8 + 8 + 16 = 32;  c51 (P_0): 8 + 8 = 16.
+    //   pieces in one burst behind the mid-chunk barrier (PD_PAIR_DMA_SPREAD 0): chunk c+1's pieces were issued at the sync of chunk c-2,
+    //     VMC(c) = 8 + hook instructions issued in [second half of c-2, first half of c]:
+    //     c46: 8 + 8 = 16;  c47: 8 + 16 + 8 = 32;  c48: 8 + 8 + 16 + 8 = 40;  c49: 40;  c50 (V_0): 8 + 8 + 16 = 32;  c51 (P_0): 8 + 8 = 16.
+    //   one piece every second group (PD_PAIR_DMA_SPREAD 1): VMC(c) = 8 + hook instructions issued in [second half of c-1, first half of c]:
+    //     c46: 8 + 0 + 8 = 16;  c47: 8 + 8 + 8 = 24;  c48: 8 + 8 + 8 = 24;  c49: 24;  c50 (V_0): 8 + 8 + 0 = 16;  c51 (P_0): 8.
     auto head = [&](auto first_tag, int h) __attribute__((always_inline)) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -362,7 +385,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
-      PK_CHUNK(FIRST ? 40 : 8, 0, (void)0, (void)0, PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[0][gi], ooff[0], gi); })
+      PK_CHUNK(FIRST ? PK_VMC(40, 24) : 8, 0, (void)0, (void)0, PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[0][gi], ooff[0], gi); })
 #if PD_PAIR_DEBUG
       if (h == 0) { dump4(1, 0, t[0][0], t[0][1], t[0][2], t[0][3]); dump4(1, 1, t[1][0], t[1][1], t[1][2], t[1][3]); }
 #endif
@@ -375,7 +398,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
       PK_TRACE();   // q done
       // ---------------- k^T = Wk_h a^T  (head 0: ... and those of cuboid 1) ----------------
-      PK_CHUNK(FIRST ? 40 : 8, 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[1][gi], ooff[1], gi); })
+      PK_CHUNK(FIRST ? PK_VMC(40, 24) : 8, 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[1][gi], ooff[1], gi); })
       PK_DRAIN();
       PK_TRACE();   // k done
       // ---------------- S^T = K Q^T, softmax over the keys (registers + two row swaps) ----------------
@@ -418,7 +441,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
       PK_TRACE();   // softmax done
       // ---------------- v = a Wv_h^T (plain product: lane = feature, 4 consecutive tokens -> the A operand of O^T = V^T P^T) -------
-      PK_CHUNK(FIRST ? 32 : 8, 0, (void)0, (void)0, {
+      PK_CHUNK(FIRST ? PK_VMC(32, 16) : 8, 0, (void)0, (void)0, {
         if (PK_MFMA_ON) {
           t[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i >> 2], wf, t[0][i & 3], 0, 0, 0);
           t[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i >> 2], wf, t[1][i & 3], 0, 0, 0);
@@ -443,7 +466,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       if constexpr (FIRST) add_vec(xn, T_BP);       // the finished rows have left: acc <- x + b_proj, the accumulator of every head's proj
       PK_TRACE();   // v + PV done
       // ---------------- x^T += Wp[:, head h] O_h^T ----------------
-      PK_CHUNK(FIRST ? 16 : 8, 0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
+      PK_CHUNK(FIRST ? PK_VMC(16, 8) : 8, 0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
     };
     head(std::true_type{}, 0);
 #pragma unroll 1
@@ -533,7 +556,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     PK_TRACE();   // FFN loop done
     // W2_14 beside the whole of gelu(h_15) and the next tile's rows of cuboid 0, then W2_15 beside those of cuboid 1
     // (the LayerNorm fragments are dead: xn takes their registers)
-    PK_CHUNK(16, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { PK_GELU_GROUP(hn, 0, 2, gi) if (PK_HOOK_IO) xn[0][gi] = PK_ROW_LD(noff[0], gi); })
+    PK_CHUNK(PK_VMC(16, 16), 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { PK_GELU_GROUP(hn, 0, 2, gi) if (PK_HOOK_IO) xn[0][gi] = PK_ROW_LD(noff[0], gi); })
     PK_GELU_GROUP(hn, 0, 2, 16)
     PK_GELU_GROUP(hn, 0, 2, 17)
 #pragma unroll
@@ -541,7 +564,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
       hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
     }
-    PK_CHUNK(32, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { if (PK_HOOK_IO) xn[1][gi] = PK_ROW_LD(noff[1], gi); })
+    PK_CHUNK(PK_VMC(32, 24), 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { if (PK_HOOK_IO) xn[1][gi] = PK_ROW_LD(noff[1], gi); })
     PK_DRAIN();                                     // (the next tile's LayerNorm follows)
     PK_TRACE();   // FFN done
   }
