@@ -979,3 +979,37 @@ def test_attn_ffn_pair_rejects_what_it_does_not_run():
     x = torch.zeros(1, 32, 256, device=DEV)
     with pytest.raises(L.PrediffHipError):
         L.attn_ffn_pair(x, x, x, x, None, 1, 32, 2, 16, 0.125)        # neither a token table nor its affine form
+
+
+def test_attn_ffn_pair_stress_bit_equal():
+    """60 launches of pd_attn_ffn_pair at the benchmark's occupancy (32 trajectories: 832 tiles, four per workgroup, the weight stream and
+    the pipelined tile boundary running on across tiles) interleaved with a bandwidth-hungry copy on another stream: every result
+    bit-equal to the first.  The kernel's counted `s_waitcnt vmcnt(N)` / `lgkmcnt(N)` waits assume an exact, in-order instruction
+    census; a miscount shows up as timing-dependent garbage in a few rows, which this would catch."""
+    from prediff_amd.cuboid_geometry import attention_tables
+    from prediff_amd.packing import pack_pair_block, pack_pair_vecs
+    shape, cuboid, B, Cn, heads, Hd = (13, 16, 16), (1, 1, 16), 32, 256, 4, 1024
+    ntok = 13 * 256
+    g = torch.Generator(device="cpu").manual_seed(77)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    x = r(B, ntok, Cn)
+    ws = pack_pair_block(r(768, 256, sc=1 / 16), r(256, 256, sc=1 / 16), r(1024, 256, sc=1 / 16), r(256, 1024, sc=1 / 32))
+    tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+    vecs = pack_pair_vecs(1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), 1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), r(1024, sc=.1), r(4, 16, 16, sc=.5))
+    tok = tabs["tok_index"].to(DEV)
+    run = lambda out: L.attn_ffn_pair(x, out, ws, vecs, tok, B, ntok, tabs["nc"], tabs["vol"], 0.125, tok_affine=tabs["affine"])
+    ref = torch.empty_like(x)
+    run(ref)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ref).all())
+    side = torch.cuda.Stream()
+    big_a, big_b = torch.empty(64 << 20, device=DEV), torch.empty(64 << 20, device=DEV)
+    out = torch.empty_like(x)
+    for it in range(60):
+        if it % 2:
+            with torch.cuda.stream(side):
+                big_b.copy_(big_a)                       # 512 MB of HBM traffic beside the launch
+        out.fill_(float("nan"))
+        run(out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), f"launch {it}: {int((out != ref).sum())} elements differ"
