@@ -853,7 +853,9 @@ class CuboidTransformerUNet(nn.Module):
         for a, at in enumerate(blk.attn_l):
             pair = P.get(f"{name}.pair{a}") if (self.fuse_pair and self.fuse_attn and self.fuse_ffn) else None
             geo = self._geom[level][a]
-            if pair is not None and (B * geo["nc"] + 7) // 8 >= self.pair_min_tiles:
+            # (split_k = False is the batch-split-reproducible mode: no kernel choice may depend on the per-launch batch, so the pair
+            #  kernel -- row-local, bit-identical at every batch size -- then runs whatever the tile count)
+            if pair is not None and (B * geo["nc"] + 7) // 8 >= (self.pair_min_tiles if self.split_k else 0):
                 # x += attn(x); x = ffn(x) in one launch, rows register resident (csrc/pair_block.hip)
                 L.attn_ffn_pair(x, x, pair[0], pair[1], tabs[a]["tok"], B, S, geo["nc"], geo["vol"], float(at.scale), eps_attn=pair[2],
                                 eps_ffn=pair[3], tok_affine=geo.get("affine"))
