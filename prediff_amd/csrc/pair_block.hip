@@ -121,6 +121,7 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
                                       // property of the chunk pair, the four waves meet at every chunk's barrier)
 #endif
 
+template <int NC>
 __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace pairk;
@@ -222,13 +223,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   }
 #define PK_MFMA_T(ACC, AF) /* transposed product on a [64 features x 256 k] chunk: fragment i = 4 ks + dt */ \
   if (PK_MFMA_ON) {                                                                                        \
-    ACC[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[0][i >> 2], ACC[0][i & 3], 0, 0, 0);    \
-    ACC[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[1][i >> 2], ACC[1][i & 3], 0, 0, 0);    \
+    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                      \
+      ACC[c_][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[c_][i >> 2], ACC[c_][i & 3], 0, 0, 0); \
   }
 #define PK_MFMA_OUT(OF) /* x^T += W[256 outputs x 64 k] act^T: fragment i = 16 st + nt */                      \
   if (PK_MFMA_ON) {                                                                                            \
-    acc[0][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[0][i >> 4], acc[0][i & 15], 0, 0, 0);      \
-    acc[1][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[1][i >> 4], acc[1][i & 15], 0, 0, 0);      \
+    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                          \
+      acc[c_][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[c_][i >> 4], acc[c_][i & 15], 0, 0, 0); \
   }
 
   // rows of a tile's cuboids for this lane = (slot q, column group g), as byte offsets into x / out.  An invalid slot gets an offset
@@ -237,15 +238,15 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
   const auto rO = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.xbytes, 0x00020000);
   constexpr uint32_t OOB = 0xFFFFF000u;
-  auto tile_rows = [&](int tile, uint32_t (&off)[2]) {
+  auto tile_rows = [&](int tile, uint32_t (&off)[NC]) {
     // (the lane id is re-derived here, opaquely: q and g kept alive across the whole tile loop were the two registers this kernel
     //  did not have -- they went to scratch, and a scratch reload drains every DMA piece in flight)
     uint32_t l2;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
     const int q = (int)(l2 & 15u), g = (int)(l2 >> 4);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int64_t gc = (int64_t)tile * 8 + wave * 2 + c;
+    for (int c = 0; c < NC; ++c) {
+      const int64_t gc = (int64_t)tile * (4 * NC) + wave * NC + c;
       int row = -1;
       if (gc < (int64_t)p.B * p.nc && q < p.vol) {
         const int b = (int)(gc / p.nc), cu = (int)(gc - (int64_t)b * p.nc);
@@ -270,11 +271,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // transposed product.  xn: the rows of the NEXT tile.  The tile boundary is software pipelined: xn is requested one row-instruction
   // per fragment group during the last two chunks of a tile, the finished rows (acc) leave one row-instruction per group during the
   // first two chunks of the next tile (whose LayerNorm and q / k / v products read xn), and only then acc <- xn + b_proj.
-  f32x4 acc[2][16], xn[2][16];
-  uint32_t roff[2] = {OOB, OOB}, noff[2], ooff[2] = {OOB, OOB};
+  f32x4 acc[NC][16], xn[NC][16];
+  uint32_t roff[NC], noff[NC], ooff[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) roff[c] = ooff[c] = OOB;
   tile_rows(blockIdx.x, noff);
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) {
       xn[c][nt] = PK_ROW_LD(noff[c], nt);
@@ -289,9 +292,12 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     PK_TRACE();   // tile start
-    ooff[0] = roff[0]; ooff[1] = roff[1];
-    roff[0] = noff[0]; roff[1] = noff[1];
-    noff[0] = noff[1] = OOB;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      ooff[c] = roff[c];
+      roff[c] = noff[c];
+      noff[c] = OOB;
+    }
     if (tile + (int)gridDim.x < p.ntiles) tile_rows(tile + gridDim.x, noff);
 #if PD_PAIR_DEBUG
     auto dump4 = [&](int stage, int c, const f32x4& a, const f32x4& b, const f32x4& cc4, const f32x4& d) {
@@ -301,12 +307,12 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
     };
 #endif
-    bf16x8 af[2][8];                                // LayerNorm output as B-operand fragments: [cuboid][k-step of 32]
+    bf16x8 af[NC][8];                                // LayerNorm output as B-operand fragments: [cuboid][k-step of 32]
     // LayerNorm over the 256 columns of a row (64 in this lane, the rest in lanes q + 16 g'), -> af
-    auto layer_norm = [&](const f32x4 (&src)[2][16], int t_gamma, int t_beta, float eps) {
-      float mean[2], rstd[2];
+    auto layer_norm = [&](const f32x4 (&src)[NC][16], int t_gamma, int t_beta, float eps) {
+      float mean[NC], rstd[NC];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NC; ++c) {
         float s = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) s += (src[c][nt][0] + src[c][nt][1]) + (src[c][nt][2] + src[c][nt][3]);
@@ -337,7 +343,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gb[ks & 1][0]), "+v"(gb[ks & 1][1]), "+v"(gb[ks & 1][2]), "+v"(gb[ks & 1][3]));
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
           f32x4 y[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf)
@@ -349,7 +355,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
     };
     // acc[c][nt] = src[c][nt] + table[16 nt + 4 g .. +3]  (proj / FFN-2 bias: the accumulator starts from residual + bias)
-    auto add_vec = [&](const f32x4 (&src)[2][16], int t_off) {
+    auto add_vec = [&](const f32x4 (&src)[NC][16], int t_off) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         f32x4 bv[8];
@@ -359,7 +365,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc[c][half * 8 + i] = src[c][half * 8 + i] + bv[i];
+          for (int c = 0; c < NC; ++c) acc[c][half * 8 + i] = src[c][half * 8 + i] + bv[i];
       }
     };
 
@@ -373,24 +379,29 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     //     c46: 8 + 8 = 16;  c47: 8 + 16 + 8 = 32;  c48: 8 + 8 + 16 + 8 = 40;  c49: 40;  c50 (V_0): 8 + 8 + 16 = 32;  c51 (P_0): 8 + 8 = 16.
     //   one piece every second group (PD_PAIR_DMA_SPREAD 1): VMC(c) = 8 + hook instructions issued in [second half of c-1, first half of c]:
     //     c46: 8 + 0 + 8 = 16;  c47: 8 + 8 + 8 = 24;  c48: 8 + 8 + 8 = 24;  c49: 24;  c50 (V_0): 8 + 8 + 0 = 16;  c51 (P_0): 8.
+    //   with ONE cuboid per wave (NC = 1) only W2_14 carries loads (16) and Q_0 stores (16): c46 16, c47 8 + 16 = 24, c48 8 + 8 + 8 = 24,
+    //   c49 8 + 16 = 24, c50 8 + 8 = 16, c51 8  (burst form; the spread form is built for NC = 2 only).
+    static_assert(NC == 2 || !PD_PAIR_DMA_SPREAD, "the one-piece-per-group DMA schedule is derived for two cuboids per wave");
+    constexpr int VMC_W2_14 = 16, VMC_W2_15 = NC == 2 ? PK_VMC(32, 24) : 24, VMC_Q0 = NC == 2 ? PK_VMC(40, 24) : 24,
+                  VMC_K0 = NC == 2 ? PK_VMC(40, 24) : 24, VMC_V0 = NC == 2 ? PK_VMC(32, 16) : 16, VMC_P0 = NC == 2 ? PK_VMC(16, 8) : 8;
     auto head = [&](auto first_tag, int h) __attribute__((always_inline)) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 t[2][4];
-      bf16x8 qf[2][2], kf[2][2];
+      f32x4 t[NC][4];
+      bf16x8 qf[NC][2], kf[NC][2];
       f32x4 rb;                                     // relative-position bias of (head h, query q, keys 4 g .. 4 g + 3)
       const uint32_t vrb_h = vrb + (uint32_t)h * 1024u;
       // ---------------- q^T = Wq_h a^T  (head 0: the previous tile's rows of cuboid 0 leave in its shadow) ----------------
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
-      PK_CHUNK(FIRST ? PK_VMC(40, 24) : 8, 0, (void)0, (void)0, PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[0][gi], ooff[0], gi); })
+      PK_CHUNK(FIRST ? VMC_Q0 : 8, 0, (void)0, (void)0, PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[0][gi], ooff[0], gi); })
 #if PD_PAIR_DEBUG
-      if (h == 0) { dump4(1, 0, t[0][0], t[0][1], t[0][2], t[0][3]); dump4(1, 1, t[1][0], t[1][1], t[1][2], t[1][3]); }
+      if (h == 0) { for (int c = 0; c < NC; ++c) dump4(1, c, t[c][0], t[c][1], t[c][2], t[c][3]); }
 #endif
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NC; ++c) {
         qf[c][0] = pk_pack8(t[c][0], t[c][1]);
         qf[c][1] = pk_pack8(t[c][2], t[c][3]);
 #pragma unroll
@@ -398,13 +409,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
       PK_TRACE();   // q done
       // ---------------- k^T = Wk_h a^T  (head 0: ... and those of cuboid 1) ----------------
-      PK_CHUNK(FIRST ? PK_VMC(40, 24) : 8, 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[1][gi], ooff[1], gi); })
+      PK_CHUNK(FIRST ? VMC_K0 : 8, 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO && NC == 2) PK_ROW_ST(acc[NC - 1][gi], ooff[NC - 1], gi); })
       PK_DRAIN();
       PK_TRACE();   // k done
       // ---------------- S^T = K Q^T, softmax over the keys (registers + two row swaps) ----------------
-      s16x4 pf[2];
+      s16x4 pf[NC];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NC; ++c) {
 #if PD_PAIR_DEBUG
         if (h == 0) dump4(2, c, t[c][0], t[c][1], t[c][2], t[c][3]);
 #endif
@@ -441,16 +452,15 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
       PK_TRACE();   // softmax done
       // ---------------- v = a Wv_h^T (plain product: lane = feature, 4 consecutive tokens -> the A operand of O^T = V^T P^T) -------
-      PK_CHUNK(FIRST ? PK_VMC(32, 16) : 8, 0, (void)0, (void)0, {
+      PK_CHUNK(FIRST ? VMC_V0 : 8, 0, (void)0, (void)0, {
         if (PK_MFMA_ON) {
-          t[0][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i >> 2], wf, t[0][i & 3], 0, 0, 0);
-          t[1][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i >> 2], wf, t[1][i & 3], 0, 0, 0);
+          _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) t[c_][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c_][i >> 2], wf, t[c_][i & 3], 0, 0, 0);
         }
       }, (void)0)
       PK_DRAIN();
-      bf16x8 of[2][2];
+      bf16x8 of[NC][2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NC; ++c) {
         f32x4 o[4];
 #if PD_PAIR_DEBUG
         if (h == 0) dump4(5, c, t[c][0], t[c][1], t[c][2], t[c][3]);
@@ -466,7 +476,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       if constexpr (FIRST) add_vec(xn, T_BP);       // the finished rows have left: acc <- x + b_proj, the accumulator of every head's proj
       PK_TRACE();   // v + PV done
       // ---------------- x^T += Wp[:, head h] O_h^T ----------------
-      PK_CHUNK(FIRST ? PK_VMC(16, 8) : 8, 0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
+      PK_CHUNK(FIRST ? VMC_P0 : 8, 0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
     };
     head(std::true_type{}, 0);
 #pragma unroll 1
@@ -482,7 +492,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     // itself, as three software-pipelined stages (polynomial | exp, +1 | rcp, mul) of one value per fragment group: independent
     // short chains beside the MFMAs instead of one 9-deep dependent chain per value (a lone wave hides no VALU latency).
     const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4);
-    f32x4 hc[2][4], hn[2][4], b1n[4];
+    f32x4 hc[NC][4], hn[NC][4], b1n[4];
     float ga[32], gd[32];
 #define PK_HV(H, v) H[(v) >> 4][((v) >> 2) & 3][(v) & 3]
 #define PK_GELU_GROUP(H, VB, NPER, GI)                                                                                    \
@@ -497,25 +507,25 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     PK_B1_FETCH(vb1)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1n[0]), "+v"(b1n[1]), "+v"(b1n[2]), "+v"(b1n[3]));
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
     const uint32_t vb1_1 = vb1 + 256u;
     // ---------------- h_0^T = W1_0 a^T + b1 (in its shadow: b1 of chunk 1) ----------------
     PK_CHUNK(8, 4, PK_B1_FETCH(vb1_1), PK_B1_LANDED(), PK_MFMA_T(hc, af), (void)0)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int ht = 0; ht < 4; ++ht) hn[c][ht] = b1n[ht];
     PK_TRACE();   // W1_0 done
     // ---------------- h_1 beside the whole of gelu(h_0) (two values per group); b1 of chunk 2 ----------------
     const uint32_t vb1_2 = vb1 + 512u;
-    PK_CHUNK(8, 4, PK_B1_FETCH(vb1_2), PK_B1_LANDED(), PK_MFMA_T(hn, af), PK_GELU_GROUP(hc, 0, 2, gi))
-    PK_GELU_GROUP(hc, 0, 2, 16)
-    PK_GELU_GROUP(hc, 0, 2, 17)
-    bf16x8 hfr[2][2];
+    PK_CHUNK(8, 4, PK_B1_FETCH(vb1_2), PK_B1_LANDED(), PK_MFMA_T(hn, af), PK_GELU_GROUP(hc, 0, NC, gi))
+    PK_GELU_GROUP(hc, 0, NC, 16)
+    PK_GELU_GROUP(hc, 0, NC, 17)
+    bf16x8 hfr[NC][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
       hfr[c][0] = pk_pack8(hc[c][0], hc[c][1]);
       hfr[c][1] = pk_pack8(hc[c][2], hc[c][3]);
     }
@@ -524,11 +534,11 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll 1
     for (int j = 0; j < HID / 64 - 2; ++j) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
       const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < HID / 64 ? j + 3 : 0) * 256u;
-#if PD_PAIR_GELU_BOTH
+      if constexpr (NC == 2 && PD_PAIR_GELU_BOTH) {
       // x^T += W2[:, chunk j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (cuboid 0)
       PK_CHUNK(8, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 1, gi))
       PK_GELU_GROUP(hn, 0, 1, 16)
@@ -537,16 +547,16 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       PK_CHUNK(8, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 16, 1, gi))
       PK_GELU_GROUP(hn, 16, 1, 16)
       PK_GELU_GROUP(hn, 16, 1, 17)
-#else
+      } else {
       // x^T += W2[:, chunk j] gelu(h_j)^T
       PK_CHUNK(8, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), (void)0)
       // h_{j+2}^T = W1_{j+2} a^T + b1   beside the whole of gelu(h_{j+1}) (two values per group); b1 of chunk j + 3.
-      PK_CHUNK(8, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 0, 2, gi))
-      PK_GELU_GROUP(hn, 0, 2, 16)
-      PK_GELU_GROUP(hn, 0, 2, 17)
-#endif
+      PK_CHUNK(8, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 0, NC, gi))
+      PK_GELU_GROUP(hn, 0, NC, 16)
+      PK_GELU_GROUP(hn, 0, NC, 17)
+      }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NC; ++c) {
         hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
         hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
 #pragma unroll
@@ -556,21 +566,21 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     PK_TRACE();   // FFN loop done
     // W2_14 beside the whole of gelu(h_15) and the next tile's rows of cuboid 0, then W2_15 beside those of cuboid 1
     // (the LayerNorm fragments are dead: xn takes their registers)
-    PK_CHUNK(PK_VMC(16, 16), 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { PK_GELU_GROUP(hn, 0, 2, gi) if (PK_HOOK_IO) xn[0][gi] = PK_ROW_LD(noff[0], gi); })
-    PK_GELU_GROUP(hn, 0, 2, 16)
-    PK_GELU_GROUP(hn, 0, 2, 17)
+    PK_CHUNK(VMC_W2_14, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { PK_GELU_GROUP(hn, 0, NC, gi) if (PK_HOOK_IO) xn[0][gi] = PK_ROW_LD(noff[0], gi); })
+    PK_GELU_GROUP(hn, 0, NC, 16)
+    PK_GELU_GROUP(hn, 0, NC, 17)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
       hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
       hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
     }
-    PK_CHUNK(PK_VMC(32, 24), 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { if (PK_HOOK_IO) xn[1][gi] = PK_ROW_LD(noff[1], gi); })
+    PK_CHUNK(VMC_W2_15, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { if constexpr (NC == 2) { if (PK_HOOK_IO) xn[NC - 1][gi] = PK_ROW_LD(noff[NC - 1], gi); } })
     PK_DRAIN();                                     // (the next tile's LayerNorm follows)
     PK_TRACE();   // FFN done
   }
   // ---- the last tile's rows ----
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) PK_ROW_ST(acc[c][nt], roff[c], nt);
   // nothing of this workgroup may still be writing LDS when its allocation is handed to the next one
@@ -578,12 +588,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #endif
 }
 
+template <int NC>
 static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   using namespace pairk;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_ffn_pair: hipFuncSetAttribute(%d) failed: %s", LDS_BYTES, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -593,12 +604,13 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   // persistent: every workgroup takes the same number of tiles (the last few one less), one workgroup per CU
   const int per_wg = (a.ntiles + 255) / 256;
   const int grid = (a.ntiles + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(pair_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(pair_kernel<NC>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
 
 extern "C" unsigned long long* pd_pair_trace = nullptr;
+extern "C" int pd_pair_force_nc = 0;             // A/B: 1 / 2 = cuboids per wave whatever the grid; 0 = automatic
 #if PD_PAIR_DEBUG
 extern "C" float* pd_pair_dbg_buf = nullptr;    // (profiling / debugging builds only: scripts/debug_pair.py)
 extern "C" int pd_pair_dbg_stage = 0;
@@ -636,6 +648,10 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   a.aff_outer = a.aff_on ? tok_affine[1] : 0;
   a.aff_inner = a.aff_on ? tok_affine[2] : 0;
   a.aff_slot = a.aff_on ? tok_affine[3] : 0;
-  a.ntiles = (int)(((int64_t)B * nc + 7) / 8);
-  return launch_pair(a, (hipStream_t)stream);
+  // two cuboids per wave (128-row tiles: every weight fragment feeds two MFMAs) once that leaves no CU idle; below that ONE cuboid per
+  // wave (64-row tiles): twice the workgroups, half the MFMAs per streamed chunk -- the small-batch form
+  const int64_t cuboids = (int64_t)B * nc;
+  const int nc_wave = pd_pair_force_nc ? pd_pair_force_nc : ((cuboids + 7) / 8 > 128 ? 2 : 1);
+  a.ntiles = (int)((cuboids + 4 * nc_wave - 1) / (4 * nc_wave));
+  return nc_wave == 2 ? launch_pair<2>(a, (hipStream_t)stream) : launch_pair<1>(a, (hipStream_t)stream);
 }

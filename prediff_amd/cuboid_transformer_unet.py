@@ -343,9 +343,10 @@ class CuboidTransformerUNet(nn.Module):
         self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 64)
         # bf16 mode: one launch per (attention, FFN) pair with the rows register resident (csrc/pair_block.hip) where the block has the
         # level-0 geometry of the SEVIR-LR denoiser (units 256, 4 heads, hidden 1024, GELU, cuboid volume <= 16, no mask, no qkv bias)
-        # and the launch has at least `pair_min_tiles` tiles of 128 rows (below that the two 64-row kernels fill more CUs)
+        # and the launch has at least `pair_min_tiles` tiles of 128 rows (0: always -- the library switches to one cuboid per wave, 64-row
+        # tiles, when 128-row tiles would leave CUs idle: 48 vs 54 us per pair at 4 trajectories, 73 vs 84 at 8)
         self.fuse_pair = os.environ.get("PD_FUSE_PAIR", "1") != "0"
-        self.pair_min_tiles = int(os.environ.get("PD_PAIR_MIN_TILES", "160"))
+        self.pair_min_tiles = int(os.environ.get("PD_PAIR_MIN_TILES", "0"))
         self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)

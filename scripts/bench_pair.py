@@ -34,6 +34,9 @@ def timeit(fn, n=20):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    if os.environ.get("PD_PAIR_NC"):
+        import ctypes
+        ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc").value = int(os.environ["PD_PAIR_NC"])
     shape, Cn, heads, Hd = (13, 16, 16), 256, 4, 1024
     ntok = shape[0] * shape[1] * shape[2]
     g = torch.Generator(device="cpu").manual_seed(1234)

@@ -918,8 +918,20 @@ def _pair_case(name):
     return shape, cuboid, B, Cn, heads, Hd, sd_a, sd_f, x
 
 
+@pytest.fixture
+def pair_nc(request):
+    """pd_pair_force_nc: cuboids per wave of pd_attn_ffn_pair (1 = 64-row tiles, the small-grid form; 2 = 128-row tiles)."""
+    import ctypes
+    v = ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc")
+    old = v.value
+    v.value = request.param
+    yield request.param
+    v.value = old
+
+
+@pytest.mark.parametrize("pair_nc", [1, 2], indirect=True)
 @pytest.mark.parametrize("name", list(PAIR_CASES))
-def test_attn_ffn_pair_vs_oracle(name):
+def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     """pd_attn_ffn_pair (csrc/pair_block.hip) against the oracle's statement of one (CuboidSelfAttentionLayer, PositionwiseFFN) pair
     of StackCuboidSelfAttentionBlock (reference cuboid_transformer.py:1147-1156: x = x + attn(x); x = ffn(x)), against the two round-3
     kernels it replaces, with the token ids from the table and from its affine form, and twice (bit-equal).  bf16 operands, fp32
@@ -947,7 +959,7 @@ def test_attn_ffn_pair_vs_oracle(name):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out).all()), "a row was not written (or written with garbage)"
     e = rel_l2((out - xd).reshape(x.shape).cpu(), y_ref - x)
-    print(f"[attn_ffn_pair {name}] update rel-L2 vs oracle {e:.3e}")
+    print(f"[attn_ffn_pair {name}, {pair_nc} cuboid(s) per wave] update rel-L2 vs oracle {e:.3e}")
     assert e < 6e-3
     assert rel_l2(out.reshape(x.shape).cpu(), y_ref) < 6e-3          # the pair's result (the FFN update is as large as x itself)
     # in place, token ids from the table instead of the affine form, and a repeat: bit-identical
