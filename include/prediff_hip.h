@@ -97,6 +97,11 @@ int pd_layernorm_fp8(const float* x, const float* gamma, const float* beta, uint
 int pd_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
                              int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
                              pd_stream_t stream);
+/* The same with the padding rule of the gather: pad_nearest != 0 = PatchMerging3D(padding_type="nearest") on a shape the down-sampling
+ * does not divide (models/utils.py:228-256: the padded grid is the nearest-neighbour resize of the tensor); 0 = zero padding. */
+int pd_patch_merge_layernorm_ex(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                             int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps, int pad_nearest,
+                             pd_stream_t stream);
 
 /* nn.GroupNorm(G, C, eps) [+ optional (1+scale)*y+shift] [+ SiLU] over channels-last x (B, S, C) fp32 -> bf16 rows of
  * ld_out elements.  `partials` is caller workspace of B*nchunk*G*2 doubles (nchunk from pd_groupnorm_nchunk).
@@ -159,6 +164,10 @@ typedef struct pd_cuboid_attn_args {
   int32_t force_generic;
   int32_t out_fp8_log2;      /* k > 0 (MFMA cores, cuboid volume <= 64 only): out_bf16 points to e4m3 BYTES (ld_out counts bytes) and receives
                                 e4m3(o * 2^k), round to nearest even, saturating: the A operand of an fp8 proj launch.  0: bf16 output */
+  const int32_t* tok_out;    /* NULL: a slot's result goes to the token it was gathered from (tok_index).  Else [nc][vol]: the token that
+                                RECEIVES the slot's result, -1 = nobody -- padding_type "nearest" on a non-divisible shape, where the padded grid
+                                is a nearest-neighbour resize of the tokens (several slots read one token) and the un-padding resizes back
+                                (models/utils.py:228-270).  Runs on the generic core. */
 } pd_cuboid_attn_args;
 int pd_cuboid_attention(const pd_cuboid_attn_args* a, pd_stream_t stream);
 

@@ -39,7 +39,7 @@ class CuboidAttnArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("qkv_bf16", "qkv_f32", "tok_index", "bias", "mask", "out_bf16", "out_bf16_lo", "out_f32")] + \
                [(n, C.c_int32) for n in ("B", "ntok", "C", "heads", "nc", "vol", "ld_qkv", "ld_out")] + \
-               [("scale", C.c_float), ("force_generic", C.c_int32), ("out_fp8_log2", C.c_int32)]
+               [("scale", C.c_float), ("force_generic", C.c_int32), ("out_fp8_log2", C.c_int32), ("tok_out", C.c_void_p)]
 
 
 _lib = None
@@ -53,6 +53,7 @@ _PROTOS = {
     "pd_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pd_layernorm_fp8": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "pd_patch_merge_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_void_p]),
+    "pd_patch_merge_layernorm_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_int, C.c_void_p]),
     "pd_groupnorm_nchunk": (C.c_int, [C.c_int, C.c_int]),
     "pd_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 +
                           [C.c_float, C.c_int, C.c_void_p]),
@@ -213,9 +214,9 @@ def layernorm_fp8(x, gamma, beta, out, rows, Cn, ld_out, fp8_scale, eps=1e-5):
            "pd_layernorm_fp8")
 
 
-def patch_merge_layernorm(x, gamma, beta, out, out_lo, B, T, H, W, Cn, ds, ld_out, eps=1e-5):
-    _check(lib().pd_patch_merge_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(out_lo), B, T, H, W, Cn,
-                                          ds[0], ds[1], ds[2], ld_out, eps, stream_ptr()), "pd_patch_merge_layernorm")
+def patch_merge_layernorm(x, gamma, beta, out, out_lo, B, T, H, W, Cn, ds, ld_out, eps=1e-5, pad_nearest=False):
+    _check(lib().pd_patch_merge_layernorm_ex(ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(out_lo), B, T, H, W, Cn,
+                                             ds[0], ds[1], ds[2], ld_out, eps, 1 if pad_nearest else 0, stream_ptr()), "pd_patch_merge_layernorm")
 
 
 def groupnorm_nchunk(S, Cn):
@@ -260,7 +261,7 @@ def cast_rows(x, out, out_lo, n_samples, rows_in, row_off, rows_out, Cn, ld_in, 
 
 
 def cuboid_attention(*, qkv_bf16=None, qkv_f32=None, tok_index, bias, mask, out_bf16=None, out_bf16_lo=None,
-                     out_f32=None, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out, scale, force_generic=False, out_fp8_log2=0):
+                     out_f32=None, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out, scale, force_generic=False, out_fp8_log2=0, tok_out=None):
     a = CuboidAttnArgs()
     a.qkv_bf16, a.qkv_f32, a.tok_index, a.bias, a.mask = ptr(qkv_bf16), ptr(qkv_f32), ptr(tok_index), ptr(bias), ptr(mask)
     a.out_bf16, a.out_bf16_lo, a.out_f32 = ptr(out_bf16), ptr(out_bf16_lo), ptr(out_f32)
@@ -268,6 +269,7 @@ def cuboid_attention(*, qkv_bf16=None, qkv_f32=None, tok_index, bias, mask, out_
     a.scale = scale
     a.force_generic = 1 if force_generic else 0
     a.out_fp8_log2 = out_fp8_log2     # k > 0: out_bf16 is an e4m3 byte tensor receiving e4m3(o * 2^k) (MFMA cores only)
+    a.tok_out = ptr(tok_out)          # [nc][vol] token that receives each slot's result (padding_type "nearest"), or None = tok_index
     _check(lib().pd_cuboid_attention(C.byref(a), stream_ptr()), "pd_cuboid_attention")
 
 

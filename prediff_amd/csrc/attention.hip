@@ -272,13 +272,16 @@ __global__ void __launch_bounds__(256) cuboid_attn_generic_kernel(const pd_cuboi
   float* sk = sq + vol * hd;            // [vol][hd+1]
   float* sv = sk + vol * (hd + 1);      // [vol][hd]
   float* ss = sv + vol * hd;            // [vol][vol+1]
-  __shared__ int stok[GA_MAXVOL];
+  __shared__ int stok[GA_MAXVOL], stok_out[GA_MAXVOL];
   const int64_t item = blockIdx.x;
   const int h = (int)(item % p.heads);
   const int c = (int)((item / p.heads) % p.nc);
   const int b = (int)(item / ((int64_t)p.heads * p.nc));
   const int tid = threadIdx.x;
-  if (tid < vol) stok[tid] = p.tok_index[c * vol + tid];
+  if (tid < vol) {
+    stok[tid] = p.tok_index[c * vol + tid];
+    stok_out[tid] = p.tok_out ? p.tok_out[c * vol + tid] : stok[tid];    // (padding_type "nearest": who receives the slot's result)
+  }
   __syncthreads();
   for (int i = tid; i < vol * hd; i += 256) {
     const int r = i / hd, d = i - r * hd;
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(256) cuboid_attn_generic_kernel(const pd_cuboi
   __syncthreads();
   for (int i = tid; i < vol * hd; i += 256) {
     const int qi = i / hd, d = i - qi * hd;
-    const int tok = stok[qi];
+    const int tok = stok_out[qi];
     if (tok < 0) continue;
     float a = 0.f;
     for (int kj = 0; kj < vol; ++kj) a += ss[qi * (vol + 1) + kj] * sv[kj * hd + d];
@@ -342,7 +345,9 @@ extern "C" int pd_cuboid_attention(const pd_cuboid_attn_args* pa, pd_stream_t st
   hipStream_t s = (hipStream_t)stream;
   const int64_t nitems = (int64_t)a.B * a.nc * a.heads;
   const bool mfma_ok = a.qkv_bf16 && a.vol <= 64 && (hd % 32) == 0 && a.out_bf16 && !a.out_f32 && !a.out_bf16_lo &&
-                       (a.ld_qkv % 8) == 0 && (a.ld_out % 4) == 0 && !a.force_generic;
+                       (a.ld_qkv % 8) == 0 && (a.ld_out % 4) == 0 && !a.force_generic && !a.tok_out;
+  PD_CHECK_ARG(!a.tok_out || a.vol <= GA_MAXVOL, "pd_cuboid_attention: a separate output token table (padding_type \"nearest\") runs on the "
+               "generic core: cuboid volume %d > %d", a.vol, GA_MAXVOL);
   if (a.out_fp8_log2 > 0 && !mfma_ok) {
     pd_set_error("pd_cuboid_attention: an e4m3 output is built for the MFMA cores only (bf16 q/k/v, cuboid volume <= 64, head_dim %% 32 == 0, out_bf16 alone)");
     return PD_ERR_UNSUPPORTED;

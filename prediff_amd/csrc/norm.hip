@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
                                                         pd_bf16* __restrict__ out_lo, int64_t rows, int C, int ld_out,
                                                         float eps, float fp8_scale,
                                                         // patch-merge gather geometry (GATHER only)
-                                                        int T, int H, int W, int Cs, int dt, int dh, int dw) {
+                                                        int T, int H, int W, int Cs, int dt, int dh, int dw, int nearest) {
   const int lane = threadIdx.x & 63;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   if (row0 >= rows) return;
@@ -46,7 +46,13 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
           // element e = ((it*dh + ih)*dw + iw)*Cs + cs   (cuboid_transformer.py:286-292)
           const int sub = c / Cs, cs = c - sub * Cs;
           const int iw = sub % dw, ih = (sub / dw) % dh, it = sub / (dw * dh);
-          const int tt = to * dt + it, hh = ho * dh + ih, ww = wo * dw + iw;
+          int tt = to * dt + it, hh = ho * dh + ih, ww = wo * dw + iw;
+          if (nearest) {
+            // padding_type "nearest" (models/utils.py:228-256): the padded grid is F.interpolate(x, size = padded size), i.e. padded
+            // coordinate p reads source floor(p * size / padded size) -- always inside the tensor
+            const int Tp = ((T + dt - 1) / dt) * dt, Hp = ((H + dh - 1) / dh) * dh, Wp = ((W + dw - 1) / dw) * dw;
+            tt = tt * T / Tp; hh = hh * H / Hp; ww = ww * W / Wp;
+          }
           if (tt < T && hh < H && ww < W)
             t = *(const float4*)(x + ((((gb * T + tt) * H + hh) * W + ww) * (int64_t)Cs + cs));
         } else {
@@ -114,11 +120,12 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 
 template <bool GATHER, bool F8 = false>
 static void launch_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo, int64_t rows, int C,
-                             int ld_out, float eps, int T, int H, int W, int Cs, int dt, int dh, int dw, hipStream_t s, float fp8_scale = 0.f) {
+                             int ld_out, float eps, int T, int H, int W, int Cs, int dt, int dh, int dw, hipStream_t s, float fp8_scale = 0.f,
+                             int nearest = 0) {
   const int nv = (C + 255) / 256;
 #define PD_LN(NV, R)                                                                                                              \
   hipLaunchKernelGGL((layernorm_kernel<GATHER, NV, R, F8>), dim3((unsigned)((rows + 4 * (R) - 1) / (4 * (R)))), dim3(256), 0, s, x, gamma, \
-                     beta, out, out_lo, rows, C, ld_out, eps, fp8_scale, T, H, W, Cs, dt, dh, dw)
+                     beta, out, out_lo, rows, C, ld_out, eps, fp8_scale, T, H, W, Cs, dt, dh, dw, nearest)
   if (nv <= 1) PD_LN(1, 4);
   else if (nv <= 2) PD_LN(2, 2);
   else if (nv <= 4) PD_LN(4, 1);
@@ -152,17 +159,23 @@ extern "C" int pd_layernorm_fp8(const float* x, const float* gamma, const float*
   return PD_OK;
 }
 
-extern "C" int pd_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
-                                        int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
-                                        pd_stream_t stream) {
+extern "C" int pd_patch_merge_layernorm_ex(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                                           int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
+                                           int pad_nearest, pd_stream_t stream) {
   PD_CHECK_ARG(x && gamma && beta && out, "pd_patch_merge_layernorm: null pointer");
   const int Cm = C * dt * dh * dw;
   PD_CHECK_ARG((C & 3) == 0 && Cm <= 256 * LN_MAXV, "pd_patch_merge_layernorm: C=%d (merged %d) unsupported", C, Cm);
   PD_CHECK_ARG(ld_out >= Cm && (ld_out & 3) == 0 && ld_out <= ((Cm + 255) / 256) * 256, "pd_patch_merge_layernorm: bad ld_out=%d", ld_out);
   const int64_t rows = (int64_t)B * ((T + dt - 1) / dt) * ((H + dh - 1) / dh) * ((W + dw - 1) / dw);
-  launch_layernorm<true>(x, gamma, beta, out, out_lo, rows, Cm, ld_out, eps, T, H, W, C, dt, dh, dw, (hipStream_t)stream);
+  launch_layernorm<true>(x, gamma, beta, out, out_lo, rows, Cm, ld_out, eps, T, H, W, C, dt, dh, dw, (hipStream_t)stream, 0.f, pad_nearest ? 1 : 0);
   PD_CHECK_LAUNCH();
   return PD_OK;
+}
+
+extern "C" int pd_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                                        int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
+                                        pd_stream_t stream) {
+  return pd_patch_merge_layernorm_ex(x, gamma, beta, out, out_lo, B, T, H, W, C, dt, dh, dw, ld_out, eps, 0, stream);
 }
 
 // -------------------------------------------------------------------------------------------------

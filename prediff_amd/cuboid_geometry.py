@@ -72,13 +72,24 @@ def attention_tables(shape, cuboid, shift, strategy, padding_type):
     T, H, W = (int(v) for v in shape)
     cub, sh = clamp_cuboid((T, H, W), cuboid, shift, strategy)
     pad = tuple((b - s % b) % b for s, b in zip((T, H, W), cub))
-    if padding_type == "nearest" and any(pad):
-        raise NotImplementedError("padding_type='nearest' with a non-divisible shape is not supported by the HIP path")
     P = (T + pad[0], H + pad[1], W + pad[2])
     ct, ch, cw = _slot_coords(P, cub, strategy)
     # torch.roll(x, -shift): slot at padded coordinate p reads padded position (p + shift) mod P
     st, s_h, sw = (ct + sh[0]) % P[0], (ch + sh[1]) % P[1], (cw + sh[2]) % P[2]
-    tok = _flatten_slots(st, s_h, sw, lambda t, h, w: np.where((t < T) & (h < H) & (w < W), (t * H + h) * W + w, -1))
+    tok_out = None
+    if padding_type == "nearest" and any(pad):
+        # models/utils.py:228-270: the padded grid is F.interpolate(x, size=P) (nearest): padded position p holds token floor(p * size / P)
+        # per axis -- several slots read one token -- and the un-padding is F.interpolate back to (T, H, W): token o receives the result
+        # of padded position floor(o * P / size).  So the gather table and the table of receivers differ (pd_cuboid_attn_args.tok_out).
+        src = lambda p, n, Pn: (p * n) // Pn
+        tok = _flatten_slots(st, s_h, sw, lambda t, h, w: (src(t, T, P[0]) * H + src(h, H, P[1])) * W + src(w, W, P[2]))
+        recv = np.full(P, -1, dtype=np.int64)                 # padded position -> receiving token
+        ot, oh, ow = np.meshgrid(np.arange(T), np.arange(H), np.arange(W), indexing="ij")
+        recv[(ot * P[0]) // T, (oh * P[1]) // H, (ow * P[2]) // W] = (ot * H + oh) * W + ow
+        tok_out = _flatten_slots(st, s_h, sw, lambda t, h, w: recv[t, h, w])
+        assert sorted(tok_out[tok_out >= 0].tolist()) == list(range(T * H * W))
+    else:
+        tok = _flatten_slots(st, s_h, sw, lambda t, h, w: np.where((t < T) & (h < H) & (w < W), (t * H + h) * W + w, -1))
     nc, vol = tok.shape
 
     # shifted-window region ids (cuboid_transformer.py:516-525): three python slices per axis, later ones win
@@ -96,7 +107,9 @@ def attention_tables(shape, cuboid, shift, strategy, padding_type):
         mask = mask & valid[:, :, None] & valid[:, None, :]
     mask_t = None if mask.all() else torch.from_numpy(mask.astype(np.uint8)).contiguous()
     tok_t = torch.from_numpy(tok.astype(np.int32)).contiguous()
-    return dict(cuboid=cub, shift=sh, pad=pad, nc=int(nc), vol=int(vol), tok_index=tok_t, mask=mask_t, affine=affine_form(tok_t))
+    tok_out_t = torch.from_numpy(tok_out.astype(np.int32)).contiguous() if tok_out is not None else None
+    return dict(cuboid=cub, shift=sh, pad=pad, nc=int(nc), vol=int(vol), tok_index=tok_t, mask=mask_t, tok_out=tok_out_t,
+                affine=affine_form(tok_t) if tok_out is None else None)
 
 
 def affine_form(tok_index: torch.Tensor):

@@ -567,7 +567,7 @@ class CuboidTransformerUNet(nn.Module):
                 for a, (at, ff) in enumerate(zip(blk.attn_l, blk.ffn_l)):
                     geo = self._geom[level][a]
                     if (at.dim == 256 and ff.ffn_1.out_features == 1024 and not ff.gated and at.use_final_proj and at.qkv.bias is None
-                            and geo["mask"] is None and not any(geo["pad"])
+                            and geo["mask"] is None and not any(geo["pad"]) and geo.get("tok_out") is None
                             and L.attn_ffn_pair_supported(at.dim, at.num_heads, ff.ffn_1.out_features, geo["vol"], ff.activation_name)):
                         na, nf = f"{name}.attn{a}", f"{name}.ffn{a}"
                         P[f"{name}.pair{a}"] = (
@@ -613,7 +613,8 @@ class CuboidTransformerUNet(nn.Module):
             self._packed_key = key
             self._pack_generation += 1      # HIP graphs captured against the previous operand buffers are stale (LatentDiffusion._graph_step)
             if device not in self._tables_dev:
-                self._tables_dev[device] = [[dict(tok=g["tok_index"].to(device), mask=(g["mask"].to(device) if g["mask"] is not None else None))
+                self._tables_dev[device] = [[dict(tok=g["tok_index"].to(device), mask=(g["mask"].to(device) if g["mask"] is not None else None),
+                                                  tok_out=(g["tok_out"].to(device) if g.get("tok_out") is not None else None))
                                              for g in lvl] for lvl in self._geom]
         return self._packed
 
@@ -728,13 +729,12 @@ class CuboidTransformerUNet(nn.Module):
     def _patch_merge(self, P, name, dl: PatchMerging3D, x, B, thw, Cp, Cout, ds, out, dev):
         """PatchMerging3D.forward (cuboid_transformer.py:261-296): gather the ds-neighbourhood (zero padded), LayerNorm, reduction Linear."""
         Tp, Hp, Wp = thw
-        if dl.padding_type == "nearest" and (Hp % ds[1] or Wp % ds[2] or Tp % ds[0]):
-            raise NotImplementedError("PatchMerging3D padding_type='nearest' on a non-divisible shape")
         So = -(-Tp // ds[0]) * -(-Hp // ds[1]) * -(-Wp // ds[2])
         Km = Cp * ds[0] * ds[1] * ds[2]
         ldm = pad64(Km)
         a, alo = self._bf("pm.a", B * So, ldm, dev)
-        L.patch_merge_layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B, Tp, Hp, Wp, Cp, ds, ldm)
+        L.patch_merge_layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B, Tp, Hp, Wp, Cp, ds, ldm,
+                                pad_nearest=dl.padding_type == "nearest")
         wr, wrlo = P[name + ".red.w"]
         L.igemm(a, wr, A_lo=alo, W_lo=wrlo, M=B * So, N=Cout, Cin=ldm, out_f32=out)
 
@@ -760,14 +760,15 @@ class CuboidTransformerUNet(nn.Module):
             # the reference pads AFTER the LayerNorm (cuboid_transformer.py:829), so a padded token's q/k/v equal the qkv bias;
             # the HIP kernels give padded slots q = k = v = 0.  Unreachable through CuboidTransformerUNet (qkv_bias is always False).
             raise NotImplementedError("qkv_bias=True together with a padded (non-divisible) shape is not supported by the HIP path")
-        if (self.precision == "bf16" and self.fuse_attn and at.use_final_proj and ld == C
+        if (self.precision == "bf16" and self.fuse_attn and at.use_final_proj and ld == C and tabs.get("tok_out") is None
                 and L.attn_block_fused_supported(C, at.num_heads, geo["vol"])):
             # one launch, q/k/v/attention output never leave the CU (csrc/attn_block.hip)
             L.attn_block_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".qkv.w"][0], P[name + ".qkv.b"],
                                P[name + ".proj.w"][0], P[name + ".proj.b"], tabs["tok"], P[name + ".bias"], tabs["mask"],
                                B, S, C, at.num_heads, geo["nc"], geo["vol"], float(at.scale), tok_affine=geo.get("affine"))
             return
-        if (name + ".qkv.w8") in P and (name + ".proj.w8") in P and geo["vol"] <= 64 and (C // at.num_heads) % 32 == 0 and ld == C:
+        if ((name + ".qkv.w8") in P and (name + ".proj.w8") in P and geo["vol"] <= 64 and (C // at.num_heads) % 32 == 0 and ld == C
+                and tabs.get("tok_out") is None):
             # precision="fp8", long-K level: LayerNorm -> e4m3, QKV on e4m3 operands (bf16 q/k/v for the core), the core's output -> e4m3,
             # proj on e4m3 operands (+ residual).  Tensor scales (powers of two) ride in alpha.
             k8 = self.FP8_ACT_LOG2
@@ -789,7 +790,7 @@ class CuboidTransformerUNet(nn.Module):
         fp32 = self.precision == "fp32"
         o, olo = self._bf("attn.o", B * S, ld, dev)
         kw = dict(tok_index=tabs["tok"], bias=P[name + ".bias"], mask=tabs["mask"], B=B, ntok=S, Cn=C, heads=at.num_heads,
-                  nc=geo["nc"], vol=geo["vol"], ld_qkv=3 * C, ld_out=ld, scale=float(at.scale))
+                  nc=geo["nc"], vol=geo["vol"], ld_qkv=3 * C, ld_out=ld, scale=float(at.scale), tok_out=tabs.get("tok_out"))
         need_f32_out = not at.use_final_proj
         of32 = self._buf("attn.of32", (B * S, ld), torch.float32, dev) if need_f32_out else None
         if fp32:

@@ -83,8 +83,8 @@ def test_small_layers_vs_reference_golden(golden, precision):
         e = rel_l2(x.reshape(2, 3, 4, 4, 32), g[f"ffn_{i}"])
         print(f"[ffn {act} gated={gated} {precision}] {e:.3e}")
         assert e < TOL[precision]
-    # PatchMerging3D: divisible and zero-padded shapes (padding_type="nearest" on a non-divisible shape raises: DESIGN §7)
-    for i, (shape, ptype) in enumerate([((3, 8, 8), "zeros"), ((3, 7, 6), "zeros")]):
+    # PatchMerging3D: divisible, zero-padded and nearest-padded (models/utils.py:228-256) shapes
+    for i, (shape, ptype) in enumerate([((3, 8, 8), "zeros"), ((3, 7, 6), "zeros"), ((3, 7, 6), "nearest")]):
         pm = PatchMerging3D(dim=16, out_dim=32, downsample=(1, 2, 2), padding_type=ptype)
         pm.load_state_dict(seeded_state_dict(TP.patch_merge(16, 32), 210 + i), strict=True)
         pm = pm.cuda()
@@ -100,9 +100,6 @@ def test_small_layers_vs_reference_golden(golden, precision):
         e = rel_l2(out.reshape(g[f"pm_{i}"].shape), g[f"pm_{i}"])
         print(f"[patch merging {shape} {ptype} {precision}] {e:.3e}")
         assert e < TOL[precision]
-    pm = PatchMerging3D(dim=16, out_dim=32, downsample=(1, 2, 2), padding_type="nearest")
-    with pytest.raises(NotImplementedError):
-        net._patch_merge({}, "d", pm, torch.zeros(2 * 3 * 7 * 6, 16, device=DEV), 2, (3, 7, 6), 16, 32, (1, 2, 2), None, dev)
     # Upsample3DLayer: nearest x2 + Conv2d 3x3
     up = Upsample3DLayer(dim=32, out_dim=16, target_size=(3, 8, 8))
     up.load_state_dict(seeded_state_dict(TP.upsample3d(32, 16), 220), strict=True)
@@ -116,3 +113,42 @@ def test_small_layers_vs_reference_golden(golden, precision):
     e = rel_l2(out.reshape(2, 3, 8, 8, 16), g["up_0"])
     print(f"[upsample3d {precision}] {e:.3e}")
     assert e < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [3, 6, 7])
+def test_attention_layer_padded_vs_reference_golden(golden, case, precision):
+    """CuboidSelfAttentionLayer on shapes the cuboid does not divide, against the reference goldens (tests/golden/attn_layer.npz):
+    case 3 zero padding, case 6 'ignore' padding with a shifted window, case 7 padding_type="nearest" (models/utils.py:228-270: the padded
+    grid is a nearest-neighbour resize of the tokens and the un-padding resizes back, so the token a slot reads and the token that receives
+    its result differ -- pd_cuboid_attn_args.tok_out)."""
+    from _cases import ATTN_CASES
+    from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
+    from prediff_amd.cuboid_transformer_unet import CuboidSelfAttentionLayer
+    c = ATTN_CASES[case]
+    Cn, heads, shape, cuboid = c["dim"], c["heads"], tuple(c["shape"]), tuple(c["cuboid"])
+    at = CuboidSelfAttentionLayer(dim=Cn, num_heads=heads, cuboid_size=cuboid, shift_size=c["shift"], strategy=c["strategy"],
+                                  padding_type=c["padding_type"])
+    sd = seeded_state_dict(TP.attn_layer(Cn, heads, cuboid), 100 + case)
+    at.load_state_dict(sd, strict=True)
+    at = at.cuda()
+    dev = torch.device(DEV, 0)
+    net = _host(precision)
+    P = {}
+    pk = net._packers(P, dev)
+    pk["norm"]("a.ln", at.norm); pk["lin"]("a.qkv", at.qkv); pk["lin"]("a.proj", at.proj)
+    geo = attention_tables(shape, cuboid, c["shift"], c["strategy"], c["padding_type"])
+    assert (geo["tok_out"] is not None) == (c["padding_type"] == "nearest")
+    P["a.bias"] = relative_position_bias(at.relative_position_bias_table, at.relative_position_index.cpu(), geo["vol"]).to(dev)
+    tabs = dict(tok=geo["tok_index"].to(dev), mask=geo["mask"].to(dev) if geo["mask"] is not None else None,
+                tok_out=geo["tok_out"].to(dev) if geo["tok_out"] is not None else None)
+    B, S = c["B"], shape[0] * shape[1] * shape[2]
+    x = seeded_input(f"attn{case}", (B,) + shape + (Cn,), 1)
+    xd = x.reshape(B * S, Cn).cuda().contiguous()
+    x0 = xd.clone()
+    net._attention(P, "a", at, xd, B, S, Cn, tabs, geo, dev)
+    torch.cuda.synchronize()
+    y = (xd - x0).reshape(B, *shape, Cn)
+    e = rel_l2(y, golden("attn_layer")[f"y_{case}"])
+    print(f"[attention layer case {case} ({c['padding_type']}) {precision}] rel-L2 vs reference golden {e:.3e}")
+    assert e < (1e-4 if precision == "fp32" else 1e-2)

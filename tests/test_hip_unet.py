@@ -160,3 +160,24 @@ def test_v1_forward_b32_vs_oracle_with_pair_kernel():
     assert e_ab < TOL["bf16"]
     per_sample = [rel_l2(out[i], ref[i]) for i in range(B)]
     assert max(per_sample) < 2 * TOL["bf16"], per_sample
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_tiny_unet_nearest_padding_non_divisible(precision):
+    """padding_type="nearest" on a grid neither the cuboids (2, 4, 4) nor the (1, 2, 2) patch merging divide (5 x 7 x 6): the gather /
+    receive token tables of the attention layers and the nearest-padded patch merging, whole denoiser against the oracle
+    (reference models/utils.py:228-270, cuboid_transformer.py:261-296, :812-966)."""
+    from _cases import _unet
+    cfg = _unet("video_swin_2x4", padding_type="nearest", input_shape=[3, 7, 6, 4], target_shape=[2, 7, 6, 4])
+    net = CuboidTransformerUNet(**cfg, precision=precision)
+    sd = seeded_state_dict(net.state_dict(), 911)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    x = seeded_input("npx", (2,) + tuple(cfg["target_shape"]), 2)
+    cond = seeded_input("npc", (2,) + tuple(cfg["input_shape"]), 3)
+    t = torch.tensor([7, 431])
+    out = net(x.cuda(), t.cuda(), cond.cuda())
+    ref = OU.unet_forward({k: v.cpu() for k, v in sd.items()}, cfg, x, t, cond)
+    e = rel_l2(out, ref)
+    print(f"[tiny unet, nearest padding, 5x7x6, {precision}] rel-L2 vs oracle {e:.3e}")
+    assert e < TOL[precision]

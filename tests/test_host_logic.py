@@ -28,11 +28,13 @@ def test_tok_index_matches_reference_reorder(golden, i):
 def test_mask_matches_reference(golden, i):
     shape, cuboid, shift, strategy, padding_type = MASK_CASES[i]
     g = golden("cuboid_index")
-    if padding_type == "nearest":
-        with pytest.raises(NotImplementedError):
-            G.attention_tables(shape, cuboid, shift, strategy, padding_type)
-        return
     t = G.attention_tables(shape, cuboid, shift, strategy, padding_type)
+    if padding_type == "nearest":
+        # the padded grid is a nearest-neighbour resize: every slot reads a token (none is empty), every token receives exactly one result
+        T, H, W = shape
+        assert t["tok_out"] is not None and t["affine"] is None and int(t["tok_index"].min()) >= 0
+        recv = t["tok_out"].numpy().ravel()
+        assert sorted(recv[recv >= 0].tolist()) == list(range(T * H * W))
     assert list(t["cuboid"]) + list(t["shift"]) == g[f"mask_{i}_clamped"].tolist()
     ref = g[f"mask_{i}"]
     if t["mask"] is None:
