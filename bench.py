@@ -627,6 +627,12 @@ def main():
             else:
                 line["attention_block"] = attn_alone
         if strong is not None:
+            if n_gpus == 1 and "B4" in small and strong["ensemble"] == 32:
+                # what the SAME ensemble would do on 8 GPUs (4 members each): the step loop has no collective, so 8 x the measured
+                # 4-trajectory rate -- a projection from this GPU's own numbers, not a measurement
+                strong["projected_8gpu"] = {"trajectories_per_gpu": 4, "steps_per_sec": round(8 * small["B4"]["value"], 1),
+                                            "speedup_vs_this_gpu": round(8 * small["B4"]["value"] / strong["value"], 2),
+                                            "basis": "8 x small_batch.B4 (no collective in the step loop); north-star target 6x"}
             line["ensemble_strong_scaling"] = strong      # BASELINE configs[2]: ensemble=32 over the node's GPUs
         if small:
             line["small_batch"] = small                   # B in {1..16} beside the headline batch
