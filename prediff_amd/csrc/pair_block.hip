@@ -43,6 +43,10 @@ constexpr int C = 256, HEADS = 4, HID = 1024;
 #ifndef PD_PAIR_DMA_SPREAD
 #define PD_PAIR_DMA_SPREAD 0
 #endif
+#ifndef PD_PAIR_DMA_EARLY
+#define PD_PAIR_DMA_EARLY 0          // 1: a second barrier at the START of a chunk, behind which chunk c + 3 is requested (three chunks of lead
+#endif                              //    instead of two and a half); the landing check of chunk c + 1 stays at the middle.  Measured SLOWER
+                                    //    (259-265 vs 250-258 us at 32 trajectories, 53 vs 50 us at 4): the stream is not DMA-latency bound
 constexpr int PF = PD_PAIR_PF, PFN = 8;                     // weight fragments in flight (LDS latency ~ 4 x 32 MFMA clocks) / register slots: the slot of
                                                    // fragment i is i % PFN in EVERY chunk, so PFN must divide the 32 fragments of a chunk
 constexpr int CHUNK = 32768, NSLOT = 4, NFRAG = 32;
@@ -190,6 +194,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // instructions separate two chunk loops the fragments in flight are drained first (PK_DRAIN).  scripts/check_async_lds.py replays
   // the LDS queue over the generated ISA and fails the build if any instruction touches a destination that is still in flight.
 #define PK_VMC(BURST, SPREAD) (PD_PAIR_DMA_SPREAD ? (SPREAD) : (BURST))
+#define PK_VMC0 (PD_PAIR_DMA_EARLY ? 16 : 8)   /* chunks without hook traffic around them: the DMA pieces younger than chunk c + 1 */
 #define PK_RD_ON (!(PD_PAIR_ABLATE & 2))
 #define PK_MFMA_ON (!(PD_PAIR_ABLATE & 4))
 #define PK_RD(i_)                                                                                 \
@@ -203,9 +208,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     const uint32_t vn_ = vbase + (uint32_t)((cc + 1) & (NSLOT - 1)) * CHUNK;                      \
     _Pragma("unroll") for (int gi = 0; gi < NFRAG / 2; ++gi) {                                    \
       if (gi == 0) { EXTRA_STMT; }                                                                \
+      if (PD_PAIR_DMA_EARLY && gi == 0) {                                                         \
+        asm volatile("s_barrier" ::: "memory");                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < DMA_PER_WAVE; ++i_) issue_piece();                \
+      }                                                                                           \
       if (gi == NFRAG / 4) {                                                                      \
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VMC) : "memory");                   \
-        if (!PD_PAIR_DMA_SPREAD) { _Pragma("unroll") for (int i_ = 0; i_ < DMA_PER_WAVE; ++i_) issue_piece(); } \
+        if (!PD_PAIR_DMA_SPREAD && !PD_PAIR_DMA_EARLY) { _Pragma("unroll") for (int i_ = 0; i_ < DMA_PER_WAVE; ++i_) issue_piece(); } \
       }                                                                                           \
       if (PD_PAIR_DMA_SPREAD && (gi & 1) == 0) issue_piece();                                     \
       PK_RD(2 * gi + PF);                                                                         \
@@ -382,8 +391,15 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     //   with ONE cuboid per wave (NC = 1) only W2_14 carries loads (16) and Q_0 stores (16): c46 16, c47 8 + 16 = 24, c48 8 + 8 + 8 = 24,
     //   c49 8 + 16 = 24, c50 8 + 8 = 16, c51 8  (burst form; the spread form is built for NC = 2 only).
     static_assert(NC == 2 || !PD_PAIR_DMA_SPREAD, "the one-piece-per-group DMA schedule is derived for two cuboids per wave");
-    constexpr int VMC_W2_14 = 16, VMC_W2_15 = NC == 2 ? PK_VMC(32, 24) : 24, VMC_Q0 = NC == 2 ? PK_VMC(40, 24) : 24,
-                  VMC_K0 = NC == 2 ? PK_VMC(40, 24) : 24, VMC_V0 = NC == 2 ? PK_VMC(32, 16) : 16, VMC_P0 = NC == 2 ? PK_VMC(16, 8) : 8;
+    //   PD_PAIR_DMA_EARLY: chunk c + 1's pieces go out at the START of chunk c - 2, so VMC(c) = 16 (chunks c + 2, c + 3) + the hook instructions of
+    //   chunks c - 2, c - 1 and the first half of c:  NC = 2: c46 24, c47 40, c48 56, c49 56, c50 48, c51 32;  NC = 1: 24, 32, 40, 32, 32, 16.
+    constexpr int VMC_W2_14 = PD_PAIR_DMA_EARLY ? 24 : 16;
+    constexpr int VMC_W2_15 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 40 : 32) : (NC == 2 ? PK_VMC(32, 24) : 24);
+    constexpr int VMC_Q0 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 56 : 40) : (NC == 2 ? PK_VMC(40, 24) : 24);
+    constexpr int VMC_K0 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 56 : 32) : (NC == 2 ? PK_VMC(40, 24) : 24);
+    constexpr int VMC_V0 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 48 : 32) : (NC == 2 ? PK_VMC(32, 16) : 16);
+    constexpr int VMC_P0 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 32 : 16) : (NC == 2 ? PK_VMC(16, 8) : 8);
+    static_assert(!(PD_PAIR_DMA_EARLY && PD_PAIR_DMA_SPREAD), "one DMA schedule at a time");
     auto head = [&](auto first_tag, int h) __attribute__((always_inline)) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -396,7 +412,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
-      PK_CHUNK(FIRST ? VMC_Q0 : 8, 0, (void)0, (void)0, PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[0][gi], ooff[0], gi); })
+      PK_CHUNK(FIRST ? VMC_Q0 : PK_VMC0, 0, (void)0, (void)0, PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[0][gi], ooff[0], gi); })
 #if PD_PAIR_DEBUG
       if (h == 0) { for (int c = 0; c < NC; ++c) dump4(1, c, t[c][0], t[c][1], t[c][2], t[c][3]); }
 #endif
@@ -409,7 +425,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
       PK_TRACE();   // q done
       // ---------------- k^T = Wk_h a^T  (head 0: ... and those of cuboid 1) ----------------
-      PK_CHUNK(FIRST ? VMC_K0 : 8, 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO && NC == 2) PK_ROW_ST(acc[NC - 1][gi], ooff[NC - 1], gi); })
+      PK_CHUNK(FIRST ? VMC_K0 : PK_VMC0, 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO && NC == 2) PK_ROW_ST(acc[NC - 1][gi], ooff[NC - 1], gi); })
       PK_DRAIN();
       PK_TRACE();   // k done
       // ---------------- S^T = K Q^T, softmax over the keys (registers + two row swaps) ----------------
@@ -452,7 +468,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
       PK_TRACE();   // softmax done
       // ---------------- v = a Wv_h^T (plain product: lane = feature, 4 consecutive tokens -> the A operand of O^T = V^T P^T) -------
-      PK_CHUNK(FIRST ? VMC_V0 : 8, 0, (void)0, (void)0, {
+      PK_CHUNK(FIRST ? VMC_V0 : PK_VMC0, 0, (void)0, (void)0, {
         if (PK_MFMA_ON) {
           _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) t[c_][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c_][i >> 2], wf, t[c_][i & 3], 0, 0, 0);
         }
@@ -476,7 +492,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       if constexpr (FIRST) add_vec(xn, T_BP);       // the finished rows have left: acc <- x + b_proj, the accumulator of every head's proj
       PK_TRACE();   // v + PV done
       // ---------------- x^T += Wp[:, head h] O_h^T ----------------
-      PK_CHUNK(FIRST ? VMC_P0 : 8, 0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
+      PK_CHUNK(FIRST ? VMC_P0 : PK_VMC0, 0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
     };
     head(std::true_type{}, 0);
 #pragma unroll 1
@@ -512,7 +528,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
     const uint32_t vb1_1 = vb1 + 256u;
     // ---------------- h_0^T = W1_0 a^T + b1 (in its shadow: b1 of chunk 1) ----------------
-    PK_CHUNK(8, 4, PK_B1_FETCH(vb1_1), PK_B1_LANDED(), PK_MFMA_T(hc, af), (void)0)
+    PK_CHUNK(PK_VMC0, 4, PK_B1_FETCH(vb1_1), PK_B1_LANDED(), PK_MFMA_T(hc, af), (void)0)
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -520,7 +536,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     PK_TRACE();   // W1_0 done
     // ---------------- h_1 beside the whole of gelu(h_0) (two values per group); b1 of chunk 2 ----------------
     const uint32_t vb1_2 = vb1 + 512u;
-    PK_CHUNK(8, 4, PK_B1_FETCH(vb1_2), PK_B1_LANDED(), PK_MFMA_T(hn, af), PK_GELU_GROUP(hc, 0, NC, gi))
+    PK_CHUNK(PK_VMC0, 4, PK_B1_FETCH(vb1_2), PK_B1_LANDED(), PK_MFMA_T(hn, af), PK_GELU_GROUP(hc, 0, NC, gi))
     PK_GELU_GROUP(hc, 0, NC, 16)
     PK_GELU_GROUP(hc, 0, NC, 17)
     bf16x8 hfr[NC][2];
@@ -540,18 +556,18 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < HID / 64 ? j + 3 : 0) * 256u;
       if constexpr (NC == 2 && PD_PAIR_GELU_BOTH) {
       // x^T += W2[:, chunk j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (cuboid 0)
-      PK_CHUNK(8, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 1, gi))
+      PK_CHUNK(PK_VMC0, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 1, gi))
       PK_GELU_GROUP(hn, 0, 1, 16)
       PK_GELU_GROUP(hn, 0, 1, 17)
       // h_{j+2}^T = W1_{j+2} a^T + b1   beside the second half of gelu(h_{j+1}); b1 of chunk j + 3
-      PK_CHUNK(8, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 16, 1, gi))
+      PK_CHUNK(PK_VMC0, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 16, 1, gi))
       PK_GELU_GROUP(hn, 16, 1, 16)
       PK_GELU_GROUP(hn, 16, 1, 17)
       } else {
       // x^T += W2[:, chunk j] gelu(h_j)^T
-      PK_CHUNK(8, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), (void)0)
+      PK_CHUNK(PK_VMC0, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), (void)0)
       // h_{j+2}^T = W1_{j+2} a^T + b1   beside the whole of gelu(h_{j+1}) (two values per group); b1 of chunk j + 3.
-      PK_CHUNK(8, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 0, NC, gi))
+      PK_CHUNK(PK_VMC0, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 0, NC, gi))
       PK_GELU_GROUP(hn, 0, NC, 16)
       PK_GELU_GROUP(hn, 0, NC, 17)
       }
