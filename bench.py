@@ -72,14 +72,15 @@ def kernel_times(ldm, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
     """Average duration (s) of (a) the Conv3d implicit-GEMM launches, (b) the level-0 (attention, FFN) pair launches (pd_attn_ffn_pair)
     and (c) the round-3 fused attention-block launches (pd_attn_block_fused: what runs when the pair kernel does not -- measured with
     the pair kernel switched off) of one denoiser forward, with HIP events on the launch stream (eager mode: one event pair per launch).
-    Returns (conv_s, conv_launches, attn_s, attn_launches, pair_s, pair_launches)."""
+    Returns (conv_s, conv_launches, attn_s, attn_launches, pair_s, pair_launches, pair512_s, pair512_launches): the pair launches of the
+    level-0 (units 256) and of the level-1 (units 512) blocks separately."""
     from prediff_amd import _lib as L
     net = ldm.torch_nn_module
     z = torch.randn(ldm.get_batch_latent_shape(B), device=device)
     zc = torch.randn((B,) + tuple(cond_shape), device=device)
     t = torch.full((B,), 500, dtype=torch.long, device=device)
     orig_igemm, orig_attn, orig_pair = L.igemm, L.attn_block_fused, L.attn_ffn_pair
-    conv_pairs, attn_pairs, pair_pairs = [], [], []
+    conv_pairs, attn_pairs, pair_pairs, pair512_pairs = [], [], [], []
 
     def bracket(fn, store, a, k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -98,7 +99,7 @@ def kernel_times(ldm, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
         bracket(orig_attn, attn_pairs, a, k)
 
     def timed_pair(*a, **k):
-        bracket(orig_pair, pair_pairs, a, k)
+        bracket(orig_pair, pair512_pairs if k.get("units", 256) == 512 else pair_pairs, a, k)
     net(z, t, zc)
     L.igemm, L.attn_block_fused, L.attn_ffn_pair = timed_igemm, timed_attn, timed_pair
     fuse_pair = getattr(net, "fuse_pair", False)
@@ -117,7 +118,8 @@ def kernel_times(ldm, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
             net.fuse_pair = fuse_pair
     torch.cuda.synchronize(device)
     avg = lambda ps: sum(a.elapsed_time(b) for a, b in ps) * 1e-3 / len(ps) if ps else None
-    return avg(conv_pairs), len(conv_pairs) // reps, avg(attn_pairs), len(attn_pairs) // reps, avg(pair_pairs), len(pair_pairs) // reps
+    return (avg(conv_pairs), len(conv_pairs) // reps, avg(attn_pairs), len(attn_pairs) // reps, avg(pair_pairs), len(pair_pairs) // reps,
+            avg(pair512_pairs), len(pair512_pairs) // reps)
 
 
 def kernel_times_two_lanes(ldm_a, ldm_b, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
@@ -556,7 +558,7 @@ def main():
         n_gpus = world
         value = n_gpus * B * args.steps / elapsed
         ldm.num_streams = S
-        ker_s, launches, attn_s, attn_launches, pair_s, pair_launches = kernel_times(ldm, Bl, device, cond_shape=WL["cond"])     # the kernels as launched: one lane's sub-batch
+        ker_s, launches, attn_s, attn_launches, pair_s, pair_launches, pair512_s, pair512_launches = kernel_times(ldm, Bl, device, cond_shape=WL["cond"])     # the kernels as launched: one lane's sub-batch
         flops_per_launch = WL["conv3d_gflop"] * 1e9 * Bl / CONV3D_LAUNCHES_PER_STEP
         achieved = flops_per_launch / ker_s / 1e12
         traffic = None
@@ -626,6 +628,15 @@ def main():
                     "attention_block_alone_round3_kernel": attn_alone}
             else:
                 line["attention_block"] = attn_alone
+            if pair512_s:
+                # level-1 pair: S = 832 tokens, C = 512, hidden 2048, cuboid volume 13 or 8
+                gf1 = Bl * 832 * (2 * 4 * 512 * 512 + 2 * 2 * 512 * 2048 + 4 * 10 * 512) / 1e9
+                line["attention_block_level1"] = {
+                    "kernel": "pair_kernel<1, 2> (csrc/pair_block.hip): the same pair at units 512 (4 heads of 128, hidden 2048), 16 rows per wave; "
+                              "replaces qkv / proj / FFN-1 / FFN-2 GEMM launches + 2 LayerNorm + attention core launches",
+                    "achieved": round(gf1 / pair512_s / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(gf1 / pair512_s / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(pair512_s * 1e6, 2),
+                    "launches_per_step": pair512_launches * S, "gflop_per_launch": round(gf1, 3)}
         if strong is not None:
             if n_gpus == 1 and "B4" in small and strong["ensemble"] == 32:
                 # what the SAME ensemble would do on 8 GPUs (4 members each): the step loop has no collective, so 8 x the measured

@@ -247,18 +247,23 @@ int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const
                            int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps, const int32_t* tok_affine,
                            pd_stream_t stream);
 /* One (CuboidSelfAttentionLayer, PositionwiseFFN) pair of StackCuboidSelfAttentionBlock.forward (cuboid_transformer.py:1147-1156:
- * x = x + attn(x); x = ffn(x) with the FFN's own residual; attention :812-966, FFN :182-208) in ONE launch, bf16 engine, for units 256,
- * 4 heads of 64, hidden 1024, GELU, cuboid volume <= 16, no qkv bias, no attention mask (every level-0 axial layer of the SEVIR-LR
- * denoiser); in place allowed.  The rows of two cuboids stay in the registers of one wave from the first LayerNorm to the last
- * residual: x is read once and written once (csrc/pair_block.hip).
- *   wstream: 48 chunks of 32 KB = the four weight matrices as bf16 MFMA fragments in consumption order (prediff_amd/packing.py:
- *            pack_pair_block documents the layout);  vecs: 3584 floats = LN1 gamma, beta, proj bias, LN2 gamma, beta, FFN-2 bias
- *            (256 each), FFN-1 bias (1024), relative-position bias zero padded to (4, 16, 16)  (pack_pair_vecs).
+ * x = x + attn(x); x = ffn(x) with the FFN's own residual; attention :812-966, FFN :182-208) in ONE launch, bf16 engine, GELU, cuboid
+ * volume <= 16, no qkv bias, no attention mask, for units 256 (4 heads of 64, hidden 1024: every level-0 axial layer of the SEVIR-LR
+ * denoiser) and units 512 (4 heads of 128, hidden 2048: every level-1 layer); in place allowed.  The rows of a wave (32 x 256 or
+ * 16 x 512) stay in its registers from the first LayerNorm to the last residual: x is read once and written once
+ * (csrc/pair_block.hip).  A wave works on 16-slot groups: one cuboid each, or pd_attn_ffn_pair_cuboids_per_group(vol) = 2 cuboids of
+ * volume <= 8 side by side.
+ *   wstream: 48 (units 256) / 192 (units 512) chunks of 32 KB = the four weight matrices as bf16 MFMA fragments in consumption order
+ *            (prediff_amd/packing.py: pack_pair_block documents the layout);
+ *   vecs:    LN1 gamma, beta, proj bias, LN2 gamma, beta, FFN-2 bias (units floats each), FFN-1 bias (hidden), then the (4, 16, 16) score
+ *            table of a group: [head][query slot][key slot] = relative-position bias where both slots belong to the same cuboid, -inf
+ *            everywhere else (padded slots, the group's other cuboid)  (pack_pair_vecs): 3584 / 6144 floats;
  *   tok_index [nc][vol] / tok_affine (HOST pointer, 4 ints, or NULL): as for pd_attn_block_fused_ex; one of them is required. */
 int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol, int act);
+int pd_attn_ffn_pair_cuboids_per_group(int vol);
 int pd_attn_ffn_pair(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
-                     const int32_t* tok_affine, int B, int ntok, int nc, int vol, float scale, float eps_attn, float eps_ffn,
-                     pd_stream_t stream);
+                     const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn,
+                     float eps_ffn, pd_stream_t stream);
 
 /* ---- Diagnostic / tuning globals (exported DATA symbols; bench.py, scripts/ and tests poke them through ctypes.in_dll for A/B
  * measurements -- production callers leave them alone).  Every one is process-global and read at launch time. */

@@ -81,7 +81,8 @@ _PROTOS = {
     "pd_attn_block_fused_ex": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "pd_ffn_fused": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pd_attn_ffn_pair_supported": (C.c_int, [C.c_int] * 5),
-    "pd_attn_ffn_pair": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]),
+    "pd_attn_ffn_pair_cuboids_per_group": (C.c_int, [C.c_int]),
+    "pd_attn_ffn_pair": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float] * 3 + [C.c_void_p]),
     "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -369,10 +370,14 @@ def attn_ffn_pair_supported(Cn, heads, hidden, vol, act="gelu"):
     return bool(lib().pd_attn_ffn_pair_supported(Cn, heads, hidden, vol, ACT[act]))
 
 
-def attn_ffn_pair(x, out, wstream, vecs, tok_index, B, ntok, nc, vol, scale, eps_attn=1e-5, eps_ffn=1e-5, tok_affine=None):
-    """One (CuboidSelfAttentionLayer, PositionwiseFFN) pair of a level-0 block in one launch (csrc/pair_block.hip).
+def attn_ffn_pair_cuboids_per_group(vol):
+    return 2 if 1 <= vol <= 8 else 1              # == pd_attn_ffn_pair_cuboids_per_group (tests/test_host_logic.py compares)
+
+
+def attn_ffn_pair(x, out, wstream, vecs, tok_index, B, ntok, nc, vol, scale, eps_attn=1e-5, eps_ffn=1e-5, tok_affine=None, units=256):
+    """One (CuboidSelfAttentionLayer, PositionwiseFFN) pair of a block (units 256 or 512) in one launch (csrc/pair_block.hip).
     wstream / vecs: packing.pack_pair_block / pack_pair_vecs."""
     aff = (C.c_int32 * 4)(*tok_affine) if tok_affine is not None else None
     _check(lib().pd_attn_ffn_pair(ptr(x), ptr(out), ptr(wstream), ptr(vecs), ptr(tok_index),
-                                  C.cast(aff, C.c_void_p) if aff is not None else None, B, ntok, nc, vol, scale, eps_attn, eps_ffn,
-                                  stream_ptr()), "pd_attn_ffn_pair")
+                                  C.cast(aff, C.c_void_p) if aff is not None else None, B, ntok, nc, vol, units, scale, eps_attn,
+                                  eps_ffn, stream_ptr()), "pd_attn_ffn_pair")

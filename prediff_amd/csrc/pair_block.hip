@@ -1,5 +1,6 @@
 // pd_attn_ffn_pair:  x += proj(cuboid_attention(qkv(LayerNorm(x))));  x += W2 gelu(W1 LayerNorm(x) + b1) + b2   in ONE kernel
-// for the level-0 blocks of the SEVIR-LR denoiser (units 256, 4 heads of 64, hidden 1024, cuboid volume <= 16):
+// for the blocks of the SEVIR-LR denoiser -- level 0: units 256, 4 heads of 64, hidden 1024 (CW = 1); level 1: units 512, 4 heads of
+// 128, hidden 2048 (CW = 2) -- with cuboid volume <= 16 (two cuboids of volume <= 8 share a 16-slot group):
 // one (CuboidSelfAttentionLayer, PositionwiseFFN) pair of StackCuboidSelfAttentionBlock.forward -- reference
 // cuboid_transformer.py:812-966 (attention), :182-208 (FFN), :1147-1156 (the pair and its residuals).
 //
@@ -36,27 +37,38 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 namespace pairk {
-constexpr int C = 256, HEADS = 4, HID = 1024;
+constexpr int HEADS = 4;
 #ifndef PD_PAIR_PF
 #define PD_PAIR_PF 4
 #endif
-#ifndef PD_PAIR_DMA_SPREAD
-#define PD_PAIR_DMA_SPREAD 0
-#endif
-#ifndef PD_PAIR_DMA_EARLY
-#define PD_PAIR_DMA_EARLY 0          // 1: a second barrier at the START of a chunk, behind which chunk c + 3 is requested (three chunks of lead
-#endif                              //    instead of two and a half); the landing check of chunk c + 1 stays at the middle.  Measured SLOWER
-                                    //    (259-265 vs 250-258 us at 32 trajectories, 53 vs 50 us at 4): the stream is not DMA-latency bound
+// Two other DMA schedules were built behind compile-time switches, measured on MI355X and removed again (profiles/r04_*):
+// one piece every second fragment group instead of a burst of 8 behind the mid-chunk barrier (3 % slower: with one wave per SIMD every
+// piece costs the wave its own issue slots either way), and a second barrier at the START of a chunk behind which chunk c + 3 is
+// requested (259-265 vs 250-258 us at 32 trajectories, 53 vs 50 us at 4: the stream is not DMA-latency bound).
 constexpr int PF = PD_PAIR_PF, PFN = 8;                     // weight fragments in flight (LDS latency ~ 4 x 32 MFMA clocks) / register slots: the slot of
                                                    // fragment i is i % PFN in EVERY chunk, so PFN must divide the 32 fragments of a chunk
 constexpr int CHUNK = 32768, NSLOT = 4, NFRAG = 32;
 static_assert(NFRAG % PFN == 0 && PF + 2 <= PFN && PF % 2 == 0 && PF + 4 <= 15, "fragment pipeline geometry");
 constexpr int DMA_PER_WAVE = CHUNK / 4 / 1024;     // 8 x 1 KB per wave per chunk
-// fp32 tables in LDS (float offsets) == layout of the `vecs` argument
-constexpr int T_LN1G = 0, T_LN1B = 256, T_BP = 512, T_LN2G = 768, T_LN2B = 1024, T_B2 = 1280, T_B1 = 1536, T_RB = 2560, T_FLOATS = 3584;
-constexpr int RING_OFF = 16384;
-constexpr int LDS_BYTES = RING_OFF + NSLOT * CHUNK;   // 147456
-constexpr int CH_ALL = 48;                         // chunks per tile: 4 heads x (q, k, v, proj) + 16 x (W1_j, W2_j)
+// geometry of one block width: CW = units / 256
+template <int CW>
+struct G {
+  static constexpr int C = 256 * CW, HID = 1024 * CW, HD = C / HEADS;
+  static constexpr int CT = C / 16;                // 16-column tiles of a row
+  static constexpr int KS = C / 32;                // k-steps of 32 over the units
+  static constexpr int DT = HD / 16;               // 16-feature tiles of a head
+  static constexpr int HS = HD / 32;               // k-steps over a head
+  static constexpr int NQ = CW * CW;               // chunks of one head's Wq / Wk / Wv ([HD x C]) and of its proj slice ([C x HD])
+  static constexpr int NW = CW;                    // chunks of W1_j ([64 x C]) and of W2_j ([C x 64])
+  static constexpr int NJ = HID / 64;
+  // fp32 tables in LDS (float offsets) == layout of the `vecs` argument
+  static constexpr int T_LN1G = 0, T_LN1B = C, T_BP = 2 * C, T_LN2G = 3 * C, T_LN2B = 4 * C, T_B2 = 5 * C, T_B1 = 6 * C, T_RB = 6 * C + HID,
+                       T_FLOATS = T_RB + HEADS * 256;
+  static constexpr int RING_OFF = (T_FLOATS * 4 + 8191) / 8192 * 8192;
+  static constexpr int LDS_BYTES = RING_OFF + NSLOT * CHUNK;       // 147456 / 155648
+  static constexpr int CH_ALL = HEADS * 4 * NQ + 2 * NJ * NW;      // chunks per tile: 48 / 192
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
 }  // namespace pairk
 
 struct pd_pair_args_k {
@@ -66,6 +78,7 @@ struct pd_pair_args_k {
   const float* vecs;          // T_FLOATS floats
   const int32_t* tok_index;   // [nc][vol] or null with aff_on
   int B, ntok, nc, vol;
+  int pack;                   // cuboids per 16-slot group: 2 when 2 vol <= 16
   float scale, eps1, eps2;
   int aff_on, aff_ninner, aff_outer, aff_inner, aff_slot;
   int ntiles;
@@ -125,10 +138,15 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
                                       // property of the chunk pair, the four waves meet at every chunk's barrier)
 #endif
 
-template <int NC>
+template <int NC, int CW>
 __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace pairk;
+  using GG = G<CW>;
+  constexpr int C = GG::C, CT = GG::CT, KS = GG::KS, DT = GG::DT, HS = GG::HS, NQ = GG::NQ, NW = GG::NW, NJ = GG::NJ;
+  constexpr int T_LN1G = GG::T_LN1G, T_LN1B = GG::T_LN1B, T_BP = GG::T_BP, T_LN2G = GG::T_LN2G, T_LN2B = GG::T_LN2B, T_B2 = GG::T_B2,
+                T_B1 = GG::T_B1, T_RB = GG::T_RB, T_FLOATS = GG::T_FLOATS, RING_OFF = GG::RING_OFF, CH_ALL = GG::CH_ALL;
+  static_assert(NC * CW <= 2, "a wave holds 32 x 256 or 16 x 512 fp32 row values");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,16 +160,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // ---- weight stream: chunk ids 0 .. CH_ALL-1 cyclically, chunk number n -> ring slot n & 3 ----
   const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, p.wbytes, 0x00020000);
   // Every wave copies a quarter of every chunk, as 8 pieces of 1 KB (one DMA instruction each); piece k of a wave belongs to chunk
-  // k / 8.  Default (PD_PAIR_DMA_SPREAD 0): the prologue issues chunks 0..2, then the 8 pieces of chunk c + 3 go out in one burst
-  // behind the mid-chunk barrier of chunk c (everybody is past chunk c - 1, whose slot this is).  PD_PAIR_DMA_SPREAD 1 issues ONE
-  // piece every second fragment group instead (prologue: chunks 0, 1 and half of 2; groups 0..6 of chunk c: second half of chunk c + 2,
-  // groups 8..14: first half of chunk c + 3), the "even interleave" of the 256^2 GEMM kernel -- measured here 3 % SLOWER (275-279 vs
-  // 264-270 us at 32 trajectories, two rounds): with one wave per SIMD every piece costs the wave its own issue slots either way.
+  // k / 8.  The prologue issues chunks 0..2, then the 8 pieces of chunk c + 3 go out in one burst behind the mid-chunk barrier of
+  // chunk c (everybody is past chunk c - 1, whose slot this is).
   int n_piece = 0, kid = 0;                        // pieces issued by this wave; stream id of the chunk the next piece belongs to
   const uint32_t dma_voff = (uint32_t)lane * 16u;
   auto issue_piece = [&]() {
 #if PD_PAIR_ABLATE & 1
-    if (n_piece >= (PD_PAIR_DMA_SPREAD ? 20 : 24)) { ++n_piece; return; }
+    if (n_piece >= 24) { ++n_piece; return; }
 #endif
     const int sub = n_piece & (DMA_PER_WAVE - 1);
     char* d = smem + RING_OFF + ((n_piece >> 3) & (NSLOT - 1)) * CHUNK + wave * (DMA_PER_WAVE * 1024) + sub * 1024;
@@ -161,7 +176,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     if (sub == DMA_PER_WAVE - 1) kid = (kid + 1 == CH_ALL) ? 0 : kid + 1;
   };
 #pragma unroll
-  for (int i = 0; i < (PD_PAIR_DMA_SPREAD ? 20 : 24); ++i) issue_piece();
+  for (int i = 0; i < 24; ++i) issue_piece();
 
   const uint32_t vbase = (uint32_t)(uintptr_t)(smem + RING_OFF) + (uint32_t)lane * 16u;   // fragment reads: lane-linear 16 B
   const uint32_t vtab = (uint32_t)(uintptr_t)smem + (uint32_t)g * 16u;                     // fp32 tables: 4 floats at column 4 g
@@ -176,15 +191,15 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   int cc = 0;                                       // chunks consumed by this workgroup
   bf16x8 w[PFN] = {};                               // fragment pipeline (runs on across chunks, tiles and phases)
 
-  // One chunk = 32 fragments = 16 groups of two.  Per group: two fragment reads three groups ahead, ONE counted wait, the four MFMAs
-  // of the group's two fragments (BODY_STMT, once per fragment: `i`, `wf`) and HOOK_STMT (`gi`): independent work for their shadow
+  // One chunk = 32 fragments = 16 groups of two.  Per group: two fragment reads three groups ahead, ONE counted wait, the MFMAs of the
+  // group's two fragments (BODY_STMT, once per fragment: `i`, `wf`) and HOOK_STMT (`gi`): independent work for their shadow
   // (GELU stages, ONE row load or store).
-  // In the middle of chunk cc (group 8): chunk cc+1 has landed for everybody and everybody is past chunk cc-1, whose slot takes chunk
-  // cc+3.  The last piece of chunk cc+1 was issued just before the previous mid-chunk sync, so VMC = the VMEM instructions issued
-  // since then that may stay in flight: 8 DMA pieces (4 of chunk cc+2 in the second half of chunk cc-1, 4 in the first half of
-  // chunk cc) plus the row loads / stores the hooks issued in those two half chunks (a fixed schedule: the constants are derived at
-  // the tile loop).  Loads and stores retire in order (one vmcnt queue on gfx9-class hardware), and every hook instruction is
-  // issued unconditionally.
+  // In the middle of chunk cc (group 8, SYNC_STMT): chunk cc+1 has landed for everybody and everybody is past chunk cc-1, whose slot
+  // takes chunk cc+3.  The last piece of chunk cc+1 was issued just before the previous mid-chunk sync, so the wait is vmcnt(VMC) with
+  // VMC = the VMEM instructions issued since then that may stay in flight: the 8 DMA pieces of chunk cc+2 plus the row loads / stores
+  // the hooks issued in the second half of chunk cc-1 and the first half of chunk cc (a fixed schedule: the constants are derived at
+  // the tile loop).  Loads and stores retire in order (one vmcnt queue on gfx9-class hardware).  A VMC SMALLER than the true count is
+  // merely a stronger wait; a larger one would let a piece of chunk cc+1 stay in flight.
   // EXTRA_STMT: NEXTRA other LDS reads issued at the start; they have landed at group PF / 2, where LANDED_STMT re-defines their
   // destinations (PK_LANDED).
   // RULE for every asynchronous (inline-asm) LDS read in this kernel: its destination must not live long BEFORE its wait -- the
@@ -193,8 +208,8 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // (PK_LANDED, no instruction) right after the wait that covers them and only that new value lives on; and wherever more than a few
   // instructions separate two chunk loops the fragments in flight are drained first (PK_DRAIN).  scripts/check_async_lds.py replays
   // the LDS queue over the generated ISA and fails the build if any instruction touches a destination that is still in flight.
-#define PK_VMC(BURST, SPREAD) (PD_PAIR_DMA_SPREAD ? (SPREAD) : (BURST))
-#define PK_VMC0 (PD_PAIR_DMA_EARLY ? 16 : 8)   /* chunks without hook traffic around them: the DMA pieces younger than chunk c + 1 */
+#define PK_VMC0 8   /* chunks without hook traffic around them: the DMA pieces younger than chunk c + 1 */
+#define PK_SYNC(VMC) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VMC) : "memory")
 #define PK_RD_ON (!(PD_PAIR_ABLATE & 2))
 #define PK_MFMA_ON (!(PD_PAIR_ABLATE & 4))
 #define PK_RD(i_)                                                                                 \
@@ -202,21 +217,16 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     if ((i_) < NFRAG) PK_WLD(w[(i_) % PFN], va_, (i_) * 1024);                                     \
     else PK_WLD(w[(i_) % PFN], vn_, ((i_) - NFRAG) * 1024);                                        \
   }
-#define PK_CHUNK(VMC, NEXTRA, EXTRA_STMT, LANDED_STMT, BODY_STMT, HOOK_STMT)                      \
+#define PK_CHUNK(SYNC_STMT, NEXTRA, EXTRA_STMT, LANDED_STMT, BODY_STMT, HOOK_STMT)                \
   {                                                                                               \
     const uint32_t va_ = vbase + (uint32_t)(cc & (NSLOT - 1)) * CHUNK;                            \
     const uint32_t vn_ = vbase + (uint32_t)((cc + 1) & (NSLOT - 1)) * CHUNK;                      \
     _Pragma("unroll") for (int gi = 0; gi < NFRAG / 2; ++gi) {                                    \
       if (gi == 0) { EXTRA_STMT; }                                                                \
-      if (PD_PAIR_DMA_EARLY && gi == 0) {                                                         \
-        asm volatile("s_barrier" ::: "memory");                                                   \
+      if (gi == NFRAG / 4) {                                                                      \
+        SYNC_STMT;                                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < DMA_PER_WAVE; ++i_) issue_piece();                \
       }                                                                                           \
-      if (gi == NFRAG / 4) {                                                                      \
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VMC) : "memory");                   \
-        if (!PD_PAIR_DMA_SPREAD && !PD_PAIR_DMA_EARLY) { _Pragma("unroll") for (int i_ = 0; i_ < DMA_PER_WAVE; ++i_) issue_piece(); } \
-      }                                                                                           \
-      if (PD_PAIR_DMA_SPREAD && (gi & 1) == 0) issue_piece();                                     \
       PK_RD(2 * gi + PF);                                                                         \
       PK_RD(2 * gi + PF + 1);                                                                     \
       asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[(2 * gi) % PFN]), "+v"(w[(2 * gi + 1) % PFN]) \
@@ -230,20 +240,32 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     }                                                                                             \
     ++cc;                                                                                         \
   }
-#define PK_MFMA_T(ACC, AF) /* transposed product on a [64 features x 256 k] chunk: fragment i = 4 ks + dt */ \
-  if (PK_MFMA_ON) {                                                                                        \
-    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                      \
-      ACC[c_][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[c_][i >> 2], ACC[c_][i & 3], 0, 0, 0); \
+  // fragment i of a chunk of ...
+#define PK_MFMA_T(ACC, AF, SUB) /* ... a head's Wq / Wk ([HD x C], transposed product): feature tile i % DT, k-step SUB * 32 / DT + i / DT */ \
+  if (PK_MFMA_ON) {                                                                                                  \
+    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
+      ACC[c_][i % DT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[c_][(SUB) * (32 / DT) + i / DT], ACC[c_][i % DT], 0, 0, 0); \
   }
-#define PK_MFMA_OUT(OF) /* x^T += W[256 outputs x 64 k] act^T: fragment i = 16 st + nt */                      \
-  if (PK_MFMA_ON) {                                                                                            \
-    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                          \
-      acc[c_][i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[c_][i >> 4], acc[c_][i & 15], 0, 0, 0); \
+#define PK_MFMA_V(ACC, AF, SUB) /* ... a head's Wv (plain product: lane = feature, 4 consecutive tokens) */             \
+  if (PK_MFMA_ON) {                                                                                                  \
+    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
+      ACC[c_][i % DT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[c_][(SUB) * (32 / DT) + i / DT], wf, ACC[c_][i % DT], 0, 0, 0); \
+  }
+#define PK_MFMA_H(ACC, AF, SUB) /* ... W1_j ([64 x C]): hidden tile i & 3, k-step 8 SUB + i / 4 */                      \
+  if (PK_MFMA_ON) {                                                                                                  \
+    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
+      ACC[c_][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[c_][(SUB) * 8 + (i >> 2)], ACC[c_][i & 3], 0, 0, 0); \
+  }
+#define PK_MFMA_OUT(OF, SUB) /* ... a [C outputs x k] slice of Wproj / W2 (x^T += W act^T): column tile i % CT, k-step SUB * 32 / CT + i / CT */ \
+  if (PK_MFMA_ON) {                                                                                                  \
+    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
+      acc[c_][i % CT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[c_][(SUB) * (32 / CT) + i / CT], acc[c_][i % CT], 0, 0, 0); \
   }
 
-  // rows of a tile's cuboids for this lane = (slot q, column group g), as byte offsets into x / out.  An invalid slot gets an offset
-  // beyond the buffers: its loads return 0 and its stores are dropped by the descriptor's bounds check -- ALWAYS exactly 32 load and
-  // 32 store instructions per tile, no lane ever branches.
+  // rows of a tile's 16-slot groups for this lane = (slot q, column group g), as byte offsets into x / out.  A group holds ONE cuboid,
+  // or TWO of volume <= 8 (p.pack == 2: slots [0, vol) and [vol, 2 vol); the relative-position table keeps their scores apart).  An
+  // invalid slot gets an offset beyond the buffers: its loads return 0 and its stores are dropped by the descriptor's bounds check --
+  // ALWAYS exactly NC * CT load and store instructions per tile, no lane ever branches.
   const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
   const auto rO = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.xbytes, 0x00020000);
   constexpr uint32_t OOB = 0xFFFFF000u;
@@ -253,14 +275,15 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     uint32_t l2;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
     const int q = (int)(l2 & 15u), g = (int)(l2 >> 4);
+    const int sub = q >= p.vol ? 1 : 0, slot = q - sub * p.vol;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int64_t gc = (int64_t)tile * (4 * NC) + wave * NC + c;
+      const int64_t gc = ((int64_t)tile * (4 * NC) + wave * NC + c) * p.pack + sub;
       int row = -1;
-      if (gc < (int64_t)p.B * p.nc && q < p.vol) {
+      if (gc < (int64_t)p.B * p.nc && sub < p.pack && slot < p.vol) {
         const int b = (int)(gc / p.nc), cu = (int)(gc - (int64_t)b * p.nc);
-        const int tok = p.aff_on ? (cu / p.aff_ninner) * p.aff_outer + (cu % p.aff_ninner) * p.aff_inner + q * p.aff_slot
-                                 : p.tok_index[cu * p.vol + q];
+        const int tok = p.aff_on ? (cu / p.aff_ninner) * p.aff_outer + (cu % p.aff_ninner) * p.aff_inner + slot * p.aff_slot
+                                 : p.tok_index[cu * p.vol + slot];
         if (tok >= 0 && tok < p.ntok) row = b * p.ntok + tok;
       }
       off[c] = row < 0 ? OOB : (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)g * 16u;
@@ -275,12 +298,18 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #define PK_ROW_LD(OFF, NT) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (OFF) + (uint32_t)((NT) * 64), 0, PD_PAIR_AUX_LD))
 #define PK_ROW_ST(V, OFF, NT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), rO, (OFF) + (uint32_t)((NT) * 64), 0, PD_PAIR_AUX_ST)
 #define PK_HOOK_IO (!(PD_PAIR_ABLATE & 16))
+  // hook of fragment group gi in the TP-th chunk of a tile: row instruction 16 TP + gi of the NC * CT stores of the previous tile's rows
+#define PK_ST_HOOK(TP)                                                                                                     \
+  { const int fi_ = 16 * (TP) + gi; if (PK_HOOK_IO && fi_ < NC * CT) PK_ROW_ST(acc[fi_ / CT][fi_ % CT], ooff[fi_ / CT], fi_ % CT); }
+  // ... in the chunk EP chunks before the tile's last (EP = 1, 0): row instruction 16 (1 - EP) + gi of the NC * CT loads of the next tile's rows
+#define PK_LD_HOOK(EP)                                                                                                     \
+  { const int fi_ = 16 * (1 - (EP)) + gi; if (PK_HOOK_IO && fi_ < NC * CT) xn[fi_ / CT][fi_ % CT] = PK_ROW_LD(noff[fi_ / CT], fi_ % CT); }
 
   // acc: the rows in flight (x -> x + attn -> x + attn + ffn), lane = (token q, columns 16 nt + 4 g .. +3): the MFMA C layout of every
   // transposed product.  xn: the rows of the NEXT tile.  The tile boundary is software pipelined: xn is requested one row-instruction
   // per fragment group during the last two chunks of a tile, the finished rows (acc) leave one row-instruction per group during the
-  // first two chunks of the next tile (whose LayerNorm and q / k / v products read xn), and only then acc <- xn + b_proj.
-  f32x4 acc[NC][16], xn[NC][16];
+  // first two chunks of the next tile (whose LayerNorm and q products read xn), and only then acc <- xn + b_proj.
+  f32x4 acc[NC][CT], xn[NC][CT];
   uint32_t roff[NC], noff[NC], ooff[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) roff[c] = ooff[c] = OOB;
@@ -288,11 +317,11 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int nt = 0; nt < 16; ++nt) {
+    for (int nt = 0; nt < CT; ++nt) {
       xn[c][nt] = PK_ROW_LD(noff[c], nt);
       acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};       // (the first tile has no predecessor: its hook stores go to OOB offsets)
     }
-  // chunks 0, 1 and half of 2 landed (the row loads above are younger: this wait covers both), visible to every wave; fragment prologue
+  // chunks 0..2 landed (the row loads above are younger: this wait covers both), visible to every wave; fragment prologue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -311,24 +340,24 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #if PD_PAIR_DEBUG
     auto dump4 = [&](int stage, int c, const f32x4& a, const f32x4& b, const f32x4& cc4, const f32x4& d) {
       if (p.dbg_buf && p.dbg_stage == stage && roff[c] != OOB) {
-        float* o = p.dbg_buf + roff[c] / 4;
+        float* o = p.dbg_buf + roff[c] / (4 * CW);
         *(f32x4*)(o) = a; *(f32x4*)(o + 16) = b; *(f32x4*)(o + 32) = cc4; *(f32x4*)(o + 48) = d;
       }
     };
 #endif
-    bf16x8 af[NC][8];                                // LayerNorm output as B-operand fragments: [cuboid][k-step of 32]
-    // LayerNorm over the 256 columns of a row (64 in this lane, the rest in lanes q + 16 g'), -> af
-    auto layer_norm = [&](const f32x4 (&src)[NC][16], int t_gamma, int t_beta, float eps) {
+    bf16x8 af[NC][KS];                               // LayerNorm output as B-operand fragments: [group][k-step of 32]
+    // LayerNorm over the C columns of a row (C / 4 in this lane, the rest in lanes q + 16 g'), -> af
+    auto layer_norm = [&](const f32x4 (&src)[NC][CT], int t_gamma, int t_beta, float eps) {
       float mean[NC], rstd[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         float s = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt) s += (src[c][nt][0] + src[c][nt][1]) + (src[c][nt][2] + src[c][nt][3]);
+        for (int nt = 0; nt < CT; ++nt) s += (src[c][nt][0] + src[c][nt][1]) + (src[c][nt][2] + src[c][nt][3]);
         mean[c] = pk_rows4_sum(s) * (1.0f / C);
         float v = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt) {
+        for (int nt = 0; nt < CT; ++nt) {
           const float d0 = src[c][nt][0] - mean[c], d1 = src[c][nt][1] - mean[c], d2 = src[c][nt][2] - mean[c], d3 = src[c][nt][3] - mean[c];
           v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
@@ -344,8 +373,8 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       };
       ld_gb(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) {
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
           ld_gb(ks + 1, (ks + 1) & 1);
           asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(gb[ks & 1][0]), "+v"(gb[ks & 1][1]), "+v"(gb[ks & 1][2]), "+v"(gb[ks & 1][3]));
         } else {
@@ -364,68 +393,87 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       }
     };
     // acc[c][nt] = src[c][nt] + table[16 nt + 4 g .. +3]  (proj / FFN-2 bias: the accumulator starts from residual + bias)
-    auto add_vec = [&](const f32x4 (&src)[NC][16], int t_off) {
+    auto add_vec = [&](const f32x4 (&src)[NC][CT], int t_off) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int blk = 0; blk < CT / 8; ++blk) {
         f32x4 bv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) PK_LDS_F4(bv[i], vtab, (t_off + 16 * (half * 8 + i)) * 4);
+        for (int i = 0; i < 8; ++i) PK_LDS_F4(bv[i], vtab, (t_off + 16 * (blk * 8 + i)) * 4);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int c = 0; c < NC; ++c) acc[c][half * 8 + i] = src[c][half * 8 + i] + bv[i];
+          for (int c = 0; c < NC; ++c) acc[c][blk * 8 + i] = src[c][blk * 8 + i] + bv[i];
       }
     };
 
     // ================= attention: x += proj(attn(LN1(x))) =================
+    if constexpr (CW == 2) {
+#pragma unroll
+      for (int nt = 0; nt < CT; ++nt)
+        if (PK_HOOK_IO) PK_ROW_ST(acc[0][nt], ooff[0], nt);
+    }
     layer_norm(xn, T_LN1G, T_LN1B, p.eps1);
+    if constexpr (CW == 2) add_vec(xn, T_BP);
     PK_TRACE();   // LN1 done
-    // VMEM schedule around a tile boundary (chunk c = consumption order; hooks issue one row instruction per group):
-    //   W2_14 (c46): 16 loads, W2_15 (c47): 16 loads, Q_0 (c48): 16 stores, K_0 (c49): 16 stores; everything else none.
-    //   pieces in one burst behind the mid-chunk barrier (PD_PAIR_DMA_SPREAD 0): chunk c+1's pieces were issued at the sync of chunk c-2,
-    //     VMC(c) = 8 + hook instructions issued in [second half of c-2, first half of c]:
-    //     c46: 8 + 8 = 16;  c47: 8 + 16 + 8 = 32;  c48: 8 + 8 + 16 + 8 = 40;  c49: 40;  c50 (V_0): 8 + 8 + 16 = 32;  c51 (P_0): 8 + 8 = 16.
-    //   one piece every second group (PD_PAIR_DMA_SPREAD 1): VMC(c) = 8 + hook instructions issued in [second half of c-1, first half of c]:
-    //     c46: 8 + 0 + 8 = 16;  c47: 8 + 8 + 8 = 24;  c48: 8 + 8 + 8 = 24;  c49: 24;  c50 (V_0): 8 + 8 + 0 = 16;  c51 (P_0): 8.
-    //   with ONE cuboid per wave (NC = 1) only W2_14 carries loads (16) and Q_0 stores (16): c46 16, c47 8 + 16 = 24, c48 8 + 8 + 8 = 24,
-    //   c49 8 + 16 = 24, c50 8 + 8 = 16, c51 8  (burst form; the spread form is built for NC = 2 only).
-    static_assert(NC == 2 || !PD_PAIR_DMA_SPREAD, "the one-piece-per-group DMA schedule is derived for two cuboids per wave");
-    //   PD_PAIR_DMA_EARLY: chunk c + 1's pieces go out at the START of chunk c - 2, so VMC(c) = 16 (chunks c + 2, c + 3) + the hook instructions of
-    //   chunks c - 2, c - 1 and the first half of c:  NC = 2: c46 24, c47 40, c48 56, c49 56, c50 48, c51 32;  NC = 1: 24, 32, 40, 32, 32, 16.
-    constexpr int VMC_W2_14 = PD_PAIR_DMA_EARLY ? 24 : 16;
-    constexpr int VMC_W2_15 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 40 : 32) : (NC == 2 ? PK_VMC(32, 24) : 24);
-    constexpr int VMC_Q0 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 56 : 40) : (NC == 2 ? PK_VMC(40, 24) : 24);
-    constexpr int VMC_K0 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 56 : 32) : (NC == 2 ? PK_VMC(40, 24) : 24);
-    constexpr int VMC_V0 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 48 : 32) : (NC == 2 ? PK_VMC(32, 16) : 16);
-    constexpr int VMC_P0 = PD_PAIR_DMA_EARLY ? (NC == 2 ? 32 : 16) : (NC == 2 ? PK_VMC(16, 8) : 8);
-    static_assert(!(PD_PAIR_DMA_EARLY && PD_PAIR_DMA_SPREAD), "one DMA schedule at a time");
-    auto head = [&](auto first_tag, int h) __attribute__((always_inline)) {
-      constexpr bool FIRST = decltype(first_tag)::value;
+    // VMEM schedule around a tile boundary (hooks issue one row instruction per fragment group).  With 32 row instructions per tile
+    // (NC * CW == 2): the two LAST chunks of a tile carry 16 loads each, the two FIRST chunks of the next one 16 stores each, nothing
+    // anywhere else.  Chunk c + 1's pieces were issued at the sync of chunk c - 2, so
+    //     VMC(c) = 8 (pieces of chunk c + 2) + the hook instructions issued in [second half of c - 2, first half of c]:
+    //     second to last: 8 + 8 = 16;  last: 8 + 16 + 8 = 32;  first: 8 + 8 + 16 + 8 = 40;  second: 40;  third: 8 + 8 + 16 = 32;  fourth: 8 + 8 = 16.
+    // With 16 row instructions per tile (NC = CW = 1) only the second to last chunk carries loads and only the first one stores:
+    //     second to last 16, last 8 + 16 = 24, first 8 + 8 + 8 = 24, second 8 + 16 = 24, third 8 + 8 = 16, fourth 8.
+    // At level 0 the first four chunks of a tile are Q_0, K_0, V_0, P_0 and the last two W2_14, W2_15; at level 1 (four chunks per head
+    // matrix, two per W1_j / W2_j) they are the four chunks of Q_0 and the two of W2_31.
+    // At level 1 (CW = 2: four chunks per head matrix, two per W1_j / W2_j) the last two chunks (of W2_31) carry the 32 loads in the same
+    // way, but the 32 stores of the finished rows are issued in ONE burst in front of the first LayerNorm (which is amortised over four
+    // times the MFMA work per row there), and acc <- xn + b_proj follows the LayerNorm directly: acc and xn are never both alive across
+    // the heads, so ONE instantiation serves all four (head 0 differs in two wait counts only, a scalar branch):
+    //     first chunk: 8 + 8 + 16 + 32 = 64 (-> 63, the field's maximum: a stronger wait);  second: 8 + 8 + 32 = 48;  from the third on: 8.
+    constexpr bool IO32 = NC * CW == 2;
+    constexpr int VMC_E1 = 16, VMC_E0 = IO32 ? 32 : 24;
+    constexpr int VMC_T0 = CW == 2 ? 63 : IO32 ? 40 : 24, VMC_T1 = CW == 2 ? 48 : IO32 ? 40 : 24, VMC_T2 = CW == 2 ? 8 : IO32 ? 32 : 16,
+                  VMC_T3 = CW == 2 ? 8 : IO32 ? 16 : 8;
+    // FM: 1 = the tile's first head at compile time (level 0: head 0 is its own instantiation, with the row stores in its hooks),
+    // 0 = not the first, 2 = level 1: the wait counts of head 0 chosen at run time (h is uniform: a scalar branch)
+#define PK_SYNC_T(TP)                                                                                                       \
+  {                                                                                                                         \
+    constexpr int vf_ = (TP) == 0 ? VMC_T0 : (TP) == 1 ? VMC_T1 : (TP) == 2 ? VMC_T2 : (TP) == 3 ? VMC_T3 : PK_VMC0;        \
+    if constexpr (FM == 0 || vf_ == PK_VMC0) PK_SYNC(PK_VMC0);                                                              \
+    else if constexpr (FM == 1) PK_SYNC(vf_);                                                                               \
+    else { if (h == 0) PK_SYNC(vf_); else PK_SYNC(PK_VMC0); }                                                               \
+  }
+#define PK_ST_HOOK_T(TP) { if constexpr (FM == 1 && 16 * (TP) < NC * CT) PK_ST_HOOK(TP) }
+    auto head = [&](auto fm_tag, int h) __attribute__((always_inline)) {
+      constexpr int FM = decltype(fm_tag)::value;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 t[NC][4];
-      bf16x8 qf[NC][2], kf[NC][2];
-      f32x4 rb;                                     // relative-position bias of (head h, query q, keys 4 g .. 4 g + 3)
+      f32x4 t[NC][DT];
+      bf16x8 qf[NC][HS], kf[NC][HS];
+      f32x4 rb;                                     // relative-position bias of (head h, query slot q, key slots 4 g .. 4 g + 3); -inf = no such pair
       const uint32_t vrb_h = vrb + (uint32_t)h * 1024u;
-      // ---------------- q^T = Wq_h a^T  (head 0: the previous tile's rows of cuboid 0 leave in its shadow) ----------------
+      // ---------------- q^T = Wq_h a^T  (first head: the previous tile's rows leave in its shadow) ----------------
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
-      PK_CHUNK(FIRST ? VMC_Q0 : PK_VMC0, 0, (void)0, (void)0, PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO) PK_ROW_ST(acc[0][gi], ooff[0], gi); })
+        for (int dt = 0; dt < DT; ++dt) t[c][dt] = z4;
+#define PK_Q_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(SUB), 0, (void)0, (void)0, PK_MFMA_T(t, af, SUB), PK_ST_HOOK_T(SUB))
+      PK_Q_CHUNK(0) PK_Q_CHUNK(1) PK_Q_CHUNK(2) PK_Q_CHUNK(3)
 #if PD_PAIR_DEBUG
       if (h == 0) { for (int c = 0; c < NC; ++c) dump4(1, c, t[c][0], t[c][1], t[c][2], t[c][3]); }
 #endif
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        qf[c][0] = pk_pack8(t[c][0], t[c][1]);
-        qf[c][1] = pk_pack8(t[c][2], t[c][3]);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
+        for (int s = 0; s < HS; ++s) qf[c][s] = pk_pack8(t[c][2 * s], t[c][2 * s + 1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) t[c][dt] = z4;
       }
       PK_TRACE();   // q done
-      // ---------------- k^T = Wk_h a^T  (head 0: ... and those of cuboid 1) ----------------
-      PK_CHUNK(FIRST ? VMC_K0 : PK_VMC0, 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af), { if constexpr (FIRST && PK_HOOK_IO && NC == 2) PK_ROW_ST(acc[NC - 1][gi], ooff[NC - 1], gi); })
+      // ---------------- k^T = Wk_h a^T ----------------
+#define PK_K_CHUNK(SUB)                                                                                                      \
+  if constexpr ((SUB) == 0) PK_CHUNK(PK_SYNC_T(NQ + (SUB)), 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af, SUB), PK_ST_HOOK_T(NQ + (SUB))) \
+  else if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_T(t, af, SUB), PK_ST_HOOK_T(NQ + (SUB)))
+      PK_K_CHUNK(0) PK_K_CHUNK(1) PK_K_CHUNK(2) PK_K_CHUNK(3)
       PK_DRAIN();
       PK_TRACE();   // k done
       // ---------------- S^T = K Q^T, softmax over the keys (registers + two row swaps) ----------------
@@ -435,17 +483,17 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #if PD_PAIR_DEBUG
         if (h == 0) dump4(2, c, t[c][0], t[c][1], t[c][2], t[c][3]);
 #endif
-        kf[c][0] = pk_pack8(t[c][0], t[c][1]);
-        kf[c][1] = pk_pack8(t[c][2], t[c][3]);
-        f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][0], qf[c][0], z4, 0, 0, 0);
-        s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][1], qf[c][1], s4, 0, 0, 0);
+        f32x4 s4 = z4;
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          kf[c][s] = pk_pack8(t[c][2 * s], t[c][2 * s + 1]);
+          s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][s], qf[c][s], s4, 0, 0, 0);
+        }
         float sc[4], mx = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = -INFINITY;
-          if (4 * g + r < p.vol && q < p.vol) v = s4[r] * p.scale + rb[r];
-          sc[r] = v;
-          mx = fmaxf(mx, v);
+          sc[r] = s4[r] * p.scale + rb[r];          // -inf: a padded slot, or a key of the group's other cuboid
+          mx = fmaxf(mx, sc[r]);
         }
 #if PD_PAIR_DEBUG
         if (h == 0) dump4(3, c, s4, f32x4{sc[0], sc[1], sc[2], sc[3]}, rb, z4);
@@ -464,39 +512,42 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
         if (h == 0) dump4(4, c, f32x4{sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv}, f32x4{mx, sum, inv, 0.f}, z4, z4);
 #endif
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) t[c][dt] = z4;
+        for (int dt = 0; dt < DT; ++dt) t[c][dt] = z4;
       }
       PK_TRACE();   // softmax done
       // ---------------- v = a Wv_h^T (plain product: lane = feature, 4 consecutive tokens -> the A operand of O^T = V^T P^T) -------
-      PK_CHUNK(FIRST ? VMC_V0 : PK_VMC0, 0, (void)0, (void)0, {
-        if (PK_MFMA_ON) {
-          _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) t[c_][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c_][i >> 2], wf, t[c_][i & 3], 0, 0, 0);
-        }
-      }, (void)0)
+#define PK_V_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(2 * NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_V(t, af, SUB), (void)0)
+      PK_V_CHUNK(0) PK_V_CHUNK(1) PK_V_CHUNK(2) PK_V_CHUNK(3)
       PK_DRAIN();
-      bf16x8 of[NC][2];
+      bf16x8 of[NC][HS];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        f32x4 o[4];
+        f32x4 o[DT];
 #if PD_PAIR_DEBUG
         if (h == 0) dump4(5, c, t[c][0], t[c][1], t[c][2], t[c][3]);
 #endif
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk_pack4(t[c][dt]), pf[c], z4, 0, 0, 0);
+        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk_pack4(t[c][dt]), pf[c], z4, 0, 0, 0);
 #if PD_PAIR_DEBUG
         if (h == 0) dump4(6, c, o[0], o[1], o[2], o[3]);
 #endif
-        of[c][0] = pk_pack8(o[0], o[1]);
-        of[c][1] = pk_pack8(o[2], o[3]);
+#pragma unroll
+        for (int s = 0; s < HS; ++s) of[c][s] = pk_pack8(o[2 * s], o[2 * s + 1]);
       }
-      if constexpr (FIRST) add_vec(xn, T_BP);       // the finished rows have left: acc <- x + b_proj, the accumulator of every head's proj
+      if constexpr (FM == 1) add_vec(xn, T_BP);   // the finished rows have left: acc <- x + b_proj, the accumulator of every head's proj
       PK_TRACE();   // v + PV done
       // ---------------- x^T += Wp[:, head h] O_h^T ----------------
-      PK_CHUNK(FIRST ? VMC_P0 : PK_VMC0, 0, (void)0, (void)0, PK_MFMA_OUT(of), (void)0)
+#define PK_P_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(3 * NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_OUT(of, SUB), (void)0)
+      PK_P_CHUNK(0) PK_P_CHUNK(1) PK_P_CHUNK(2) PK_P_CHUNK(3)
     };
-    head(std::true_type{}, 0);
+    if constexpr (CW == 1) {
+      head(std::integral_constant<int, 1>{}, 0);
 #pragma unroll 1
-    for (int h = 1; h < HEADS; ++h) head(std::false_type{}, h);
+      for (int h = 1; h < HEADS; ++h) head(std::integral_constant<int, 0>{}, h);
+    } else {
+#pragma unroll 1
+      for (int h = 0; h < HEADS; ++h) head(std::integral_constant<int, 2>{}, h);
+    }
     PK_DRAIN();                                     // (a LayerNorm follows)
     PK_TRACE();   // attention done
 
@@ -504,12 +555,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     layer_norm(acc, T_LN2G, T_LN2B, p.eps2);
     add_vec(acc, T_B2);
     PK_TRACE();   // LN2 done
-    // Chunk order: W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0..13, W2_14, W2_15.  gelu(h_j) has the two chunks between W1_j and W2_j to
-    // itself, as three software-pipelined stages (polynomial | exp, +1 | rcp, mul) of one value per fragment group: independent
-    // short chains beside the MFMAs instead of one 9-deep dependent chain per value (a lone wave hides no VALU latency).
+    // Order of the 64-wide hidden slices: W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0..NJ-3, W2_{NJ-2}, W2_{NJ-1} (NW chunks each).  gelu(h_j)
+    // has the chunks between W1_j and W2_j to itself, as three software-pipelined stages (polynomial | exp, +1 | rcp, mul) of one value
+    // per fragment group: independent short chains beside the MFMAs instead of one 9-deep dependent chain per value (a lone wave hides
+    // no VALU latency).
     const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4);
     f32x4 hc[NC][4], hn[NC][4], b1n[4];
-    float ga[32], gd[32];
+    float ga[16 * NC], gd[16 * NC];
 #define PK_HV(H, v) H[(v) >> 4][((v) >> 2) & 3][(v) & 3]
 #define PK_GELU_GROUP(H, VB, NPER, GI)                                                                                    \
   if (!(PD_PAIR_ABLATE & 8)) _Pragma("unroll") for (int u_ = 0; u_ < (NPER); ++u_) {                                      \
@@ -517,9 +569,21 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     if ((GI) >= 1 && (GI) < 17) { const int v_ = (VB) + ((GI) - 1) * (NPER) + u_; gd[v_] = 1.0f + __builtin_amdgcn_exp2f(ga[v_]); } \
     if ((GI) >= 2 && (GI) < 18) { const int v_ = (VB) + ((GI) - 2) * (NPER) + u_; PK_HV(H, v_) = PK_HV(H, v_) * __builtin_amdgcn_rcpf(gd[v_]); } \
   }
+#define PK_GELU_TAIL(H, VB, NPER) { PK_GELU_GROUP(H, VB, NPER, 16) PK_GELU_GROUP(H, VB, NPER, 17) }
 #define PK_B1_FETCH(ADDR) { PK_LDS_F4(b1n[0], ADDR, 0); PK_LDS_F4(b1n[1], ADDR, 64); PK_LDS_F4(b1n[2], ADDR, 128); PK_LDS_F4(b1n[3], ADDR, 192); }
 #define PK_B1_LANDED() { PK_LANDED(b1n[0]); PK_LANDED(b1n[1]); PK_LANDED(b1n[2]); PK_LANDED(b1n[3]); }
-    // b1 of chunk 0: plain wait (the fragment prologue in flight is older and simply lands first)
+#define PK_PACK_H(H)                                                                                                       \
+  _Pragma("unroll") for (int c = 0; c < NC; ++c) { hfr[c][0] = pk_pack8(H[c][0], H[c][1]); hfr[c][1] = pk_pack8(H[c][2], H[c][3]); }
+    // W1 slice into ACC (its first chunk: the next slice's b1 from BADDR, HOOK0 in the shadow); W2 slice from hfr (HOOK0 beside its first chunk)
+#define PK_W1_SLICE(ACC, BADDR, HOOK0, TAIL0)                                                                              \
+  PK_CHUNK(PK_SYNC(PK_VMC0), 4, PK_B1_FETCH(BADDR), PK_B1_LANDED(), PK_MFMA_H(ACC, af, 0), HOOK0)                            \
+  TAIL0;                                                                                                                   \
+  if constexpr (NW == 2) PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_H(ACC, af, 1), (void)0)
+#define PK_W2_SLICE(HOOK0, TAIL0)                                                                                          \
+  PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), HOOK0)                                               \
+  TAIL0;                                                                                                                   \
+  if constexpr (NW == 2) PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1), (void)0)
+    // b1 of slice 0: plain wait (the fragment prologue in flight is older and simply lands first)
     PK_B1_FETCH(vb1)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1n[0]), "+v"(b1n[1]), "+v"(b1n[2]), "+v"(b1n[3]));
 #pragma unroll
@@ -527,70 +591,58 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
       for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
     const uint32_t vb1_1 = vb1 + 256u;
-    // ---------------- h_0^T = W1_0 a^T + b1 (in its shadow: b1 of chunk 1) ----------------
-    PK_CHUNK(PK_VMC0, 4, PK_B1_FETCH(vb1_1), PK_B1_LANDED(), PK_MFMA_T(hc, af), (void)0)
+    // ---------------- h_0^T = W1_0 a^T + b1 (in its shadow: b1 of slice 1) ----------------
+    PK_W1_SLICE(hc, vb1_1, (void)0, (void)0)
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int ht = 0; ht < 4; ++ht) hn[c][ht] = b1n[ht];
     PK_TRACE();   // W1_0 done
-    // ---------------- h_1 beside the whole of gelu(h_0) (two values per group); b1 of chunk 2 ----------------
+    // ---------------- h_1 beside the whole of gelu(h_0) (NC values per group); b1 of slice 2 ----------------
     const uint32_t vb1_2 = vb1 + 512u;
-    PK_CHUNK(PK_VMC0, 4, PK_B1_FETCH(vb1_2), PK_B1_LANDED(), PK_MFMA_T(hn, af), PK_GELU_GROUP(hc, 0, NC, gi))
-    PK_GELU_GROUP(hc, 0, NC, 16)
-    PK_GELU_GROUP(hc, 0, NC, 17)
+    PK_W1_SLICE(hn, vb1_2, PK_GELU_GROUP(hc, 0, NC, gi), PK_GELU_TAIL(hc, 0, NC))
     bf16x8 hfr[NC][2];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      hfr[c][0] = pk_pack8(hc[c][0], hc[c][1]);
-      hfr[c][1] = pk_pack8(hc[c][2], hc[c][3]);
-    }
+    PK_PACK_H(hc)
     PK_TRACE();   // W1_1 done
-    // invariant: hfr = gelu(h_j) as fragments, hn = h_{j+1} (pre-activation), b1n = b1 of chunk j + 2
+    // invariant: hfr = gelu(h_j) as fragments, hn = h_{j+1} (pre-activation), b1n = b1 of slice j + 2
 #pragma unroll 1
-    for (int j = 0; j < HID / 64 - 2; ++j) {
+    for (int j = 0; j < NJ - 2; ++j) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
-      const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < HID / 64 ? j + 3 : 0) * 256u;
+      const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < NJ ? j + 3 : 0) * 256u;
       if constexpr (NC == 2 && PD_PAIR_GELU_BOTH) {
-      // x^T += W2[:, chunk j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (cuboid 0)
-      PK_CHUNK(PK_VMC0, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), PK_GELU_GROUP(hn, 0, 1, gi))
-      PK_GELU_GROUP(hn, 0, 1, 16)
-      PK_GELU_GROUP(hn, 0, 1, 17)
-      // h_{j+2}^T = W1_{j+2} a^T + b1   beside the second half of gelu(h_{j+1}); b1 of chunk j + 3
-      PK_CHUNK(PK_VMC0, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 16, 1, gi))
-      PK_GELU_GROUP(hn, 16, 1, 16)
-      PK_GELU_GROUP(hn, 16, 1, 17)
+        // x^T += W2[:, slice j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (group 0)
+        PK_W2_SLICE(PK_GELU_GROUP(hn, 0, 1, gi), PK_GELU_TAIL(hn, 0, 1))
+        // h_{j+2}^T = W1_{j+2} a^T + b1   beside the second half of gelu(h_{j+1}); b1 of slice j + 3
+        PK_W1_SLICE(hc, vb1n, PK_GELU_GROUP(hn, 16, 1, gi), PK_GELU_TAIL(hn, 16, 1))
       } else {
-      // x^T += W2[:, chunk j] gelu(h_j)^T
-      PK_CHUNK(PK_VMC0, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), (void)0)
-      // h_{j+2}^T = W1_{j+2} a^T + b1   beside the whole of gelu(h_{j+1}) (two values per group); b1 of chunk j + 3.
-      PK_CHUNK(PK_VMC0, 4, PK_B1_FETCH(vb1n), PK_B1_LANDED(), PK_MFMA_T(hc, af), PK_GELU_GROUP(hn, 0, NC, gi))
-      PK_GELU_GROUP(hn, 0, NC, 16)
-      PK_GELU_GROUP(hn, 0, NC, 17)
+        // x^T += W2[:, slice j] gelu(h_j)^T
+        PK_W2_SLICE((void)0, (void)0)
+        // h_{j+2}^T = W1_{j+2} a^T + b1   beside the whole of gelu(h_{j+1}) (NC values per group); b1 of slice j + 3
+        PK_W1_SLICE(hc, vb1n, PK_GELU_GROUP(hn, 0, NC, gi), PK_GELU_TAIL(hn, 0, NC))
       }
+      PK_PACK_H(hn)
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
-        hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
+      for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) hn[c][ht] = hc[c][ht];
-      }
     }
     PK_TRACE();   // FFN loop done
-    // W2_14 beside the whole of gelu(h_15) and the next tile's rows of cuboid 0, then W2_15 beside those of cuboid 1
+    // W2_{NJ-2} beside the whole of gelu(h_{NJ-1}), then W2_{NJ-1}; the next tile's rows arrive beside the tile's last two chunks
     // (the LayerNorm fragments are dead: xn takes their registers)
-    PK_CHUNK(VMC_W2_14, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { PK_GELU_GROUP(hn, 0, NC, gi) if (PK_HOOK_IO) xn[0][gi] = PK_ROW_LD(noff[0], gi); })
-    PK_GELU_GROUP(hn, 0, NC, 16)
-    PK_GELU_GROUP(hn, 0, NC, 17)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      hfr[c][0] = pk_pack8(hn[c][0], hn[c][1]);
-      hfr[c][1] = pk_pack8(hn[c][2], hn[c][3]);
+    if constexpr (NW == 1) {
+      PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), { PK_GELU_GROUP(hn, 0, NC, gi) PK_LD_HOOK(1) })
+      PK_GELU_TAIL(hn, 0, NC)
+      PK_PACK_H(hn)
+      PK_CHUNK(PK_SYNC(VMC_E0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), PK_LD_HOOK(0))
+    } else {
+      PK_W2_SLICE(PK_GELU_GROUP(hn, 0, NC, gi), PK_GELU_TAIL(hn, 0, NC))
+      PK_PACK_H(hn)
+      PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), PK_LD_HOOK(1))
+      PK_CHUNK(PK_SYNC(VMC_E0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1), PK_LD_HOOK(0))
     }
-    PK_CHUNK(VMC_W2_15, 0, (void)0, (void)0, PK_MFMA_OUT(hfr), { if constexpr (NC == 2) { if (PK_HOOK_IO) xn[NC - 1][gi] = PK_ROW_LD(noff[NC - 1], gi); } })
     PK_DRAIN();                                     // (the next tile's LayerNorm follows)
     PK_TRACE();   // FFN done
   }
@@ -598,19 +650,20 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int nt = 0; nt < 16; ++nt) PK_ROW_ST(acc[c][nt], roff[c], nt);
+    for (int nt = 0; nt < CT; ++nt) PK_ROW_ST(acc[c][nt], roff[c], nt);
   // nothing of this workgroup may still be writing LDS when its allocation is handed to the next one
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
 
-template <int NC>
+template <int NC, int CW>
 static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   using namespace pairk;
+  constexpr int LDS_BYTES = G<CW>::LDS_BYTES;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_ffn_pair: hipFuncSetAttribute(%d) failed: %s", LDS_BYTES, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -620,36 +673,40 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   // persistent: every workgroup takes the same number of tiles (the last few one less), one workgroup per CU
   const int per_wg = (a.ntiles + 255) / 256;
   const int grid = (a.ntiles + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(pair_kernel<NC>, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((pair_kernel<NC, CW>), dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
 
 extern "C" unsigned long long* pd_pair_trace = nullptr;
-extern "C" int pd_pair_force_nc = 0;             // A/B: 1 / 2 = cuboids per wave whatever the grid; 0 = automatic
+extern "C" int pd_pair_force_nc = 0;             // A/B at units 256: 1 / 2 = 16-slot groups per wave whatever the grid; 0 = automatic
 #if PD_PAIR_DEBUG
 extern "C" float* pd_pair_dbg_buf = nullptr;    // (profiling / debugging builds only: scripts/debug_pair.py)
 extern "C" int pd_pair_dbg_stage = 0;
 #endif
 
 extern "C" int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol, int act) {
-  return C == 256 && heads == 4 && hidden == 1024 && vol >= 1 && vol <= 16 && act == PD_ACT_GELU;
+  return ((C == 256 && hidden == 1024) || (C == 512 && hidden == 2048)) && heads == 4 && vol >= 1 && vol <= 16 && act == PD_ACT_GELU;
 }
 
+// cuboids of one 16-slot group (the relative-position table of `vecs` is laid out for the same number: packing.pack_pair_vecs)
+extern "C" int pd_attn_ffn_pair_cuboids_per_group(int vol) { return vol >= 1 && 2 * vol <= 16 ? 2 : 1; }
+
 extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
-                                const int32_t* tok_affine, int B, int ntok, int nc, int vol, float scale, float eps_attn, float eps_ffn,
-                                pd_stream_t stream) {
+                                const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn,
+                                float eps_ffn, pd_stream_t stream) {
   using namespace pairk;
   PD_CHECK_ARG(x && out && wstream && vecs, "pd_attn_ffn_pair: null pointer");
+  PD_CHECK_ARG(units == 256 || units == 512, "pd_attn_ffn_pair: units %d (256 or 512)", units);
   PD_CHECK_ARG(B > 0 && ntok > 0 && (int64_t)B * ntok < (1ll << 31), "pd_attn_ffn_pair: bad sizes");
   PD_CHECK_ARG(nc > 0 && vol >= 1 && vol <= 16, "pd_attn_ffn_pair: cuboid volume %d not in 1..16", vol);
   PD_CHECK_ARG(tok_index || (tok_affine && tok_affine[0] > 0), "pd_attn_ffn_pair: neither a token table nor its affine form");
-  PD_CHECK_ARG((int64_t)B * ntok * (C * 4) < 0xFFFFF000ll, "pd_attn_ffn_pair: x larger than a 4 GiB buffer descriptor");
+  PD_CHECK_ARG((int64_t)B * ntok * (units * 4) < 0xFFFFF000ll, "pd_attn_ffn_pair: x larger than a 4 GiB buffer descriptor");
   pd_pair_args_k a;
   a.x = x; a.out = out; a.wstream = wstream; a.vecs = vecs; a.tok_index = tok_index;
   a.scale = scale; a.eps1 = eps_attn; a.eps2 = eps_ffn;
-  a.wbytes = (uint32_t)(CH_ALL * CHUNK);
-  a.xbytes = (uint32_t)((int64_t)B * ntok * (C * 4));
+  a.wbytes = (uint32_t)((units == 256 ? G<1>::CH_ALL : G<2>::CH_ALL) * CHUNK);
+  a.xbytes = (uint32_t)((int64_t)B * ntok * (units * 4));
   a.trace = pd_pair_trace;
 #if PD_PAIR_DEBUG
   a.dbg_buf = pd_pair_dbg_buf;
@@ -659,15 +716,20 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   a.dbg_stage = 0;
 #endif
   a.B = B; a.ntok = ntok; a.nc = nc; a.vol = vol;
+  a.pack = pd_attn_ffn_pair_cuboids_per_group(vol);
   a.aff_on = (tok_affine && tok_affine[0] > 0) ? 1 : 0;
   a.aff_ninner = a.aff_on ? tok_affine[0] : 1;
   a.aff_outer = a.aff_on ? tok_affine[1] : 0;
   a.aff_inner = a.aff_on ? tok_affine[2] : 0;
   a.aff_slot = a.aff_on ? tok_affine[3] : 0;
-  // two cuboids per wave (128-row tiles: every weight fragment feeds two MFMAs) once that leaves no CU idle; below that ONE cuboid per
+  const int64_t groups = ((int64_t)B * nc + a.pack - 1) / a.pack;
+  if (units == 512) {                               // one group per wave: 64-row tiles
+    a.ntiles = (int)((groups + 3) / 4);
+    return launch_pair<1, 2>(a, (hipStream_t)stream);
+  }
+  // two groups per wave (128-row tiles: every weight fragment feeds two MFMAs) once that leaves no CU idle; below that ONE group per
   // wave (64-row tiles): twice the workgroups, half the MFMAs per streamed chunk -- the small-batch form
-  const int64_t cuboids = (int64_t)B * nc;
-  const int nc_wave = pd_pair_force_nc ? pd_pair_force_nc : ((cuboids + 7) / 8 > 128 ? 2 : 1);
-  a.ntiles = (int)((cuboids + 4 * nc_wave - 1) / (4 * nc_wave));
-  return nc_wave == 2 ? launch_pair<2>(a, (hipStream_t)stream) : launch_pair<1>(a, (hipStream_t)stream);
+  const int nc_wave = pd_pair_force_nc ? pd_pair_force_nc : ((groups + 7) / 8 > 128 ? 2 : 1);
+  a.ntiles = (int)((groups + 4 * nc_wave - 1) / (4 * nc_wave));
+  return nc_wave == 2 ? launch_pair<2, 1>(a, (hipStream_t)stream) : launch_pair<1, 1>(a, (hipStream_t)stream);
 }

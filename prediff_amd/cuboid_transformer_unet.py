@@ -347,6 +347,10 @@ class CuboidTransformerUNet(nn.Module):
         # tiles, when 128-row tiles would leave CUs idle: 48 vs 54 us per pair at 4 trajectories, 73 vs 84 at 8)
         self.fuse_pair = os.environ.get("PD_FUSE_PAIR", "1") != "0"
         self.pair_min_tiles = int(os.environ.get("PD_PAIR_MIN_TILES", "0"))
+        self.pair_units = {int(u) for u in os.environ.get("PD_PAIR_UNITS", "256,512").split(",") if u}   # A/B: block widths handed to it
+        # units 512 (level 1): 64-row tiles that stream 6 MB of weights each -- below this many tiles (one per CU) the separate launches,
+        # which spread the same rows over all CUs, are faster (scripts/sweep_pair_units.sh)
+        self.pair_l1_min_tiles = int(os.environ.get("PD_PAIR_L1_MIN_TILES", "150"))
         self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)
@@ -566,7 +570,7 @@ class CuboidTransformerUNet(nn.Module):
             if self.precision == "bf16" and blk.use_inter_ffn:
                 for a, (at, ff) in enumerate(zip(blk.attn_l, blk.ffn_l)):
                     geo = self._geom[level][a]
-                    if (at.dim == 256 and ff.ffn_1.out_features == 1024 and not ff.gated and at.use_final_proj and at.qkv.bias is None
+                    if (at.dim in (256, 512) and ff.ffn_1.out_features == 4 * at.dim and not ff.gated and at.use_final_proj and at.qkv.bias is None
                             and geo["mask"] is None and not any(geo["pad"]) and geo.get("tok_out") is None
                             and L.attn_ffn_pair_supported(at.dim, at.num_heads, ff.ffn_1.out_features, geo["vol"], ff.activation_name)):
                         na, nf = f"{name}.attn{a}", f"{name}.ffn{a}"
@@ -857,10 +861,12 @@ class CuboidTransformerUNet(nn.Module):
             geo = self._geom[level][a]
             # (split_k = False is the batch-split-reproducible mode: no kernel choice may depend on the per-launch batch, so the pair
             #  kernel -- row-local, bit-identical at every batch size -- then runs whatever the tile count)
-            if pair is not None and (B * geo["nc"] + 7) // 8 >= (self.pair_min_tiles if self.split_k else 0):
+            groups = -(-B * geo["nc"] // L.attn_ffn_pair_cuboids_per_group(geo["vol"]))
+            enough = (groups + 7) // 8 >= self.pair_min_tiles if C == 256 else (groups + 3) // 4 >= self.pair_l1_min_tiles
+            if pair is not None and C in self.pair_units and (enough or not self.split_k):
                 # x += attn(x); x = ffn(x) in one launch, rows register resident (csrc/pair_block.hip)
                 L.attn_ffn_pair(x, x, pair[0], pair[1], tabs[a]["tok"], B, S, geo["nc"], geo["vol"], float(at.scale), eps_attn=pair[2],
-                                eps_ffn=pair[3], tok_affine=geo.get("affine"))
+                                eps_ffn=pair[3], tok_affine=geo.get("affine"), units=C)
                 continue
             self._attention(P, f"{name}.attn{a}", at, x, B, S, C, tabs[a], self._geom[level][a], dev)
             if blk.use_inter_ffn:

@@ -87,7 +87,7 @@ def pack_linear_fp8(weight: torch.Tensor, k_pad: Optional[int] = None):
 
 # ---------------------------------------------------------------------------------------------------- (attention, FFN) pair kernel
 PAIR_CHUNK_BYTES = 32768          # csrc/pair_block.hip: 32 fragments of 1 KB
-PAIR_VEC_FLOATS = 3584
+PAIR_VEC_FLOATS = 3584          # units 256; 6144 at units 512
 
 
 def _mfma_frags(w: torch.Tensor) -> torch.Tensor:
@@ -101,47 +101,64 @@ def _mfma_frags(w: torch.Tensor) -> torch.Tensor:
     return v.reshape(N // 16, K // 32, 64, 8).contiguous()
 
 
+def pair_cuboids_per_group(vol: int) -> int:
+    """cuboids that share one 16-slot group of pd_attn_ffn_pair (== pd_attn_ffn_pair_cuboids_per_group)"""
+    return 2 if vol >= 1 and 2 * vol <= 16 else 1
+
+
 def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
-    """The weight stream of pd_attn_ffn_pair (units 256, 4 heads, hidden 1024): 48 chunks of 32 KB in consumption order --
-    per head h: Wq_h, Wk_h, Wv_h ([64 x 256]: fragment i = 4 ks + dt), Wproj[:, 64 h : 64 h + 64] ([256 x 64]: i = 16 st + nt);
-    then W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0..13, W2_14, W2_15 (W1_j = rows 64 j .. of (1024, 256); W2_j = columns 64 j .. of
-    (256, 1024)): gelu(h_j) runs beside the two chunks between W1_j and W2_j."""
-    assert tuple(wqkv.shape) == (768, 256) and tuple(wproj.shape) == (256, 256) and tuple(w1.shape) == (1024, 256) and tuple(w2.shape) == (256, 1024)
+    """The weight stream of pd_attn_ffn_pair for units C = 256 (4 heads of 64, hidden 1024) or 512 (4 heads of 128, hidden 2048):
+    chunks of 32 KB = 32 fragments in consumption order.  With CW = C / 256, HD = C / 4, DT = HD / 16, CT = C / 16:
+      per head h: Wq_h, Wk_h, Wv_h ([HD x C], CW^2 chunks each: fragment i of chunk s = feature tile i % DT, k-step s * 32 / DT + i / DT),
+                  Wproj[:, HD h : HD h + HD] ([C x HD], CW^2 chunks: column tile i % CT, k-step s * 32 / CT + i / CT);
+      then the 64-wide hidden slices W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0 .. hidden/64 - 3, W2_{n-2}, W2_{n-1}
+      (W1_j = rows 64 j .. of (hidden, C), CW chunks: hidden tile i & 3, k-step 8 s + i / 4;  W2_j = columns 64 j .. of (C, hidden), CW
+      chunks: column tile i % CT, k-step s * 32 / CT + i / CT): gelu(h_j) runs beside the chunks between W1_j and W2_j."""
+    Cn = wproj.shape[0]
+    assert Cn in (256, 512)
+    CW, hid = Cn // 256, 4 * Cn
+    assert tuple(wqkv.shape) == (3 * Cn, Cn) and tuple(wproj.shape) == (Cn, Cn) and tuple(w1.shape) == (hid, Cn) and tuple(w2.shape) == (Cn, hid)
+    HD, CT = Cn // 4, Cn // 16
+    DT, HS = HD // 16, HD // 32
     bf = lambda t: t.detach().to(torch.bfloat16)
     fq, fp, f1, f2 = _mfma_frags(bf(wqkv)), _mfma_frags(bf(wproj)), _mfma_frags(bf(w1)), _mfma_frags(bf(w2))
 
-    def rows_chunk(fr, F0):                                # [64 features x 256 k]: i = 4 ks + dt
-        return fr[F0:F0 + 4].permute(1, 0, 2, 3).reshape(32, 64, 8)
-
-    def cols_chunk(fr, KB0):                               # [256 features x 64 k]: i = 16 st + nt
-        return fr[:, KB0:KB0 + 2].permute(1, 0, 2, 3).reshape(32, 64, 8)
+    def tile_chunks(fr, F0, nF, K0, nK):
+        """fragments [F0, F0 + nF) x [K0, K0 + nK) -> chunks of 32 with i = nF * k_local + f"""
+        v = fr[F0:F0 + nF, K0:K0 + nK].permute(1, 0, 2, 3).reshape(nF * nK, 64, 8)
+        return list(v.reshape(nF * nK // 32, 32, 64, 8))
 
     chunks = []
     for h in range(4):
         for kind in range(3):
-            chunks.append(rows_chunk(fq, (kind * 256 + 64 * h) // 16))
-        chunks.append(cols_chunk(fp, 2 * h))
-    chunks.append(rows_chunk(f1, 0))
-    chunks.append(rows_chunk(f1, 4))
-    for j in range(16):
-        chunks.append(cols_chunk(f2, 2 * j))
-        if j + 2 < 16:
-            chunks.append(rows_chunk(f1, 4 * (j + 2)))
+            chunks += tile_chunks(fq, (kind * Cn + HD * h) // 16, DT, 0, Cn // 32)
+        chunks += tile_chunks(fp, 0, CT, HS * h, HS)
+    nj = hid // 64
+    w1s = lambda j: tile_chunks(f1, 4 * j, 4, 0, Cn // 32)
+    w2s = lambda j: tile_chunks(f2, 0, CT, 2 * j, 2)
+    chunks += w1s(0) + w1s(1)
+    for j in range(nj):
+        chunks += w2s(j)
+        if j + 2 < nj:
+            chunks += w1s(j + 2)
     out = torch.stack(chunks).contiguous()
-    assert out.numel() * 2 == 48 * PAIR_CHUNK_BYTES
+    assert out.shape[0] == 16 * CW * CW + 2 * nj * CW and out.numel() * 2 == out.shape[0] * PAIR_CHUNK_BYTES
     return out
 
 
 def pack_pair_vecs(ln1_g, ln1_b, bproj, ln2_g, ln2_b, b2, b1, rel_bias) -> torch.Tensor:
-    """fp32 tables of pd_attn_ffn_pair: LN1 gamma, beta, proj bias, LN2 gamma, beta, FFN-2 bias (256 each), FFN-1 bias (1024),
-    relative-position bias (4 heads, vol, vol) zero padded to (4, 16, 16)."""
+    """fp32 tables of pd_attn_ffn_pair: LN1 gamma, beta, proj bias, LN2 gamma, beta, FFN-2 bias (units each), FFN-1 bias (hidden), and the
+    (4 heads, 16, 16) score table of a 16-slot group: the relative-position bias (4, vol, vol) on the diagonal block of every cuboid the
+    group holds (pair_cuboids_per_group(vol)), -inf everywhere else -- a padded slot, or a key of the group's other cuboid."""
     dev = ln1_g.device
-    z256 = torch.zeros(256, device=dev)
-    rb = torch.zeros(4, 16, 16, device=dev)
+    Cn = ln1_g.numel()
+    zc = torch.zeros(Cn, device=dev)
     vol = rel_bias.shape[-1]
-    rb[:, :vol, :vol] = rel_bias.detach().float()
-    parts = [ln1_g, ln1_b, bproj if bproj is not None else z256, ln2_g, ln2_b, b2 if b2 is not None else z256,
-             b1 if b1 is not None else torch.zeros(1024, device=dev), rb.reshape(-1)]
+    rb = torch.full((4, 16, 16), float("-inf"), device=dev)
+    for a in range(pair_cuboids_per_group(vol)):
+        rb[:, a * vol:(a + 1) * vol, a * vol:(a + 1) * vol] = rel_bias.detach().float()
+    parts = [ln1_g, ln1_b, bproj if bproj is not None else zc, ln2_g, ln2_b, b2 if b2 is not None else zc,
+             b1 if b1 is not None else torch.zeros(4 * Cn, device=dev), rb.reshape(-1)]
     v = torch.cat([t.detach().float().reshape(-1).to(dev) for t in parts]).contiguous()
-    assert v.numel() == PAIR_VEC_FLOATS
+    assert v.numel() == 10 * Cn + 1024
     return v

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Compile-time ablation builds of csrc/pair_block.hip (bits: 1 no weight DMA after the prologue, 2 no fragment reads, 4 no MFMAs,
-# 8 no GELU) -> prediff_amd/libprediff_hip_ab<N>.so (untracked); run on the GPU box:  bash scripts/ablate_pair.sh run [B]
+# 8 no GELU, 16 no hook row I/O) -> prediff_amd/libprediff_hip_ab<N>.so (untracked); run on the GPU box:  [PD_BENCH_UNITS=512] bash scripts/ablate_pair.sh run [B]
 cd "$(dirname "$0")/../prediff_amd/csrc" || exit 1
 VARIANTS=${VARIANTS:-"0 1 2 4 8 3 6 12 15"}
 if [ "$1" = "build" ]; then

@@ -85,6 +85,48 @@ def main():
 
 
 
+def level1(B=32):
+    """units 512 (the level-1 blocks): pair kernel against an fp32 torch statement of the pair (agreement) and its time."""
+    shape, Cn, heads, Hd = (13, 8, 8), 512, 4, 2048
+    ntok = shape[0] * shape[1] * shape[2]
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    x = (torch.randn(B, ntok, Cn, generator=g) * 1.5 + 0.2).to(DEV)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    g1, b1n, g2, b2n = 1 + r(Cn, sc=0.1), r(Cn, sc=0.1), 1 + r(Cn, sc=0.1), r(Cn, sc=0.1)
+    wqkv, wp = r(3 * Cn, Cn, sc=Cn ** -0.5), r(Cn, Cn, sc=Cn ** -0.5)
+    w1, w2 = r(Hd, Cn, sc=Cn ** -0.5), r(Cn, Hd, sc=Hd ** -0.5)
+    bp, fb1, fb2 = r(Cn, sc=0.1), r(Hd, sc=0.1), r(Cn, sc=0.1)
+    ws = pack_pair_block(wqkv, wp, w1, w2)
+    scale = (Cn // heads) ** -0.5
+    F = torch.nn.functional
+    for cuboid in ((13, 1, 1), (1, 8, 1), (1, 1, 8)):
+        tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+        vol, nc = tabs["vol"], tabs["nc"]
+        bias = r(heads, vol, vol, sc=0.5)
+        tok = tabs["tok_index"].to(DEV)
+        vecs = pack_pair_vecs(g1, b1n, bp, g2, b2n, fb2, fb1, bias)
+        assert L.attn_ffn_pair_supported(Cn, heads, Hd, vol)
+        # fp32 statement
+        idx = tok.long().reshape(-1)
+        xn = F.layer_norm(x, (Cn,), g1, b1n)[:, idx].reshape(B, nc, vol, Cn)
+        qkv = (xn @ wqkv.t()).reshape(B, nc, vol, 3, heads, Cn // heads).permute(3, 0, 1, 4, 2, 5)
+        att = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) * scale + bias, -1) @ qkv[2]
+        o = att.permute(0, 1, 3, 2, 4).reshape(B, nc * vol, Cn) @ wp.t() + bp
+        y = x.clone()
+        y[:, idx] += o
+        ref = y + F.gelu(F.layer_norm(y, (Cn,), g2, b2n) @ w1.t() + fb1) @ w2.t() + fb2
+        t = x.clone()
+        new = lambda buf, aff=True: L.attn_ffn_pair(buf, buf, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"] if aff else None, units=Cn)
+        new(t); torch.cuda.synchronize()
+        print(f"cuboid {cuboid}: rel-L2 of the update vs fp32 torch {rel(t - x, ref - x):.3e}   finite {bool(torch.isfinite(t).all())}")
+        t2 = x.clone(); new(t2, aff=False); t3 = x.clone(); new(t3); torch.cuda.synchronize()
+        print(f"   table-driven token ids == affine: {torch.equal(t2, t)};  repeat bit-equal: {torch.equal(t3, t)}")
+        buf = x.clone()
+        tn = timeit(lambda: new(buf))
+        gf = B * ntok * 2.0 * (3 * Cn * Cn + Cn * Cn + 2 * Cn * Hd + 2 * vol * Cn) / 1e9
+        print(f"   B={B}: pair kernel {tn:.1f} us  ({gf / tn * 1e3:.0f} TFLOP/s, {gf / tn * 1e3 / 2500:.3f} of peak)")
+
+
 def trace(B=32):
     """PD_PAIR_DEBUG build: phase clock stamps of wave 0 of workgroup 7 (s_memtime, 100 MHz constant clock on gfx950? printed raw)."""
     import ctypes
@@ -112,27 +154,33 @@ def trace(B=32):
 
 
 def ablate(B=32):
-    """Time of the pair launch in whatever library PD_LIB_PATH names (scripts/ablate_pair.sh builds -DPD_PAIR_ABLATE variants)."""
-    shape, Cn = (13, 16, 16), 256
-    ntok = 13 * 256
+    """Time of the pair launch in whatever library PD_LIB_PATH names (scripts/ablate_pair.sh builds -DPD_PAIR_ABLATE variants);
+    PD_BENCH_UNITS=512: the level-1 shapes."""
+    Cn = int(os.environ.get("PD_BENCH_UNITS", "256"))
+    shape, cuboid = ((13, 16, 16), (1, 16, 1)) if Cn == 256 else ((13, 8, 8), (1, 8, 1))
+    Hd = 4 * Cn
+    ntok = shape[0] * shape[1] * shape[2]
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.randn(B, ntok, Cn, generator=g).to(DEV)
     r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
-    ws = pack_pair_block(r(768, 256, sc=1 / 16), r(256, 256, sc=1 / 16), r(1024, 256, sc=1 / 16), r(256, 1024, sc=1 / 32))
-    tabs = attention_tables(shape, (1, 16, 1), (0, 0, 0), LLL, "zeros")
-    vecs = pack_pair_vecs(1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), 1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), r(1024, sc=.1), r(4, 16, 16, sc=.5))
+    ws = pack_pair_block(r(3 * Cn, Cn, sc=Cn ** -0.5), r(Cn, Cn, sc=Cn ** -0.5), r(Hd, Cn, sc=Cn ** -0.5), r(Cn, Hd, sc=Hd ** -0.5))
+    tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+    vol = tabs["vol"]
+    vecs = pack_pair_vecs(1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), 1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), r(Hd, sc=.1), r(4, vol, vol, sc=.5))
     tok = tabs["tok_index"].to(DEV)
     out = []
     for rep in range(3):
-        t = timeit(lambda: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"]))
+        t = timeit(lambda: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], vol, (Cn // 4) ** -0.5, tok_affine=tabs["affine"], units=Cn))
         x.normal_()
         out.append(f"{t:.1f} us")
-    print(os.environ.get("PD_LIB_PATH", "default"), " | ".join(out))
+    print(os.environ.get("PD_LIB_PATH", "default"), f"units {Cn}", " | ".join(out))
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "ablate":
         ablate(int(sys.argv[1]))
+    elif len(sys.argv) > 2 and sys.argv[2] == "level1":
+        level1(int(sys.argv[1]))
     elif len(sys.argv) > 2 and sys.argv[2] == "trace":
         trace(int(sys.argv[1]))
     else:

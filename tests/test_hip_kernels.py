@@ -897,20 +897,24 @@ def test_conv2d_gn_silu_two_workgroups_per_cu(N, H, W, Cin, Cout, res):
 
 # ------------------------------------------------------------------------------------------------ (attention, FFN) pair kernel
 PAIR_CASES = {
-    # name: (shape, cuboid, B)  -- units 256, 4 heads, hidden 1024 (the level-0 blocks of the SEVIR-LR denoiser)
-    "t13": ((13, 16, 16), (13, 1, 1), 2),      # axial T: 13 of 16 slots per cuboid, 64 tiles of 8 cuboids
-    "h16": ((13, 16, 16), (1, 16, 1), 1),      # axial H
-    "w16": ((13, 16, 16), (1, 1, 16), 1),      # axial W
-    "tail": ((3, 6, 7), (1, 6, 1), 3),         # 63 cuboids of 6 slots: 7 full tiles + one of 7 cuboids; 3 workgroups' worth of empty slots
-    "one": ((2, 5, 3), (2, 1, 1), 1),          # 15 cuboids of 2 slots: two tiles, the second one cuboid short
+    # name: (shape, cuboid, B, units)  -- 4 heads, hidden 4 x units: the level-0 (256) and level-1 (512) blocks of the SEVIR-LR denoiser
+    "t13": ((13, 16, 16), (13, 1, 1), 2, 256),      # axial T: 13 of 16 slots per cuboid, 64 tiles of 8 cuboids
+    "h16": ((13, 16, 16), (1, 16, 1), 1, 256),      # axial H
+    "w16": ((13, 16, 16), (1, 1, 16), 1, 256),      # axial W
+    "tail": ((3, 6, 7), (1, 6, 1), 3, 256),         # 63 cuboids of 6 slots, two per 16-slot group: 32 groups, the last one half empty
+    "one": ((2, 5, 3), (2, 1, 1), 1, 256),          # 15 cuboids of 2 slots: 8 groups
+    "L1t13": ((13, 8, 8), (13, 1, 1), 2, 512),      # level 1, axial T: one cuboid of 13 per group, 32 tiles of 4 groups
+    "L1h8": ((13, 8, 8), (1, 8, 1), 1, 512),        # level 1, axial H: two cuboids of 8 per group, all 16 slots used
+    "L1w8": ((13, 8, 8), (1, 1, 8), 1, 512),        # level 1, axial W
+    "L1odd": ((3, 5, 3), (1, 5, 1), 3, 512),        # 27 cuboids of 5 slots: 14 groups (the last with ONE cuboid), 6 dead slots per group
 }
 
 
 def _pair_case(name):
     import _templates as TP
     from _weights import seeded_input, seeded_state_dict
-    shape, cuboid, B = PAIR_CASES[name]
-    Cn, heads, Hd = 256, 4, 1024
+    shape, cuboid, B, Cn = PAIR_CASES[name]
+    heads, Hd = 4, 4 * Cn
     seed = 300 + sum(map(ord, name))
     sd_a = seeded_state_dict(TP.attn_layer(Cn, heads, cuboid), seed)
     sd_f = seeded_state_dict(TP.ffn(Cn, Hd), seed + 1)
@@ -940,6 +944,8 @@ def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
     from prediff_amd.packing import pack_pair_block, pack_pair_vecs
     shape, cuboid, B, Cn, heads, Hd, sd_a, sd_f, x = _pair_case(name)
+    if Cn == 512 and pair_nc == 2:
+        pytest.skip("units 512: one group per wave only")
     y1 = x + OU.cuboid_self_attention(sd_a, "", x, heads, cuboid, (0, 0, 0), LLL, "zeros")
     y_ref = OU.positionwise_ffn(sd_f, "", y1, "gelu")
     tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
@@ -955,7 +961,7 @@ def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     tok = tabs["tok_index"].to(DEV)
     scale = (Cn // heads) ** -0.5
     out = torch.full_like(xd, float("nan"))
-    L.attn_ffn_pair(xd, out, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"])
+    L.attn_ffn_pair(xd, out, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"], units=Cn)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out).all()), "a row was not written (or written with garbage)"
     e = rel_l2((out - xd).reshape(x.shape).cpu(), y_ref - x)
@@ -965,9 +971,11 @@ def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     # in place, token ids from the table instead of the affine form, and a repeat: bit-identical
     for aff in (None, tabs["affine"], tabs["affine"]):
         t = xd.clone()
-        L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=aff)
+        L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=aff, units=Cn)
         torch.cuda.synchronize()
         assert torch.equal(t, out)
+    if Cn != 256:
+        return                                          # (the round-3 fused kernels exist for units 256 only)
     # the two launches it replaces (same bf16 operands; erf GELU there, the 2.5e-5 sigmoid form here; another summation order)
     wq_p, _ = pack_linear(d(sd_a["qkv.weight"]), False)
     wp_p, _ = pack_linear(d(sd_a["proj.weight"]), False)
@@ -988,28 +996,35 @@ def test_attn_ffn_pair_rejects_what_it_does_not_run():
     assert not L.attn_ffn_pair_supported(128, 2, 512, 16)
     assert not L.attn_ffn_pair_supported(256, 4, 1024, 25)
     assert not L.attn_ffn_pair_supported(256, 4, 1024, 16, act="leaky")
+    assert not L.attn_ffn_pair_supported(512, 4, 1024, 16) and not L.attn_ffn_pair_supported(512, 8, 2048, 16)
+    assert L.attn_ffn_pair_supported(512, 4, 2048, 13)
     x = torch.zeros(1, 32, 256, device=DEV)
     with pytest.raises(L.PrediffHipError):
         L.attn_ffn_pair(x, x, x, x, None, 1, 32, 2, 16, 0.125)        # neither a token table nor its affine form
+    with pytest.raises(L.PrediffHipError):
+        L.attn_ffn_pair(x, x, x, x, x.int(), 1, 32, 2, 16, 0.125, units=384)
 
 
-def test_attn_ffn_pair_stress_bit_equal():
+@pytest.mark.parametrize("Cn", [256, 512])
+def test_attn_ffn_pair_stress_bit_equal(Cn):
     """60 launches of pd_attn_ffn_pair at the benchmark's occupancy (32 trajectories: 832 tiles, four per workgroup, the weight stream and
     the pipelined tile boundary running on across tiles) interleaved with a bandwidth-hungry copy on another stream: every result
     bit-equal to the first.  The kernel's counted `s_waitcnt vmcnt(N)` / `lgkmcnt(N)` waits assume an exact, in-order instruction
     census; a miscount shows up as timing-dependent garbage in a few rows, which this would catch."""
     from prediff_amd.cuboid_geometry import attention_tables
     from prediff_amd.packing import pack_pair_block, pack_pair_vecs
-    shape, cuboid, B, Cn, heads, Hd = (13, 16, 16), (1, 1, 16), 32, 256, 4, 1024
-    ntok = 13 * 256
+    shape, cuboid = ((13, 16, 16), (1, 1, 16)) if Cn == 256 else ((13, 8, 8), (1, 1, 8))      # (units 512: 416 tiles, two per workgroup)
+    B, heads, Hd = 32, 4, 4 * Cn
+    ntok = shape[0] * shape[1] * shape[2]
     g = torch.Generator(device="cpu").manual_seed(77)
     r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
     x = r(B, ntok, Cn)
-    ws = pack_pair_block(r(768, 256, sc=1 / 16), r(256, 256, sc=1 / 16), r(1024, 256, sc=1 / 16), r(256, 1024, sc=1 / 32))
+    ws = pack_pair_block(r(3 * Cn, Cn, sc=Cn ** -0.5), r(Cn, Cn, sc=Cn ** -0.5), r(Hd, Cn, sc=Cn ** -0.5), r(Cn, Hd, sc=Hd ** -0.5))
     tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
-    vecs = pack_pair_vecs(1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), 1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), r(1024, sc=.1), r(4, 16, 16, sc=.5))
+    vol = tabs["vol"]
+    vecs = pack_pair_vecs(1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), 1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), r(Hd, sc=.1), r(4, vol, vol, sc=.5))
     tok = tabs["tok_index"].to(DEV)
-    run = lambda out: L.attn_ffn_pair(x, out, ws, vecs, tok, B, ntok, tabs["nc"], tabs["vol"], 0.125, tok_affine=tabs["affine"])
+    run = lambda out: L.attn_ffn_pair(x, out, ws, vecs, tok, B, ntok, tabs["nc"], vol, (Cn // 4) ** -0.5, tok_affine=tabs["affine"], units=Cn)
     ref = torch.empty_like(x)
     run(ref)
     torch.cuda.synchronize()

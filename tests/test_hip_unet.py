@@ -126,8 +126,8 @@ def test_v1_forward_repeats_bit_equal_at_full_occupancy(precision):
 
 
 def test_v1_forward_b32_vs_oracle_with_pair_kernel():
-    """The occupancy the benchmark runs at -- 32 trajectories per launch, bf16 engine, the level-0 (attention, FFN) pairs on
-    pd_attn_ffn_pair (csrc/pair_block.hip: 832 tiles of 128 rows, four per workgroup) -- against the oracle's CPU forward of the
+    """The occupancy the benchmark runs at -- 32 trajectories per launch, bf16 engine, every (attention, FFN) pair on
+    pd_attn_ffn_pair (csrc/pair_block.hip: level 0 832 tiles of 128 rows, four per workgroup; level 1 416 / 512 tiles of 64 rows) -- against the oracle's CPU forward of the
     same 32 samples with 32 different timesteps (not a self-comparison), and against the engine with the pair kernel switched off
     (the two round-3 kernels per pair)."""
     from prediff_amd import _lib as L
@@ -151,7 +151,7 @@ def test_v1_forward_b32_vs_oracle_with_pair_kernel():
         assert len(calls) == n_pair
     finally:
         L.attn_ffn_pair = real
-    assert n_pair == 24, f"{n_pair} pair launches (expected the 24 level-0 pairs of depth [4, 4] x down / up x 3 axes)"
+    assert n_pair == 48, f"{n_pair} pair launches (expected the 24 level-0 + 24 level-1 pairs of depth [4, 4] x down / up x 3 axes)"
     ref = OU.unet_forward(sd, V1_UNET_CFG, x, t, cond)
     e, e3 = rel_l2(out, ref), rel_l2(out_r3, ref)
     e_ab = rel_l2(out, out_r3.cpu())

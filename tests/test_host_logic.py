@@ -186,3 +186,53 @@ def test_pair_kernel_async_lds_check():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_async_lds.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "0 finding(s)" in out.stdout
+
+
+@pytest.mark.parametrize("Cn", [256, 512])
+def test_pair_packing_layout(Cn):
+    """packing.pack_pair_block / pack_pair_vecs (the operands of pd_attn_ffn_pair, csrc/pair_block.hip): every weight element appears
+    exactly once in the stream, at the fragment position the kernel's chunk enumeration expects (spot checks against the documented
+    index formulas); the score table is the bias on each cuboid's diagonal block and -inf elsewhere; the group-packing rule equals the
+    library's."""
+    import torch
+    from prediff_amd import _lib as L
+    from prediff_amd.packing import pack_pair_block, pack_pair_vecs, pair_cuboids_per_group
+    hid, HD, CT = 4 * Cn, Cn // 4, Cn // 16
+    DT, CW = HD // 16, Cn // 256
+    # integer-valued bf16-exact weights (<= 250: eight significant bits) that hash (matrix, row, column)
+    enc = lambda m, R, K: ((torch.arange(R).reshape(-1, 1) * 7 + torch.arange(K).reshape(1, -1) * 3 + 41 * m) % 251).float()
+    wqkv, wp, w1, w2 = enc(1, 3 * Cn, Cn), enc(2, Cn, Cn), enc(3, hid, Cn), enc(4, Cn, hid)
+    ws = pack_pair_block(wqkv, wp, w1, w2).float()
+    nchunks = 16 * CW * CW + 2 * (hid // 64) * CW
+    assert tuple(ws.shape) == (nchunks, 32, 64, 8)
+    total = sum(float(w.double().sum()) for w in (wqkv, wp, w1, w2))
+    assert float(ws.double().sum()) == total
+    elem = lambda W, F, KB, lane, j: float(W[16 * F + (lane & 15), 32 * KB + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)])
+    # head h, kind (q, k, v), chunk s, fragment i: feature tile i % DT, k-step s * 32 / DT + i / DT
+    for h, kind, s_, i, lane, j in ((0, 0, 0, 0, 0, 0), (3, 2, CW * CW - 1, 31, 63, 7), (1, 1, 0, 5, 17, 3)):
+        c = h * 4 * CW * CW + kind * CW * CW + s_
+        F = (kind * Cn + HD * h) // 16 + i % DT
+        assert float(ws[c, i, lane, j]) == elem(wqkv, F, s_ * (32 // DT) + i // DT, lane, j)
+    # proj slice of head h, chunk s: column tile i % CT, k-step HS h + s * 32 / CT + i / CT
+    for h, s_, i, lane, j in ((0, 0, 0, 0, 0), (2, CW * CW - 1, 31, 40, 6)):
+        c = h * 4 * CW * CW + 3 * CW * CW + s_
+        assert float(ws[c, i, lane, j]) == elem(wp, i % CT, (HD // 32) * h + s_ * (32 // CT) + i // CT, lane, j)
+    # hidden slices: W1_0, W1_1, (W2_j, W1_{j+2}) ...
+    base = 16 * CW * CW
+    assert float(ws[base, 6, 33, 2]) == elem(w1, 0 + (6 & 3), 6 >> 2, 33, 2)                                   # W1_0, chunk 0
+    assert float(ws[base + CW, 9, 1, 5]) == elem(w1, 4 + (9 & 3), 9 >> 2, 1, 5)                                # W1_1, chunk 0
+    assert float(ws[base + 2 * CW, 20, 7, 1]) == elem(w2, 20 % CT, 0 + 20 // CT, 7, 1)                         # W2_0, chunk 0
+    assert float(ws[base + 3 * CW, 3, 50, 4]) == elem(w1, 8 + 3, 0, 50, 4)                                     # W1_2, chunk 0
+    assert float(ws[nchunks - 1, 31, 63, 7]) == elem(w2, 31 % CT, 2 * (hid // 64 - 1) + (CW - 1) * (32 // CT) + 31 // CT, 63, 7)   # last chunk of W2_{n-1}
+    for vol in (1, 5, 8, 9, 13, 16):
+        assert pair_cuboids_per_group(vol) == L.attn_ffn_pair_cuboids_per_group(vol) == L.lib().pd_attn_ffn_pair_cuboids_per_group(vol)
+        bias = torch.randn(4, vol, vol)
+        v = pack_pair_vecs(*(torch.full((Cn,), float(k)) for k in range(1, 7)), torch.full((hid,), 7.0), bias)
+        assert v.numel() == 10 * Cn + 1024 and [float(v[k * Cn]) for k in range(6)] == [1, 2, 3, 4, 5, 6] and float(v[6 * Cn + hid - 1]) == 7
+        rb = v[6 * Cn + hid:].reshape(4, 16, 16)
+        n = pair_cuboids_per_group(vol)
+        inside = torch.zeros(16, 16, dtype=torch.bool)
+        for a in range(n):
+            assert torch.equal(rb[:, a * vol:(a + 1) * vol, a * vol:(a + 1) * vol], bias)
+            inside[a * vol:(a + 1) * vol, a * vol:(a + 1) * vol] = True
+        assert bool(torch.isinf(rb[:, ~inside]).all()) and bool((rb[:, ~inside] < 0).all())
