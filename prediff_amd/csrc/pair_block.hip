@@ -30,6 +30,13 @@
 #include <type_traits>
 #include "common.h"
 
+// No implicit mul + add contraction in this file: the instantiations of the kernel (one / two groups per wave, units 256 / 512) must
+// compute a row with the SAME fp32 operations -- the batch-split-reproducible mode of the engine runs a trajectory through whichever
+// instantiation its launch size selects and promises bit-identical results (tests/test_hip_configs.py::test_v1_lane_split_tolerance;
+// with the default fp-contract=fast hipcc fused different pairs in different instantiations and one row in a thousand differed by a
+// bf16 rounding).  Every fused multiply-add below is written as one.
+#pragma clang fp contract(off)
+
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
 
@@ -78,7 +85,7 @@ struct pd_pair_args_k {
   const float* vecs;          // T_FLOATS floats
   const int32_t* tok_index;   // [nc][vol] or null with aff_on
   int B, ntok, nc, vol;
-  int pack;                   // cuboids per 16-slot group: 2 when 2 vol <= 16
+  int pack, gps;              // cuboids per 16-slot group (2 when 2 vol <= 16); groups per sample = ceil(nc / pack)
   float scale, eps1, eps2;
   int aff_on, aff_ninner, aff_outer, aff_inner, aff_slot;
   int ntiles;
@@ -278,10 +285,12 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     const int sub = q >= p.vol ? 1 : 0, slot = q - sub * p.vol;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int64_t gc = ((int64_t)tile * (4 * NC) + wave * NC + c) * p.pack + sub;
+      // group -> (sample, cuboids): groups never straddle samples, so where a cuboid sits inside its group -- and with it the order
+      // in which its keys are summed -- does not depend on the batch the sample is launched in
+      const int64_t gi = (int64_t)tile * (4 * NC) + wave * NC + c;
+      const int b = (int)(gi / p.gps), cu = (int)(gi - (int64_t)b * p.gps) * p.pack + sub;
       int row = -1;
-      if (gc < (int64_t)p.B * p.nc && sub < p.pack && slot < p.vol) {
-        const int b = (int)(gc / p.nc), cu = (int)(gc - (int64_t)b * p.nc);
+      if (b < p.B && cu < p.nc && sub < p.pack && slot < p.vol) {
         const int tok = p.aff_on ? (cu / p.aff_ninner) * p.aff_outer + (cu % p.aff_ninner) * p.aff_inner + slot * p.aff_slot
                                  : p.tok_index[cu * p.vol + slot];
         if (tok >= 0 && tok < p.ntok) row = b * p.ntok + tok;
@@ -359,9 +368,10 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #pragma unroll
         for (int nt = 0; nt < CT; ++nt) {
           const float d0 = src[c][nt][0] - mean[c], d1 = src[c][nt][1] - mean[c], d2 = src[c][nt][2] - mean[c], d3 = src[c][nt][3] - mean[c];
-          v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          v += __builtin_fmaf(d0, d0, d1 * d1) + __builtin_fmaf(d2, d2, d3 * d3);
         }
-        rstd[c] = rsqrtf(pk_rows4_sum(v) * (1.0f / C) + eps);
+        rstd[c] = rsqrtf(__builtin_fmaf(pk_rows4_sum(v), 1.0f / C, eps));
+        mean[c] = -mean[c] * rstd[c];              // y = (x rstd - mean rstd) gamma + beta: two fused multiply-adds per element
       }
       // gamma / beta of the k-step's two column tiles: opaque reads, one k-step ahead
       f32x4 gb[2][4];
@@ -387,7 +397,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
           for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              y[hf][r] = (src[c][2 * ks + hf][r] - mean[c]) * rstd[c] * gb[ks & 1][hf][r] + gb[ks & 1][2 + hf][r];
+              y[hf][r] = __builtin_fmaf(__builtin_fmaf(src[c][2 * ks + hf][r], rstd[c], mean[c]), gb[ks & 1][hf][r], gb[ks & 1][2 + hf][r]);
           af[c][ks] = pk_pack8(y[0], y[1]);
         }
       }
@@ -492,7 +502,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
         float sc[4], mx = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sc[r] = s4[r] * p.scale + rb[r];          // -inf: a padded slot, or a key of the group's other cuboid
+          sc[r] = __builtin_fmaf(s4[r], p.scale, rb[r]);   // -inf: a padded slot, or a key of the group's other cuboid
           mx = fmaxf(mx, sc[r]);
         }
 #if PD_PAIR_DEBUG
@@ -722,7 +732,8 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   a.aff_outer = a.aff_on ? tok_affine[1] : 0;
   a.aff_inner = a.aff_on ? tok_affine[2] : 0;
   a.aff_slot = a.aff_on ? tok_affine[3] : 0;
-  const int64_t groups = ((int64_t)B * nc + a.pack - 1) / a.pack;
+  a.gps = (nc + a.pack - 1) / a.pack;
+  const int64_t groups = (int64_t)B * a.gps;
   if (units == 512) {                               // one group per wave: 64-row tiles
     a.ntiles = (int)((groups + 3) / 4);
     return launch_pair<1, 2>(a, (hipStream_t)stream);

@@ -861,7 +861,7 @@ class CuboidTransformerUNet(nn.Module):
             geo = self._geom[level][a]
             # (split_k = False is the batch-split-reproducible mode: no kernel choice may depend on the per-launch batch, so the pair
             #  kernel -- row-local, bit-identical at every batch size -- then runs whatever the tile count)
-            groups = -(-B * geo["nc"] // L.attn_ffn_pair_cuboids_per_group(geo["vol"]))
+            groups = B * -(-geo["nc"] // L.attn_ffn_pair_cuboids_per_group(geo["vol"]))
             enough = (groups + 7) // 8 >= self.pair_min_tiles if C == 256 else (groups + 3) // 4 >= self.pair_l1_min_tiles
             if pair is not None and C in self.pair_units and (enough or not self.split_k):
                 # x += attn(x); x = ffn(x) in one launch, rows register resident (csrc/pair_block.hip)

@@ -901,12 +901,12 @@ PAIR_CASES = {
     "t13": ((13, 16, 16), (13, 1, 1), 2, 256),      # axial T: 13 of 16 slots per cuboid, 64 tiles of 8 cuboids
     "h16": ((13, 16, 16), (1, 16, 1), 1, 256),      # axial H
     "w16": ((13, 16, 16), (1, 1, 16), 1, 256),      # axial W
-    "tail": ((3, 6, 7), (1, 6, 1), 3, 256),         # 63 cuboids of 6 slots, two per 16-slot group: 32 groups, the last one half empty
+    "tail": ((3, 6, 7), (1, 6, 1), 3, 256),         # 21 cuboids of 6 slots per sample, two per 16-slot group: 11 groups per sample, the last one half empty
     "one": ((2, 5, 3), (2, 1, 1), 1, 256),          # 15 cuboids of 2 slots: 8 groups
     "L1t13": ((13, 8, 8), (13, 1, 1), 2, 512),      # level 1, axial T: one cuboid of 13 per group, 32 tiles of 4 groups
     "L1h8": ((13, 8, 8), (1, 8, 1), 1, 512),        # level 1, axial H: two cuboids of 8 per group, all 16 slots used
     "L1w8": ((13, 8, 8), (1, 1, 8), 1, 512),        # level 1, axial W
-    "L1odd": ((3, 5, 3), (1, 5, 1), 3, 512),        # 27 cuboids of 5 slots: 14 groups (the last with ONE cuboid), 6 dead slots per group
+    "L1odd": ((3, 5, 3), (1, 5, 1), 3, 512),        # 9 cuboids of 5 slots per sample: 5 groups (the last with ONE cuboid), 6 dead slots per group
 }
 
 
@@ -990,6 +990,36 @@ def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     e3 = rel_l2(out - xd, t - xd)
     print(f"[attn_ffn_pair {name}] update rel-L2 vs pd_attn_block_fused + pd_ffn_fused {e3:.3e}")
     assert e3 < 1.5e-3
+
+
+@pytest.mark.parametrize("Cn,shape,cuboid", [(256, (13, 16, 16), (13, 1, 1)), (256, (13, 16, 16), (1, 1, 16)), (256, (3, 5, 3), (1, 5, 1)),
+                                              (512, (13, 8, 8), (13, 1, 1)), (512, (13, 8, 8), (1, 8, 1)), (512, (3, 5, 3), (1, 5, 1))])
+def test_attn_ffn_pair_batch_independent(Cn, shape, cuboid):
+    """A trajectory's rows do not depend on the launch they ride in: 8 trajectories at once (units 256: two groups per wave, 128-row
+    tiles) == 4 + 4 == one alone (one group per wave) bit for bit -- the instantiations share every fp32 operation (no implicit
+    contraction in pair_block.hip) and 16-slot groups never straddle samples (the (3, 5, 3) case: 9 cuboids of 5 slots per sample, an odd
+    number, two per group).  This is what the engine's batch-split-reproducible mode (split_k = False) relies on."""
+    from prediff_amd.cuboid_geometry import attention_tables
+    from prediff_amd.packing import pack_pair_block, pack_pair_vecs
+    Hd, ntok = 4 * Cn, shape[0] * shape[1] * shape[2]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    x = r(8, ntok, Cn)
+    ws = pack_pair_block(r(3 * Cn, Cn, sc=Cn ** -0.5), r(Cn, Cn, sc=Cn ** -0.5), r(Hd, Cn, sc=Cn ** -0.5), r(Cn, Hd, sc=Hd ** -0.5))
+    tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+    vol = tabs["vol"]
+    vecs = pack_pair_vecs(1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), 1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), r(Hd, sc=.1), r(4, vol, vol, sc=.5))
+    tok = tabs["tok_index"].to(DEV)
+
+    def run(xx):
+        o = torch.full_like(xx, float("nan"))
+        L.attn_ffn_pair(xx, o, ws, vecs, tok, xx.shape[0], ntok, tabs["nc"], vol, (Cn // 4) ** -0.5, tok_affine=tabs["affine"], units=Cn)
+        torch.cuda.synchronize()
+        return o
+    o8 = run(x)
+    assert bool(torch.isfinite(o8).all())
+    assert torch.equal(o8[:4], run(x[:4].contiguous())) and torch.equal(o8[4:], run(x[4:].contiguous()))
+    assert torch.equal(o8[5:6], run(x[5:6].contiguous()))
 
 
 def test_attn_ffn_pair_rejects_what_it_does_not_run():
