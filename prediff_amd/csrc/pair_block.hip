@@ -37,8 +37,8 @@
 // bf16 rounding).  Every fused multiply-add below is written as one.
 #pragma clang fp contract(off)
 
-#define BLDS16(rsrc, ldsptr, voff, soff) \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
+#define BLDS16I(rsrc, ldsptr, voff, soff, imm) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), (imm), 0)
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
@@ -169,21 +169,32 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // Every wave copies a quarter of every chunk, as 8 pieces of 1 KB (one DMA instruction each); piece k of a wave belongs to chunk
   // k / 8.  The prologue issues chunks 0..2, then the 8 pieces of chunk c + 3 go out in one burst behind the mid-chunk barrier of
   // chunk c (everybody is past chunk c - 1, whose slot this is).
-  int n_piece = 0, kid = 0;                        // pieces issued by this wave; stream id of the chunk the next piece belongs to
+  // The instruction's immediate offset advances BOTH the global and the LDS address, so a burst needs two scalar address pairs (pieces
+  // 0..3 and 4..7 with immediates 0 / 1024 / 2048 / 3072), not eight: ~10 scalar instructions per chunk instead of ~110 (they were a
+  // fifth of all instructions the level-1 instantiation issued in its FFN loop).
+  int n_chunk = 0, kid = 0;                        // chunks requested by this wave; stream id of the next one
   const uint32_t dma_voff = (uint32_t)lane * 16u;
-  auto issue_piece = [&]() {
+  auto issue_chunk = [&]() {
 #if PD_PAIR_ABLATE & 1
-    if (n_piece >= 24) { ++n_piece; return; }
+    if (n_chunk >= 3) { ++n_chunk; return; }
 #endif
-    const int sub = n_piece & (DMA_PER_WAVE - 1);
-    char* d = smem + RING_OFF + ((n_piece >> 3) & (NSLOT - 1)) * CHUNK + wave * (DMA_PER_WAVE * 1024) + sub * 1024;
-    const uint32_t so = (uint32_t)kid * CHUNK + (uint32_t)wave * (DMA_PER_WAVE * 1024) + (uint32_t)sub * 1024u;
-    BLDS16(rW, d, dma_voff, so);
-    ++n_piece;
-    if (sub == DMA_PER_WAVE - 1) kid = (kid + 1 == CH_ALL) ? 0 : kid + 1;
+    char* d = smem + RING_OFF + (n_chunk & (NSLOT - 1)) * CHUNK + wave * (DMA_PER_WAVE * 1024);
+    const uint32_t so = (uint32_t)kid * CHUNK + (uint32_t)wave * (DMA_PER_WAVE * 1024);
+    BLDS16I(rW, d, dma_voff, so, 0);
+    BLDS16I(rW, d, dma_voff, so, 1024);
+    BLDS16I(rW, d, dma_voff, so, 2048);
+    BLDS16I(rW, d, dma_voff, so, 3072);
+    BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 0);
+    BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 1024);
+    BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 2048);
+    BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 3072);
+    ++n_chunk;
+    kid = (kid + 1 == CH_ALL) ? 0 : kid + 1;
   };
-#pragma unroll
-  for (int i = 0; i < 24; ++i) issue_piece();
+  static_assert(DMA_PER_WAVE == 8, "issue_chunk is written out for 8 pieces per wave");
+  issue_chunk();
+  issue_chunk();
+  issue_chunk();
 
   const uint32_t vbase = (uint32_t)(uintptr_t)(smem + RING_OFF) + (uint32_t)lane * 16u;   // fragment reads: lane-linear 16 B
   const uint32_t vtab = (uint32_t)(uintptr_t)smem + (uint32_t)g * 16u;                     // fp32 tables: 4 floats at column 4 g
@@ -232,7 +243,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       if (gi == 0) { EXTRA_STMT; }                                                                \
       if (gi == NFRAG / 4) {                                                                      \
         SYNC_STMT;                                                                                \
-        _Pragma("unroll") for (int i_ = 0; i_ < DMA_PER_WAVE; ++i_) issue_piece();                \
+        issue_chunk();                                                                            \
       }                                                                                           \
       PK_RD(2 * gi + PF);                                                                         \
       PK_RD(2 * gi + PF + 1);                                                                     \
