@@ -139,6 +139,11 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
 #ifndef PD_PAIR_ABLATE
 #define PD_PAIR_ABLATE 0
 #endif
+#ifndef PD_PAIR_GELU_SPREAD
+#define PD_PAIR_GELU_SPREAD 0         // one group per wave: 1 = gelu(h_j) one value every 2 / 4 fragment groups across all the chunks between W1_j and
+#endif                                // W2_j, 0 = all of it beside the first W1 chunk (one value per group).  A/B on one MI355X box, two
+                                      // rounds: units 512 at 32 trajectories 305 / 261 / 249 us spread vs 299 / 258 / 247 us; units 256 at
+                                      // 4 trajectories 48.4 / 46.1 / 46.8 vs 48.4 / 46.1 / 45.6 -- no gain: the groups are not issue bound
 #ifndef PD_PAIR_GELU_BOTH
 #define PD_PAIR_GELU_BOTH 1           // 1: gelu(h_j) split over the W2 and the W1 chunk between W1_j and W2_j; 0: all of it beside the W1 chunk
                                       // (A/B on MI355X, 32 trajectories, two rounds: 258-273 us either way -- the FFN iteration's time is a
@@ -591,19 +596,35 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     if ((GI) >= 2 && (GI) < 18) { const int v_ = (VB) + ((GI) - 2) * (NPER) + u_; PK_HV(H, v_) = PK_HV(H, v_) * __builtin_amdgcn_rcpf(gd[v_]); } \
   }
 #define PK_GELU_TAIL(H, VB, NPER) { PK_GELU_GROUP(H, VB, NPER, 16) PK_GELU_GROUP(H, VB, NPER, 17) }
+  // the same three stages for the 16 values of ONE group per wave, one value every SP fragment groups: stage k of value v runs in group
+  // SP v + k of a span of chunks (G counts the groups across them).  With two MFMAs per group (one group per wave) nine more VALU
+  // instructions in every group make the chunk issue bound; spread over all the chunks between W1_j and W2_j they disappear.
+#define PK_GELU_SP(H, SP, G)                                                                                              \
+  if (!(PD_PAIR_ABLATE & 8)) _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                           \
+    const int g_ = (G) - k_;                                                                                              \
+    if (g_ >= 0 && g_ % (SP) == 0 && g_ / (SP) < 16) {                                                                    \
+      const int v_ = g_ / (SP);                                                                                           \
+      if (k_ == 0) ga[v_] = pk_gelu_arg(PK_HV(H, v_));                                                                    \
+      if (k_ == 1) gd[v_] = 1.0f + __builtin_amdgcn_exp2f(ga[v_]);                                                        \
+      if (k_ == 2) PK_HV(H, v_) = PK_HV(H, v_) * __builtin_amdgcn_rcpf(gd[v_]);                                           \
+    }                                                                                                                     \
+  }
 #define PK_B1_FETCH(ADDR) { PK_LDS_F4(b1n[0], ADDR, 0); PK_LDS_F4(b1n[1], ADDR, 64); PK_LDS_F4(b1n[2], ADDR, 128); PK_LDS_F4(b1n[3], ADDR, 192); }
 #define PK_B1_LANDED() { PK_LANDED(b1n[0]); PK_LANDED(b1n[1]); PK_LANDED(b1n[2]); PK_LANDED(b1n[3]); }
 #define PK_PACK_H(H)                                                                                                       \
   _Pragma("unroll") for (int c = 0; c < NC; ++c) { hfr[c][0] = pk_pack8(H[c][0], H[c][1]); hfr[c][1] = pk_pack8(H[c][2], H[c][3]); }
     // W1 slice into ACC (its first chunk: the next slice's b1 from BADDR, HOOK0 in the shadow); W2 slice from hfr (HOOK0 beside its first chunk)
-#define PK_W1_SLICE(ACC, BADDR, HOOK0, TAIL0)                                                                              \
-  PK_CHUNK(PK_SYNC(PK_VMC0), 4, PK_B1_FETCH(BADDR), PK_B1_LANDED(), PK_MFMA_H(ACC, af, 0), HOOK0)                            \
-  TAIL0;                                                                                                                   \
-  if constexpr (NW == 2) PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_H(ACC, af, 1), (void)0)
-#define PK_W2_SLICE(HOOK0, TAIL0)                                                                                          \
-  PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), HOOK0)                                               \
-  TAIL0;                                                                                                                   \
-  if constexpr (NW == 2) PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1), (void)0)
+#define PK_W1_SLICE(ACC, BADDR, HOOK_A, TAIL_A, HOOK_B, TAIL_B)                                                             \
+  PK_CHUNK(PK_SYNC(PK_VMC0), 4, PK_B1_FETCH(BADDR), PK_B1_LANDED(), PK_MFMA_H(ACC, af, 0), HOOK_A)                           \
+  TAIL_A;                                                                                                                  \
+  if constexpr (NW == 2) { PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_H(ACC, af, 1), HOOK_B) TAIL_B; }
+#define PK_W2_SLICE(HOOK_A, TAIL_A, HOOK_B, TAIL_B)                                                                        \
+  PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), HOOK_A)                                              \
+  TAIL_A;                                                                                                                  \
+  if constexpr (NW == 2) { PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1), HOOK_B) TAIL_B; }
+  // gelu of ONE group per wave (NC == 1) spread over a span of chunks: SP = 32 / 16 groups per value when the span is 2 / ... chunks
+  constexpr int SP1 = CW == 2 ? 2 : 1;             // spans of one slice (W1_1, W2_{NJ-2}): NW chunks
+  constexpr int SP2 = 2 * SP1;                     // spans of two slices (W2_j, W1_{j+2})
     // b1 of slice 0: plain wait (the fragment prologue in flight is older and simply lands first)
     PK_B1_FETCH(vb1)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1n[0]), "+v"(b1n[1]), "+v"(b1n[2]), "+v"(b1n[3]));
@@ -613,7 +634,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
     const uint32_t vb1_1 = vb1 + 256u;
     // ---------------- h_0^T = W1_0 a^T + b1 (in its shadow: b1 of slice 1) ----------------
-    PK_W1_SLICE(hc, vb1_1, (void)0, (void)0)
+    PK_W1_SLICE(hc, vb1_1, (void)0, (void)0, (void)0, (void)0)
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -621,7 +642,13 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     PK_TRACE();   // W1_0 done
     // ---------------- h_1 beside the whole of gelu(h_0) (NC values per group); b1 of slice 2 ----------------
     const uint32_t vb1_2 = vb1 + 512u;
-    PK_W1_SLICE(hn, vb1_2, PK_GELU_GROUP(hc, 0, NC, gi), PK_GELU_TAIL(hc, 0, NC))
+    if constexpr (NC == 2) {
+      PK_W1_SLICE(hn, vb1_2, PK_GELU_GROUP(hc, 0, NC, gi), PK_GELU_TAIL(hc, 0, NC), (void)0, (void)0)
+    } else if constexpr (NW == 1) {
+      PK_W1_SLICE(hn, vb1_2, PK_GELU_SP(hc, 1, gi), { PK_GELU_SP(hc, 1, 16) PK_GELU_SP(hc, 1, 17) }, (void)0, (void)0)
+    } else {
+      PK_W1_SLICE(hn, vb1_2, PK_GELU_SP(hc, 2, gi), (void)0, PK_GELU_SP(hc, 2, 16 + gi), PK_GELU_SP(hc, 2, 32))
+    }
     bf16x8 hfr[NC][2];
     PK_PACK_H(hc)
     PK_TRACE();   // W1_1 done
@@ -635,14 +662,22 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
       const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < NJ ? j + 3 : 0) * 256u;
       if constexpr (NC == 2 && PD_PAIR_GELU_BOTH) {
         // x^T += W2[:, slice j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (group 0)
-        PK_W2_SLICE(PK_GELU_GROUP(hn, 0, 1, gi), PK_GELU_TAIL(hn, 0, 1))
+        PK_W2_SLICE(PK_GELU_GROUP(hn, 0, 1, gi), PK_GELU_TAIL(hn, 0, 1), (void)0, (void)0)
         // h_{j+2}^T = W1_{j+2} a^T + b1   beside the second half of gelu(h_{j+1}); b1 of slice j + 3
-        PK_W1_SLICE(hc, vb1n, PK_GELU_GROUP(hn, 16, 1, gi), PK_GELU_TAIL(hn, 16, 1))
-      } else {
+        PK_W1_SLICE(hc, vb1n, PK_GELU_GROUP(hn, 16, 1, gi), PK_GELU_TAIL(hn, 16, 1), (void)0, (void)0)
+      } else if constexpr (NC == 2) {
         // x^T += W2[:, slice j] gelu(h_j)^T
-        PK_W2_SLICE((void)0, (void)0)
+        PK_W2_SLICE((void)0, (void)0, (void)0, (void)0)
         // h_{j+2}^T = W1_{j+2} a^T + b1   beside the whole of gelu(h_{j+1}) (NC values per group); b1 of slice j + 3
-        PK_W1_SLICE(hc, vb1n, PK_GELU_GROUP(hn, 0, NC, gi), PK_GELU_TAIL(hn, 0, NC))
+        PK_W1_SLICE(hc, vb1n, PK_GELU_GROUP(hn, 0, NC, gi), PK_GELU_TAIL(hn, 0, NC), (void)0, (void)0)
+      } else if constexpr (!PD_PAIR_GELU_SPREAD) {
+        PK_W2_SLICE((void)0, (void)0, (void)0, (void)0)
+        PK_W1_SLICE(hc, vb1n, PK_GELU_SP(hn, 1, gi), { PK_GELU_SP(hn, 1, 16) PK_GELU_SP(hn, 1, 17) }, (void)0, (void)0)
+      } else {
+        // one group per wave: gelu(h_{j+1}) one value every SP2 groups across the chunks of W2_j and W1_{j+2}
+        PK_W2_SLICE(PK_GELU_SP(hn, SP2, gi), (void)0, PK_GELU_SP(hn, SP2, 16 + gi), (void)0)
+        PK_W1_SLICE(hc, vb1n, PK_GELU_SP(hn, SP2, 16 * NW + gi), (void)0, PK_GELU_SP(hn, SP2, 16 * NW + 16 + gi), (void)0)
+        if constexpr (NW == 1) { PK_GELU_SP(hn, SP2, 32) }      // (two chunks: stage 3 of the last value falls behind them)
       }
       PK_PACK_H(hn)
 #pragma unroll
@@ -654,12 +689,17 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     // W2_{NJ-2} beside the whole of gelu(h_{NJ-1}), then W2_{NJ-1}; the next tile's rows arrive beside the tile's last two chunks
     // (the LayerNorm fragments are dead: xn takes their registers)
     if constexpr (NW == 1) {
-      PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), { PK_GELU_GROUP(hn, 0, NC, gi) PK_LD_HOOK(1) })
-      PK_GELU_TAIL(hn, 0, NC)
+      if constexpr (NC == 2) {
+        PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), { PK_GELU_GROUP(hn, 0, NC, gi) PK_LD_HOOK(1) })
+        PK_GELU_TAIL(hn, 0, NC)
+      } else {
+        PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), { PK_GELU_SP(hn, 1, gi) PK_LD_HOOK(1) })
+        PK_GELU_SP(hn, 1, 16) PK_GELU_SP(hn, 1, 17)
+      }
       PK_PACK_H(hn)
       PK_CHUNK(PK_SYNC(VMC_E0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), PK_LD_HOOK(0))
     } else {
-      PK_W2_SLICE(PK_GELU_GROUP(hn, 0, NC, gi), PK_GELU_TAIL(hn, 0, NC))
+      PK_W2_SLICE(PK_GELU_SP(hn, 2, gi), (void)0, PK_GELU_SP(hn, 2, 16 + gi), PK_GELU_SP(hn, 2, 32))
       PK_PACK_H(hn)
       PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), PK_LD_HOOK(1))
       PK_CHUNK(PK_SYNC(VMC_E0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1), PK_LD_HOOK(0))
