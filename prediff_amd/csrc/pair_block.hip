@@ -52,10 +52,15 @@ constexpr int HEADS = 4;
 // one piece every second fragment group instead of a burst of 8 behind the mid-chunk barrier (3 % slower: with one wave per SIMD every
 // piece costs the wave its own issue slots either way), and a second barrier at the START of a chunk behind which chunk c + 3 is
 // requested (259-265 vs 250-258 us at 32 trajectories, 53 vs 50 us at 4: the stream is not DMA-latency bound).
-constexpr int PF = PD_PAIR_PF, PFN = 8;                     // weight fragments in flight (LDS latency ~ 4 x 32 MFMA clocks) / register slots: the slot of
-                                                   // fragment i is i % PFN in EVERY chunk, so PFN must divide the 32 fragments of a chunk
+#ifndef PD_PAIR_PF1
+#define PD_PAIR_PF1 4               // (4 / 6 / 8 in flight measured alike for both forms, two rounds on one box: 297-303 / 253-259 / 242-248 us at units
+#endif                              //  512, 254-258 / 241-249 / 230-248 us at units 256, 46-48 us at 4 trajectories: LDS latency is covered at 4)
+// weight fragments in flight (PD_PAIR_PF with two groups per wave, PD_PAIR_PF1 with one).  Register slots: the slot of fragment i is
+// i % PFN in EVERY chunk, so PFN must divide the 32 fragments of a chunk.
+template <int NC> struct FragPipe {
+  static constexpr int PF = NC == 2 ? PD_PAIR_PF : PD_PAIR_PF1, PFN = PF + 2 <= 8 ? 8 : 16;
+};
 constexpr int CHUNK = 32768, NSLOT = 4, NFRAG = 32;
-static_assert(NFRAG % PFN == 0 && PF + 2 <= PFN && PF % 2 == 0 && PF + 4 <= 15, "fragment pipeline geometry");
 constexpr int DMA_PER_WAVE = CHUNK / 4 / 1024;     // 8 x 1 KB per wave per chunk
 // geometry of one block width: CW = units / 256
 template <int CW>
@@ -128,14 +133,19 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
 #define PK_LDS_F4(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define PK_LANDED(v) asm volatile("" : "+v"(v))
 #define PK_DRAIN()                                                                                                        \
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), \
-               "+v"(w[7]))
+  {                                                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), \
+                 "+v"(w[7]));                                                                                             \
+    if constexpr (PFN == 16)                                                                                              \
+      asm volatile("" : "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15])); \
+  }
 
 #ifndef PD_PAIR_DEBUG
 #define PD_PAIR_DEBUG 0
 #endif
 // compile-time ablations for profiling builds (-DPD_PAIR_ABLATE=bits, scripts/ablate_pair.sh): 1 no weight DMA after the prologue,
-// 2 no fragment reads, 4 no MFMAs in the chunk bodies, 8 no GELU work in the chunk hooks, 16 no row loads / stores in the chunk hooks
+// 2 no fragment reads, 4 no MFMAs in the chunk bodies, 8 no GELU work in the chunk hooks, 16 no row loads / stores in the chunk hooks,
+// 32 no mid-chunk wait + barrier (timing only: the results are garbage)
 #ifndef PD_PAIR_ABLATE
 #define PD_PAIR_ABLATE 0
 #endif
@@ -159,6 +169,8 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   constexpr int T_LN1G = GG::T_LN1G, T_LN1B = GG::T_LN1B, T_BP = GG::T_BP, T_LN2G = GG::T_LN2G, T_LN2B = GG::T_LN2B, T_B2 = GG::T_B2,
                 T_B1 = GG::T_B1, T_RB = GG::T_RB, T_FLOATS = GG::T_FLOATS, RING_OFF = GG::RING_OFF, CH_ALL = GG::CH_ALL;
   static_assert(NC * CW <= 2, "a wave holds 32 x 256 or 16 x 512 fp32 row values");
+  constexpr int PF = FragPipe<NC>::PF, PFN = FragPipe<NC>::PFN;
+  static_assert(NFRAG % PFN == 0 && PF + 2 <= PFN && PF % 2 == 0 && PF + 4 <= 15, "fragment pipeline geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -232,7 +244,11 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // instructions separate two chunk loops the fragments in flight are drained first (PK_DRAIN).  scripts/check_async_lds.py replays
   // the LDS queue over the generated ISA and fails the build if any instruction touches a destination that is still in flight.
 #define PK_VMC0 8   /* chunks without hook traffic around them: the DMA pieces younger than chunk c + 1 */
+#if PD_PAIR_ABLATE & 32
+#define PK_SYNC(VMC) asm volatile("" ::"n"(VMC) : "memory")
+#else
 #define PK_SYNC(VMC) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VMC) : "memory")
+#endif
 #define PK_RD_ON (!(PD_PAIR_ABLATE & 2))
 #define PK_MFMA_ON (!(PD_PAIR_ABLATE & 4))
 #define PK_RD(i_)                                                                                 \
