@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   const int nk_all = ntap * kchunks;
   const int kslice = SK ? (int)blockIdx.y : 0;
   const int kt0 = SK ? (int)((int64_t)nk_all * kslice / p.ksplit) : 0;
-  const int nk = SK ? (int)((int64_t)nk_all * (kslice + 1) / p.ksplit) - kt0 : nk_all;
+  const int nk = (p.debug_flags & 1) ? 0 : SK ? (int)((int64_t)nk_all * (kslice + 1) / p.ksplit) - kt0 : nk_all;   // (bit 1: profiling, epilogue only)
   char* const dma_dst = smem + wave * (8 * 128);   // + half * HT + i * (64 * 128) + buffer * KBUF  (lane * 16 is implicit)
 
   auto set_tap = [&](int hh, int tap) {
@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   }
 #undef QUAD16
   if (wr == 0) __builtin_amdgcn_s_barrier();   // re-join the two wave rows
+  if (p.debug_flags & 2) return;               // (profiling: main loop only, nothing is stored)
 
   // ---- epilogue: two 32-column slabs per wave (8 waves x 128 x 32 fp32 = 128 KB = the operand buffers) ----
   float* sC = (float*)smem + wave * (128 * 32);
