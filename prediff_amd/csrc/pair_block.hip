@@ -160,8 +160,8 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
                                       // property of the chunk pair, the four waves meet at every chunk's barrier)
 #endif
 
-template <int NC, int CW>
-__global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
+template <int NC, int CW, int NWV = 4>
+__global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace pairk;
   using GG = G<CW>;
@@ -169,6 +169,8 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   constexpr int T_LN1G = GG::T_LN1G, T_LN1B = GG::T_LN1B, T_BP = GG::T_BP, T_LN2G = GG::T_LN2G, T_LN2B = GG::T_LN2B, T_B2 = GG::T_B2,
                 T_B1 = GG::T_B1, T_RB = GG::T_RB, T_FLOATS = GG::T_FLOATS, RING_OFF = GG::RING_OFF, CH_ALL = GG::CH_ALL;
   static_assert(NC * CW <= 2, "a wave holds 32 x 256 or 16 x 512 fp32 row values");
+  static_assert(NWV == 4 || (NWV == 8 && NC == 1 && CW == 1), "eight waves (two per SIMD, 256 registers each): 16 x 256 rows per wave only");
+  constexpr int DPW = NFRAG / NWV;                  // 1 KB DMA pieces per wave per chunk: 8 / 4
   constexpr int PF = FragPipe<NC>::PF, PFN = FragPipe<NC>::PFN;
   static_assert(NFRAG % PFN == 0 && PF + 2 <= PFN && PF % 2 == 0 && PF + 4 <= 15, "fragment pipeline geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   const int q = lane & 15, g = lane >> 4;
 
   // ---- tables -> LDS (before any DMA is in flight: a compiler-visible LDS store behind a DMA would drain it) ----
-  for (int i = tid; i < T_FLOATS; i += 256) ((float*)smem)[i] = p.vecs[i];
+  for (int i = tid; i < T_FLOATS; i += NWV * 64) ((float*)smem)[i] = p.vecs[i];
   __syncthreads();
 
   // ---- weight stream: chunk ids 0 .. CH_ALL-1 cyclically, chunk number n -> ring slot n & 3 ----
@@ -195,20 +197,22 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #if PD_PAIR_ABLATE & 1
     if (n_chunk >= 3) { ++n_chunk; return; }
 #endif
-    char* d = smem + RING_OFF + (n_chunk & (NSLOT - 1)) * CHUNK + wave * (DMA_PER_WAVE * 1024);
-    const uint32_t so = (uint32_t)kid * CHUNK + (uint32_t)wave * (DMA_PER_WAVE * 1024);
+    char* d = smem + RING_OFF + (n_chunk & (NSLOT - 1)) * CHUNK + wave * (DPW * 1024);
+    const uint32_t so = (uint32_t)kid * CHUNK + (uint32_t)wave * (DPW * 1024);
     BLDS16I(rW, d, dma_voff, so, 0);
     BLDS16I(rW, d, dma_voff, so, 1024);
     BLDS16I(rW, d, dma_voff, so, 2048);
     BLDS16I(rW, d, dma_voff, so, 3072);
-    BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 0);
-    BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 1024);
-    BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 2048);
-    BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 3072);
+    if constexpr (DPW == 8) {
+      BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 0);
+      BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 1024);
+      BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 2048);
+      BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 3072);
+    }
     ++n_chunk;
     kid = (kid + 1 == CH_ALL) ? 0 : kid + 1;
   };
-  static_assert(DMA_PER_WAVE == 8, "issue_chunk is written out for 8 pieces per wave");
+  static_assert(DPW == 8 || DPW == 4, "issue_chunk is written out for 8 or 4 pieces per wave");
   issue_chunk();
   issue_chunk();
   issue_chunk();
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
   // (PK_LANDED, no instruction) right after the wait that covers them and only that new value lives on; and wherever more than a few
   // instructions separate two chunk loops the fragments in flight are drained first (PK_DRAIN).  scripts/check_async_lds.py replays
   // the LDS queue over the generated ISA and fails the build if any instruction touches a destination that is still in flight.
-#define PK_VMC0 8   /* chunks without hook traffic around them: the DMA pieces younger than chunk c + 1 */
+#define PK_VMC0 DPW   /* chunks without hook traffic around them: the DMA pieces younger than chunk c + 1 */
 #if PD_PAIR_ABLATE & 32
 #define PK_SYNC(VMC) asm volatile("" ::"n"(VMC) : "memory")
 #else
@@ -319,7 +323,7 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     for (int c = 0; c < NC; ++c) {
       // group -> (sample, cuboids): groups never straddle samples, so where a cuboid sits inside its group -- and with it the order
       // in which its keys are summed -- does not depend on the batch the sample is launched in
-      const int64_t gi = (int64_t)tile * (4 * NC) + wave * NC + c;
+      const int64_t gi = (int64_t)tile * (NWV * NC) + wave * NC + c;
       const int b = (int)(gi / p.gps), cu = (int)(gi - (int64_t)b * p.gps) * p.pack + sub;
       int row = -1;
       if (b < p.B && cu < p.nc && sub < p.pack && slot < p.vol) {
@@ -473,9 +477,10 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
     // the heads, so ONE instantiation serves all four (head 0 differs in two wait counts only, a scalar branch):
     //     first chunk: 8 + 8 + 16 + 32 = 64 (-> 63, the field's maximum: a stronger wait);  second: 8 + 8 + 32 = 48;  from the third on: 8.
     constexpr bool IO32 = NC * CW == 2;
-    constexpr int VMC_E1 = 16, VMC_E0 = IO32 ? 32 : 24;
-    constexpr int VMC_T0 = CW == 2 ? 63 : IO32 ? 40 : 24, VMC_T1 = CW == 2 ? 48 : IO32 ? 40 : 24, VMC_T2 = CW == 2 ? 8 : IO32 ? 32 : 16,
-                  VMC_T3 = CW == 2 ? 8 : IO32 ? 16 : 8;
+    // (all of the above with 8 DMA pieces per wave and chunk; in general DPW + the hook instructions of the window)
+    constexpr int VMC_E1 = DPW + 8, VMC_E0 = DPW + (IO32 ? 24 : 16);
+    constexpr int VMC_T0 = CW == 2 ? 63 : DPW + (IO32 ? 32 : 16), VMC_T1 = CW == 2 ? 48 : DPW + (IO32 ? 32 : 16),
+                  VMC_T2 = CW == 2 ? DPW : DPW + (IO32 ? 24 : 8), VMC_T3 = CW == 2 ? DPW : DPW + (IO32 ? 8 : 0);
     // FM: 1 = the tile's first head at compile time (level 0: head 0 is its own instantiation, with the row stores in its hooks),
     // 0 = not the first, 2 = level 1: the wait counts of head 0 chosen at run time (h is uniform: a scalar branch)
 #define PK_SYNC_T(TP)                                                                                                       \
@@ -733,14 +738,14 @@ __global__ void __launch_bounds__(256, 1) pair_kernel(const pd_pair_args_k p) {
 #endif
 }
 
-template <int NC, int CW>
+template <int NC, int CW, int NWV = 4>
 static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   using namespace pairk;
   constexpr int LDS_BYTES = G<CW>::LDS_BYTES;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_ffn_pair: hipFuncSetAttribute(%d) failed: %s", LDS_BYTES, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -750,13 +755,16 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   // persistent: every workgroup takes the same number of tiles (the last few one less), one workgroup per CU
   const int per_wg = (a.ntiles + 255) / 256;
   const int grid = (a.ntiles + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL((pair_kernel<NC, CW>), dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((pair_kernel<NC, CW, NWV>), dim3((unsigned)grid), dim3(NWV * 64), LDS_BYTES, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
 
 extern "C" unsigned long long* pd_pair_trace = nullptr;
-extern "C" int pd_pair_force_nc = 0;             // A/B at units 256: 1 / 2 = 16-slot groups per wave whatever the grid; 0 = automatic
+extern "C" int pd_pair_force_nc = 0;             // A/B at units 256: 1 / 2 = 16-slot groups per wave (four waves), 8 = eight waves of one group, whatever the grid; 0 = automatic
+#ifndef PD_PAIR_BIG_FORM
+#define PD_PAIR_BIG_FORM 2                       // the form of the 128-row tiles: 2 (four waves x two groups) or 8 (eight waves x one group)
+#endif
 #if PD_PAIR_DEBUG
 extern "C" float* pd_pair_dbg_buf = nullptr;    // (profiling / debugging builds only: scripts/debug_pair.py)
 extern "C" int pd_pair_dbg_stage = 0;
@@ -805,9 +813,15 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
     a.ntiles = (int)((groups + 3) / 4);
     return launch_pair<1, 2>(a, (hipStream_t)stream);
   }
-  // two groups per wave (128-row tiles: every weight fragment feeds two MFMAs) once that leaves no CU idle; below that ONE group per
-  // wave (64-row tiles): twice the workgroups, half the MFMAs per streamed chunk -- the small-batch form
-  const int nc_wave = pd_pair_force_nc ? pd_pair_force_nc : ((groups + 7) / 8 > 128 ? 2 : 1);
+  // 128-row tiles once that leaves no CU idle -- as two groups per wave (four waves, every weight fragment feeds two MFMAs) or as
+  // eight waves of one group (two waves per SIMD, 256 registers each: one wave's LayerNorm / softmax / GELU / row traffic runs beside
+  // the other's MFMAs; pd_pair_force_nc = 8); below that ONE group per wave and four waves (64-row tiles): twice the workgroups,
+  // half the MFMAs per streamed chunk -- the small-batch form
+  const int nc_wave = pd_pair_force_nc ? pd_pair_force_nc : ((groups + 7) / 8 > 128 ? PD_PAIR_BIG_FORM : 1);
+  if (nc_wave == 8) {
+    a.ntiles = (int)((groups + 7) / 8);
+    return launch_pair<1, 1, 8>(a, (hipStream_t)stream);
+  }
   a.ntiles = (int)((groups + 4 * nc_wave - 1) / (4 * nc_wave));
   return nc_wave == 2 ? launch_pair<2, 1>(a, (hipStream_t)stream) : launch_pair<1, 1>(a, (hipStream_t)stream);
 }

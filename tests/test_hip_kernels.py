@@ -924,7 +924,8 @@ def _pair_case(name):
 
 @pytest.fixture
 def pair_nc(request):
-    """pd_pair_force_nc: cuboids per wave of pd_attn_ffn_pair (1 = 64-row tiles, the small-grid form; 2 = 128-row tiles)."""
+    """pd_pair_force_nc: the form of pd_attn_ffn_pair at units 256 (1 = four waves x one group: 64-row tiles, the small-grid form; 2 = four
+    waves x two groups, 8 = eight waves x one group: 128-row tiles)."""
     import ctypes
     v = ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc")
     old = v.value
@@ -933,7 +934,7 @@ def pair_nc(request):
     v.value = old
 
 
-@pytest.mark.parametrize("pair_nc", [1, 2], indirect=True)
+@pytest.mark.parametrize("pair_nc", [1, 2, 8], indirect=True)
 @pytest.mark.parametrize("name", list(PAIR_CASES))
 def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     """pd_attn_ffn_pair (csrc/pair_block.hip) against the oracle's statement of one (CuboidSelfAttentionLayer, PositionwiseFFN) pair
@@ -944,8 +945,8 @@ def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
     from prediff_amd.packing import pack_pair_block, pack_pair_vecs
     shape, cuboid, B, Cn, heads, Hd, sd_a, sd_f, x = _pair_case(name)
-    if Cn == 512 and pair_nc == 2:
-        pytest.skip("units 512: one group per wave only")
+    if Cn == 512 and pair_nc != 1:
+        pytest.skip("units 512: four waves x one group only")
     y1 = x + OU.cuboid_self_attention(sd_a, "", x, heads, cuboid, (0, 0, 0), LLL, "zeros")
     y_ref = OU.positionwise_ffn(sd_f, "", y1, "gelu")
     tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
@@ -1020,6 +1021,15 @@ def test_attn_ffn_pair_batch_independent(Cn, shape, cuboid):
     assert bool(torch.isfinite(o8).all())
     assert torch.equal(o8[:4], run(x[:4].contiguous())) and torch.equal(o8[4:], run(x[4:].contiguous()))
     assert torch.equal(o8[5:6], run(x[5:6].contiguous()))
+    if Cn == 256:                                       # the three forms of the units-256 kernel, forced
+        import ctypes
+        v = ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc")
+        try:
+            for form in (1, 2, 8):
+                v.value = form
+                assert torch.equal(run(x), o8), f"form {form} differs"
+        finally:
+            v.value = 0
 
 
 def test_attn_ffn_pair_rejects_what_it_does_not_run():
