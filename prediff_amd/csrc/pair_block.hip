@@ -57,8 +57,11 @@ constexpr int HEADS = 4;
 #endif                              //  512, 254-258 / 241-249 / 230-248 us at units 256, 46-48 us at 4 trajectories: LDS latency is covered at 4)
 // weight fragments in flight (PD_PAIR_PF with two groups per wave, PD_PAIR_PF1 with one).  Register slots: the slot of fragment i is
 // i % PFN in EVERY chunk, so PFN must divide the 32 fragments of a chunk.
-template <int NC> struct FragPipe {
-  static constexpr int PF = NC == 2 ? PD_PAIR_PF : PD_PAIR_PF1, PFN = PF + 2 <= 8 ? 8 : 16;
+#ifndef PD_PAIR_PF8
+#define PD_PAIR_PF8 4
+#endif
+template <int NC, int NWV> struct FragPipe {
+  static constexpr int PF = NWV == 8 ? PD_PAIR_PF8 : NC == 2 ? PD_PAIR_PF : PD_PAIR_PF1, PFN = PF + 2 <= 4 ? 4 : PF + 2 <= 8 ? 8 : 16;
 };
 constexpr int CHUNK = 32768, NSLOT = 4, NFRAG = 32;
 constexpr int DMA_PER_WAVE = CHUNK / 4 / 1024;     // 8 x 1 KB per wave per chunk
@@ -134,8 +137,8 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
 #define PK_LANDED(v) asm volatile("" : "+v"(v))
 #define PK_DRAIN()                                                                                                        \
   {                                                                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), \
-                 "+v"(w[7]));                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));                                 \
+    if constexpr (PFN >= 8) asm volatile("" : "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));                             \
     if constexpr (PFN == 16)                                                                                              \
       asm volatile("" : "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15])); \
   }
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
   static_assert(NC * CW <= 2, "a wave holds 32 x 256 or 16 x 512 fp32 row values");
   static_assert(NWV == 4 || (NWV == 8 && NC == 1 && CW == 1), "eight waves (two per SIMD, 256 registers each): 16 x 256 rows per wave only");
   constexpr int DPW = NFRAG / NWV;                  // 1 KB DMA pieces per wave per chunk: 8 / 4
-  constexpr int PF = FragPipe<NC>::PF, PFN = FragPipe<NC>::PFN;
+  constexpr int PF = FragPipe<NC, NWV>::PF, PFN = FragPipe<NC, NWV>::PFN;
   static_assert(NFRAG % PFN == 0 && PF + 2 <= PFN && PF % 2 == 0 && PF + 4 <= 15, "fragment pipeline geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -763,7 +766,7 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
 extern "C" unsigned long long* pd_pair_trace = nullptr;
 extern "C" int pd_pair_force_nc = 0;             // A/B at units 256: 1 / 2 = 16-slot groups per wave (four waves), 8 = eight waves of one group, whatever the grid; 0 = automatic
 #ifndef PD_PAIR_BIG_FORM
-#define PD_PAIR_BIG_FORM 2                       // the form of the 128-row tiles: 2 (four waves x two groups) or 8 (eight waves x one group)
+#define PD_PAIR_BIG_FORM 8                       // the form of the 128-row tiles: 2 (four waves x two groups) or 8 (eight waves x one group)
 #endif
 #if PD_PAIR_DEBUG
 extern "C" float* pd_pair_dbg_buf = nullptr;    // (profiling / debugging builds only: scripts/debug_pair.py)
