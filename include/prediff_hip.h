@@ -279,7 +279,7 @@ extern int pd_attn_block_debug_flags;  /* profiling ablations of the fused atten
 extern unsigned long long* pd_ffn_trace;         /* device buffer for per-phase clock stamps, or NULL (production) */
 extern unsigned long long* pd_attn_block_trace;  /* likewise */
 extern unsigned long long* pd_pair_trace;        /* likewise (pd_attn_ffn_pair; profiling builds) */
-extern int pd_pair_force_nc;           /* pd_attn_ffn_pair: 1 / 2 = cuboids per wave (64- / 128-row tiles) whatever the grid; 0 = automatic */
+extern int pd_pair_force_nc;           /* pd_attn_ffn_pair at units 256: 1 / 2 = groups per wave with four waves (64- / 128-row tiles), 8 = eight waves of one group (128-row tiles), whatever the grid; 0 = automatic */
 
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
  * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]

@@ -22,7 +22,9 @@
 //     ring, ONE barrier per chunk (= per 64 MFMAs of a wave) placed in the middle of the previous chunk so that the fragment
 //     pipeline never drains; every fragment feeds two MFMAs (the two cuboids): half the LDS bytes per MFMA of the old kernels;
 //   * persistent workgroups: the weight stream runs on across tiles, tile t+1's first chunks are in LDS before tile t ends.
-// 256 threads = 4 waves; tile = 128 rows = 8 cuboids; LDS 16 KB of tables + 128 KB ring.
+// Forms: <NC = 2, CW = 1> 4 waves x 32 rows (described above), <1, 1> 4 waves x 16 rows (64-row tiles: small grids), <1, 1, 8> 8 waves x 16
+// rows (two waves per SIMD, 226 registers: the 128-row form in use), <1, 2> 4 waves x 16 rows of 512 (units 512).  LDS 16 / 24 KB of
+// tables + 128 KB ring.
 // Numerics: those of the bf16 engine (bf16 LayerNorm output, q, k, v, P, O, hidden; fp32 accumulation, softmax, residual).  GELU is
 // evaluated as x * sigmoid(x (a + b x^2 + c x^4)) (max abs deviation from the erf form 2.5e-5, below the bf16 rounding of the hidden
 // activations that follows; 9 VALU instructions instead of 16).
