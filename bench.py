@@ -366,6 +366,8 @@ def main():
     ap.add_argument("--no-fused-attn", action="store_true")
     ap.add_argument("--no-pair", action="store_true", help="A/B: the level-0 (attention, FFN) pairs as the two round-3 launches instead of pd_attn_ffn_pair")
     ap.add_argument("--igemm-debug", type=int, default=0, help="A/B: OR-ed into every pd_igemm launch's debug_flags")
+    ap.add_argument("--pair-form", type=int, default=0, choices=[0, 1, 2, 8],
+                    help="A/B: form of pd_attn_ffn_pair at units 256 (1 / 2 = groups per wave with four waves, 8 = eight waves of one group; 0 = automatic)")
     ap.add_argument("--min-k-256", type=int, default=-1, help="A/B: shortest K (taps * Cin) the auto tile choice gives to the 256x256 kernel")
     ap.add_argument("--splitk-max-tiles", type=int, default=-1, help="A/B: split-K Conv3d only for launches of at most this many 256x256 tiles (0 = off)")
     ap.add_argument("--no-tile256", action="store_true", help="A/B: keep pd_igemm on the 128x128 kernel for the long-K launches")
@@ -426,6 +428,9 @@ def main():
     if args.igemm_debug:
         import ctypes
         ctypes.c_int.in_dll(L.lib(), "pd_igemm_debug_or").value = args.igemm_debug
+    if args.pair_form:
+        import ctypes
+        ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc").value = args.pair_form
     if args.min_k_256 >= 0:
         import ctypes
         ctypes.c_int.in_dll(L.lib(), "pd_igemm_256_min_k").value = args.min_k_256
