@@ -583,7 +583,7 @@ def main():
             "data": "synthetic (seeded random weights of the v1 architecture, N(0,1) latents/context)",
             "config": {"workload": WL["label"],
                        **({"operands": "e4m3 x e4m3 (scaled K=128 MFMA) for the 3x3x3 Conv3d launches and for the K >= 512 linears of the blocks that do not run "
-                                       "on the bf16 (attention, FFN) pair kernel (level-1 blocks below ~12 trajectories per launch, cuboid volumes > 16; "
+                                       "on the bf16 (attention, FFN) pair kernel (level-1 blocks below ~8 trajectories per launch, cuboid volumes > 16; "
                                        "e4m3 A operands written by LayerNorm, the attention core and the FFN-1 epilogue); bf16 in the pair kernel, "
                                        "the fused level-0 attention / FFN kernels, the K = 256 linears and the VAE"} if args.precision == "fp8" else
                           {"operands": "e4m3 x e4m3 (scaled K=128 MFMA) for the 3x3x3 Conv3d launches, bf16 elsewhere"} if args.precision == "fp8_conv" else {}),

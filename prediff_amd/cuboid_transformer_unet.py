@@ -350,7 +350,7 @@ class CuboidTransformerUNet(nn.Module):
         self.pair_units = {int(u) for u in os.environ.get("PD_PAIR_UNITS", "256,512").split(",") if u}   # A/B: block widths handed to it
         # units 512 (level 1): 64-row tiles that stream 6 MB of weights each -- below this many tiles (one per CU) the separate launches,
         # which spread the same rows over all CUs, are faster (scripts/sweep_pair_units.sh)
-        self.pair_l1_min_tiles = int(os.environ.get("PD_PAIR_L1_MIN_TILES", "150"))
+        self.pair_l1_min_tiles = int(os.environ.get("PD_PAIR_L1_MIN_TILES", "100"))
         self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)
