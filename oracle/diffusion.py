@@ -107,15 +107,28 @@ def ddim_step(zt: Tensor, eps: Tensor, a_t: Tensor, a_prev: Tensor, sigma: Tenso
     return a_prev.sqrt() * z0 + (1 - a_prev - sigma ** 2).clamp_min(0).sqrt() * eps + sigma * noise
 
 
+def cond_schedule(num_timesteps: int, num_timesteps_cond: int) -> np.ndarray:
+    """cond_ids of make_cond_schedule (latent_diffusion.py:295-299): the first num_timesteps_cond entries are that many levels spread
+    evenly over [0, T-1] (rounded half to even, as torch.round), every later entry is T-1."""
+    ids = np.full(num_timesteps, num_timesteps - 1, dtype=np.int64)
+    ids[:num_timesteps_cond] = np.rint(np.linspace(0.0, num_timesteps - 1, num_timesteps_cond, dtype=np.float32)).astype(np.int64)
+    return ids
+
+
 def ddpm_sample_loop(buf, denoiser: Callable, zc: Tensor, noise_tape: Sequence[Tensor], timesteps: int,
-                     align_fn: Optional[Callable] = None, clip_denoised=False) -> List[Tensor]:
+                     align_fn: Optional[Callable] = None, clip_denoised=False, cond_ids: Optional[np.ndarray] = None,
+                     cond_tape: Optional[Sequence[Tensor]] = None) -> List[Tensor]:
     """p_sample_loop with an explicit noise tape [x_T, n_{T-1}, ..., n_0].  latent_diffusion.py:633-684.
-    Returns [z_T, z_{T-1}, ..., z_0]."""
+    Returns [z_T, z_{T-1}, ..., z_0].  cond_ids / cond_tape: shorten_cond_schedule (:665-667) -- in front of step i the condition is
+    replaced by q_sample(condition, cond_ids[i], cond_tape[k]) (cumulatively: the re-noised condition is what the next step re-noises)."""
     z = noise_tape[0]
     traj = [z]
     B = z.shape[0]
     for k, i in enumerate(reversed(range(timesteps))):
         t = torch.full((B,), i, dtype=torch.long)
+        if cond_ids is not None:
+            lvl = int(cond_ids[i])
+            zc = float(buf["sqrt_alphas_cumprod"][lvl]) * zc + float(buf["sqrt_one_minus_alphas_cumprod"][lvl]) * cond_tape[k]
         eps = denoiser(z, t, zc)
         shift = align_fn(z, t) if align_fn is not None else None
         z = ddpm_step(buf, z, eps, t, noise_tape[1 + k], mean_shift=shift, clip_denoised=clip_denoised)

@@ -126,9 +126,11 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
         self.latent_shape = tuple(latent_shape)
         self.num_timesteps_cond = 1 if num_timesteps_cond is None else num_timesteps_cond
         assert self.num_timesteps_cond <= timesteps
-        if self.num_timesteps_cond > 1:
-            raise NotImplementedError("shorten_cond_schedule (num_timesteps_cond > 1) is not used by any shipped config")
-        self.shorten_cond_schedule = False
+        # num_timesteps_cond > 1: the conditioning latents are re-noised in front of every ancestral step (latent_diffusion.py:155-157,
+        # 295-299, 665-667; dead at every shipped config, "TODO: drop this option" in the reference) -- eager DDPM loop only
+        self.shorten_cond_schedule = self.num_timesteps_cond > 1
+        if self.shorten_cond_schedule:
+            self.make_cond_schedule()
         self.cond_stage_trainable = False
         self.scale_by_std = scale_by_std
         self.scale_factor = float(scale_factor)
@@ -304,6 +306,15 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
         return out[0] if isinstance(out, tuple) else out
 
     # ------------------------------------------------------------------------------------------------ reference-API math (torch ops)
+    def make_cond_schedule(self):
+        """cond_ids[i] = the noise level the conditioning latents get in front of step i: num_timesteps_cond levels spread evenly
+        over the schedule for the first num_timesteps_cond steps, the last level for every later one (latent_diffusion.py:295-299)."""
+        last = self.num_timesteps - 1
+        levels = torch.linspace(0, last, self.num_timesteps_cond).round().long()
+        ids = torch.full((self.num_timesteps,), last, dtype=torch.long)
+        ids[:self.num_timesteps_cond] = levels
+        self.register_buffer("cond_ids", ids)
+
     def q_sample(self, x_start, t, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise
         return (self.extract_into_tensor(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start +
@@ -459,7 +470,8 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
                       x_T=None, verbose=False, callback=None, timesteps=None, mask=None, x0=None, img_callback=None,
                       start_T=None, log_every_t=None, noise_tape=None):
         """Ancestral loop t = timesteps-1 .. 0 (latent_diffusion.py:633-684).  RNG draw order as the reference:
-        [x_T, noise_{T-1}, ..., noise_0] from the device's default generator, unless `noise_tape` supplies them."""
+        [x_T, noise_{T-1}, ..., noise_0] from the device's default generator, unless `noise_tape` supplies them.  With
+        shorten_cond_schedule every step draws the conditioning noise first: [x_T, c_{T-1}, noise_{T-1}, ..., c_0, noise_0]."""
         log_every_t = log_every_t or self.log_every_t
         device = self.betas.device
         B = shape[self.batch_axis]
@@ -477,8 +489,9 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
             timesteps = min(timesteps, start_T)
         if mask is not None:
             assert x0 is not None
+        shorten = self.shorten_cond_schedule          # the condition changes every step: eager path
         use_graph = (self.use_hip_graph and not use_alignment and self.parameterization == "eps" and img.is_cuda
-                     and isinstance(cond, torch.Tensor))      # a dict / None condition cannot be a static graph input: eager path
+                     and isinstance(cond, torch.Tensor) and not shorten)   # a dict / None condition cannot be a static graph input: eager path
         lanes = self._lanes("ddpm", B, cond, device, use_graph and mask is None and callback is None and img_callback is None
                             and not return_intermediates)
         if lanes is not None:
@@ -499,7 +512,7 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
         # knowledge alignment: the guidance gradient depends on z_t only, not on eps, so it runs (PyTorch autograd, caller's stream)
         # concurrently with the denoiser graphs of the lanes; the step epilogue joins them.  Same arithmetic as the eager path.
         eps_lanes = None
-        if use_alignment and self.use_hip_graph and self.parameterization == "eps" and img.is_cuda and isinstance(cond, torch.Tensor):
+        if use_alignment and self.use_hip_graph and self.parameterization == "eps" and img.is_cuda and isinstance(cond, torch.Tensor) and not shorten:
             # one denoiser graph on one side stream: the guidance is the concurrent second stream of work, and splitting the denoiser
             # into lanes as well only makes the three compete (measured at 32 / 8 trajectories: 33.4 / 11.6 ms per step with one
             # lane, 34.8 / 13.6 with two, 37.2 / 16.0 with four -- profiles/r02_j_time_alignment*.log).  `aligned_lanes` overrides.
@@ -518,7 +531,13 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
                 eps_lanes = ([self._graph_step("eps", B, cond, device, lane=0)], self._lane_streams[key][:1], B)
         st = self._graph_step("ddpm", B, cond, device) if use_graph else None
         for k, i in enumerate(reversed(range(0, timesteps))):
-            noise = noise_tape[1 + k].to(device) if noise_tape is not None else None
+            if shorten:
+                ts = torch.full((B,), i, device=device, dtype=torch.long)
+                cn = noise_tape[1 + 2 * k].to(device) if noise_tape is not None else torch.randn_like(cond)
+                cond = self.q_sample(cond, self.cond_ids[ts], noise=cn)       # (cumulative, as in the reference: `cond` is overwritten)
+                noise = noise_tape[2 + 2 * k].to(device) if noise_tape is not None else None
+            else:
+                noise = noise_tape[1 + k].to(device) if noise_tape is not None else None
             if eps_lanes is not None:
                 sts, streams, Bl = eps_lanes
                 ts = torch.full((B,), i, device=device, dtype=torch.long)
@@ -577,6 +596,8 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
         z_prev = sqrt(a_prev) z0 + sqrt(1 - a_prev - sigma^2) eps + sigma n, denoiser queried at t = steps[i]."""
         device = self.betas.device
         B = shape[self.batch_axis]
+        if self.shorten_cond_schedule:
+            raise NotImplementedError("shorten_cond_schedule (num_timesteps_cond > 1) is defined for the ancestral loop only")
         if not (1 <= int(ddim_steps) <= self.num_timesteps):
             raise ValueError(f"ddim_steps must be in [1, {self.num_timesteps}], got {ddim_steps}")
         if self.clip_denoised:

@@ -101,6 +101,9 @@ class LossEvaluationMixin:
             else:
                 assert cond is not None
                 zc = self.cond_stage_forward(cond)
+                if self.shorten_cond_schedule:          # (latent_diffusion.py:469-471: noise shaped like the RAW condition, as there)
+                    raw = cond if isinstance(cond, torch.Tensor) else cond["y"]
+                    zc = self.q_sample(zc, self.cond_ids[steps], noise=torch.randn_like(raw.float().to(dev)))
             return self.p_losses(z, zc, steps, noise=None)
 
     def training_step(self, batch, batch_idx):

@@ -284,6 +284,31 @@ def gen_diffusion():
     save("sample3", decoded=dec, latent=lat_out, tape=torch.stack(tape), zc=ldm.cond_stage_forward({"y": y}))
 
 
+def gen_cond_schedule():
+    """num_timesteps_cond > 1 (shorten_cond_schedule, reference latent_diffusion.py:155-157, 295-299, 665-667): the conditioning latents
+    are re-noised in front of every ancestral step.  Three steps of sample() on a recorded tape; draw order x_T, (c_i, noise_i) per step."""
+    cfg = TINY_UNET_CFGS["axial"]
+    net = R.CuboidTransformerUNet(**cfg)
+    reseed(net, 600)
+    vae = R.AutoencoderKL(**TINY_VAE_CFG)
+    reseed(vae, 601)
+    T_out, H, W, C = cfg["target_shape"]
+    ldm = R.LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(T_out, H * 4, W * 4, 1), timesteps=1000,
+                            beta_schedule="linear", use_ema=False, latent_shape=tuple(cfg["target_shape"]), first_stage_model=vae,
+                            cond_stage_model="__is_first_stage__", scale_factor=1.0, num_timesteps_cond=4).eval()
+    B = 2
+    lat = (B,) + tuple(cfg["target_shape"])
+    zc = seeded_input("dzc", (B,) + tuple(cfg["input_shape"]), 5)
+    torch.manual_seed(321)
+    out = ldm.p_sample_loop(cond=zc, shape=lat, timesteps=3)
+    torch.manual_seed(321)
+    xs, cs = [torch.randn(lat)], []
+    for _ in range(3):
+        cs.append(torch.randn_like(zc))
+        xs.append(torch.randn(lat))
+    save("cond_schedule", cond_ids=ldm.cond_ids, latent=out, tape_x=torch.stack(xs), tape_c=torch.stack(cs))
+
+
 def gen_training_side():
     """what the training side computes WITHOUT a gradient -- q_sample, the loss of a batch (p_losses, eval mode), the
     variational-bound weights, the EMA shadow update (utils/ema.py) and a validation-style evaluation with the EMA weights swapped in."""
@@ -459,9 +484,11 @@ def gen_nbody():
 
 def main():
     which = sys.argv[1:] or ["skill", "index", "attn", "small", "resblock", "tiny_unet", "v1_unet", "vae", "diffusion", "alignment",
-                             "v1_aligned", "nbody", "train_side"]
+                             "v1_aligned", "nbody", "train_side", "cond_schedule"]
     if "train_side" in which:
         gen_training_side()
+    if "cond_schedule" in which:
+        gen_cond_schedule()
     if "v1_aligned" in which:
         torch.set_grad_enabled(True)
         gen_v1_aligned()

@@ -157,6 +157,35 @@ def test_sample_end_to_end_with_vae(golden, precision):
     assert e_zc < tol and e_dec < tol
 
 
+def test_shorten_cond_schedule_vs_reference(golden):
+    """num_timesteps_cond = 4 (reference latent_diffusion.py:155-157, 295-299, 665-667): cond_ids bit-equal, and three ancestral steps
+    with the conditioning latents re-noised in front of each one against the reference's output on the same tapes (draw order
+    x_T, c_2, n_2, c_1, n_1, c_0, n_0); fp32-class engine, the bar of the plain loop."""
+    cfg = TINY_UNET_CFGS["axial"]
+    sd = seeded_state_dict(TP.unet_template(cfg, "tiny_unet_schema.json", "axial"), 600)
+    net = CuboidTransformerUNet(**cfg, precision="fp32")
+    net.load_state_dict(sd)
+    T_out, H, W, C = cfg["target_shape"]
+    ldm = LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(T_out, H * 4, W * 4, 1), timesteps=1000,
+                          beta_schedule="linear", use_ema=False, latent_shape=tuple(cfg["target_shape"]), first_stage_model=None,
+                          cond_stage_model=None, scale_factor=1.0, num_timesteps_cond=4).cuda().eval()
+    g = golden("cond_schedule")
+    assert ldm.shorten_cond_schedule and np.array_equal(ldm.cond_ids.cpu().numpy(), g["cond_ids"])
+    B = 2
+    lat = (B,) + tuple(cfg["target_shape"])
+    zc = seeded_input("dzc", (B,) + tuple(cfg["input_shape"]), 5).cuda()
+    tx, tc = torch.as_tensor(g["tape_x"]), torch.as_tensor(g["tape_c"])
+    tape = [tx[0]]
+    for k in range(3):
+        tape += [tc[k], tx[1 + k]]
+    out = ldm.p_sample_loop(cond=zc, shape=lat, timesteps=3, noise_tape=tape)
+    e = rel_l2(out, g["latent"])
+    print(f"[shorten_cond_schedule] 3-step loop vs reference {e:.3e}")
+    assert e < 1e-4
+    with pytest.raises(NotImplementedError):
+        ldm.ddim_sample_loop(zc, lat, ddim_steps=5)
+
+
 def test_ensemble_members_are_batch_split_invariant():
     """prediff_amd.ensemble on one GPU: a member's trajectory depends only on (base_seed, member id), not on how the
     members are batched (=> not on the world size either; the 2-rank gather logic is covered on CPU/gloo)."""

@@ -236,3 +236,24 @@ def test_pair_packing_layout(Cn):
             assert torch.equal(rb[:, a * vol:(a + 1) * vol, a * vol:(a + 1) * vol], bias)
             inside[a * vol:(a + 1) * vol, a * vol:(a + 1) * vol] = True
         assert bool(torch.isinf(rb[:, ~inside]).all()) and bool((rb[:, ~inside] < 0).all())
+
+
+def test_product_cond_schedule_vs_reference_golden():
+    """LatentDiffusion.make_cond_schedule (num_timesteps_cond > 1; reference latent_diffusion.py:295-299): cond_ids bit-equal to the
+    reference's buffer (no GPU: the module constructs on CPU)."""
+    import numpy as np
+    import torch
+    from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
+    from prediff_amd.latent_diffusion import LatentDiffusion
+    from _cases import TINY_UNET_CFGS
+    cfg = TINY_UNET_CFGS["axial"]
+    net = CuboidTransformerUNet(**cfg, precision="fp32")
+    for n_cond in (4, 1):
+        ldm = LatentDiffusion(torch_nn_module=net, layout="NTHWC", data_shape=(2, 32, 32, 1), timesteps=1000, use_ema=False,
+                              latent_shape=tuple(cfg["target_shape"]), first_stage_model=None, cond_stage_model=None,
+                              num_timesteps_cond=n_cond)
+        assert ldm.shorten_cond_schedule == (n_cond > 1)
+        if n_cond > 1:
+            g = np.load(os.path.join(ROOT, "tests", "golden", "cond_schedule.npz"))
+            assert ldm.cond_ids.dtype == torch.long and np.array_equal(ldm.cond_ids.numpy(), g["cond_ids"])
+            assert "cond_ids" in ldm.state_dict()           # a registered buffer, as in the reference

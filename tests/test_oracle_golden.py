@@ -257,6 +257,21 @@ def test_sample_loop(golden):
     assert rel_l2(dec, g["decoded"]) < 1e-4
 
 
+def test_cond_schedule_loop(golden):
+    """shorten_cond_schedule (num_timesteps_cond = 4): cond_ids bit-equal, three ancestral steps with the condition re-noised in front of
+    each one on the recorded tapes (reference latent_diffusion.py:295-299, 665-667)."""
+    g = golden("cond_schedule")
+    cfg, sd, _, buf = _tiny_ldm_state()
+    ids = OD.cond_schedule(1000, 4)
+    assert ids.dtype == g["cond_ids"].dtype and np.array_equal(ids, g["cond_ids"])
+    zc = seeded_input("dzc", (2,) + tuple(cfg["input_shape"]), 5)
+    traj = OD.ddpm_sample_loop(buf, lambda z, t, c: OU.unet_forward(sd, cfg, z, t, c), zc, [torch.as_tensor(v) for v in g["tape_x"]], 3,
+                               cond_ids=ids, cond_tape=[torch.as_tensor(v) for v in g["tape_c"]])
+    assert rel_l2(traj[-1], g["latent"]) < 1e-4
+    plain = OD.ddpm_sample_loop(buf, lambda z, t, c: OU.unet_forward(sd, cfg, z, t, c), zc, [torch.as_tensor(v) for v in g["tape_x"]], 3)
+    assert rel_l2(plain[-1], g["latent"]) > 1e-2          # the option matters on this input
+
+
 def test_ddim_self_consistency():
     """PARITY-UNPINNED DDIM rule: eta=0 is deterministic; z0 formula equals predict_start_from_noise."""
     buf = {k: torch.as_tensor(v) for k, v in OD.schedule_buffers(OD.beta_schedule("linear", 1000)).items()}
