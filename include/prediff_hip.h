@@ -279,6 +279,7 @@ extern int pd_attn_block_debug_flags;  /* profiling ablations of the fused atten
 extern unsigned long long* pd_ffn_trace;         /* device buffer for per-phase clock stamps, or NULL (production) */
 extern unsigned long long* pd_attn_block_trace;  /* likewise */
 extern unsigned long long* pd_pair_trace;        /* likewise (pd_attn_ffn_pair; profiling builds) */
+extern int pd_groupnorm_onepass;       /* pd_groupnorm_silu: 0 = always the statistics + apply pair of launches (A/B); default 1 = one pass where the shape allows */
 extern int pd_pair_force_nc;           /* pd_attn_ffn_pair at units 256: 1 / 2 = groups per wave with four waves (64- / 128-row tiles), 8 = eight waves of one group (128-row tiles), whatever the grid; 0 = automatic */
 
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs

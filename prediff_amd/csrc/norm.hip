@@ -409,6 +409,100 @@ __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restri
   }
 }
 
+// ---- one pass (round 4): a workgroup owns (sample, 32 or 16 channels) and keeps its S x 32 / 16 values in registers -- statistics (two-pass in
+// registers: mean, then the centred sum of squares) and the normalised bf16 rows from ONE read of x instead of two (the statistics
+// kernel's pass over the tensor is gone: 109 -> 0 MB per level-0 call at 32 trajectories).  NT threads, CH = 32 or 16 channels per
+// workgroup: CH / 4 threads per row segment (a float4 each), RMAX sweeps over the rows (<16, 512, 32> up to 1024 rows, <26, 512, 16> up
+// to 3328: 104 data registers per thread want the 256-register budget of 8 waves); the groups of the chunk (C / G = 4, 8, 16 or 32
+// channels) are reduced over the row lanes of a wave by shuffles and over the waves through LDS in a fixed order.  The choice of
+// this kernel depends on the shape only, never on the batch (the engine's batch-split-reproducible mode).
+template <int RMAX, int NT, int CH>
+__global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ ss_scale,
+                                                         const float* __restrict__ ss_shift, int ld_ss, pd_bf16* __restrict__ out, int S,
+                                                         int C, int G, float eps, int silu) {
+  constexpr int TPR = CH / 4, NWV = NT / 64, RP = NT / TPR;          // threads per row segment, waves, rows per sweep
+  __shared__ float sred[2][NWV][TPR];
+  // (sample, chunk) of this workgroup.  With 16-channel chunks a 128-byte line of a row is shared by TWO workgroups: they get ids 8
+  // apart -- the same XCD (workgroups go to the XCDs round robin), next to each other in its queue -- so that the line is fetched into
+  // one L2 once
+  int b, chunk;
+  {
+    const int per_row = C / CH;
+    int id = blockIdx.x;
+    if (CH == 16) {
+      const int h = (id >> 3) & 1, p = ((id >> 4) << 3) | (id & 7);    // pair index p, half h
+      id = 2 * p + h;
+    }
+    b = id / per_row;
+    chunk = id - b * per_row;
+  }
+  const int tid = threadIdx.x, slot = tid % TPR, rl = tid / TPR, wave = tid >> 6;
+  const int c = chunk * CH + slot * 4, cpg = C / G, spg = cpg >> 2;   // float4 slots per group: 1, 2, 4 (or 8 with 32-channel chunks)
+  // buffer addressing: the sample's rows behind one descriptor, lane offset in a VGPR, the sweep's offset in an SGPR -- no per-load
+  // address registers (35 in-flight 64-bit pointers were what spilled), and rows >= S read zeros / drop their stores by the range check
+  const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * S * C), 0, (uint32_t)((int64_t)S * C * 4), 0x00020000);
+  const auto rO = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * S * C), 0, (uint32_t)((int64_t)S * C * 2), 0x00020000);
+  const uint32_t voff = (uint32_t)(rl * C + c) * 4u, sstep = (uint32_t)(RP * C) * 4u;
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+  float4 v[RMAX];
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) {
+    const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rX, voff, (uint32_t)i * sstep, 0);
+    v[i] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+  }
+  // sum over the workgroup's values of this thread's group: row lanes of the wave (lane bits 3..5), the group's slots (lane bits
+  // 0..log2(spg)-1), then the 8 waves in order
+  auto group_sum = [&](float t, int buf) {
+#pragma unroll
+    for (int m = TPR; m < 64; m <<= 1) t += __shfl_xor(t, m);
+    for (int m = 1; m < spg; m <<= 1) t += __shfl_xor(t, m);
+    if ((tid & 63) < TPR) sred[buf][wave][slot] = t;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) tot += sred[buf][w][slot];
+    return tot;
+  };
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float cnt = (float)S * (float)cpg;
+  const float mean = group_sum(s, 0) / cnt;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) {
+    if (rl + RP * i < S) {
+      const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(group_sum(q, 1) / cnt + eps);
+  const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+  float a[4] = {rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w};
+  float d[4] = {be.x - mean * a[0], be.y - mean * a[1], be.z - mean * a[2], be.w - mean * a[3]};
+  if (ss_scale) {
+    const float4 sc = *(const float4*)(ss_scale + (int64_t)b * ld_ss + c), sh = *(const float4*)(ss_shift + (int64_t)b * ld_ss + c);
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] *= (1.f + scv[k]); d[k] = d[k] * (1.f + scv[k]) + shv[k]; }
+  }
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) {
+    float y[4] = {v[i].x * a[0] + d[0], v[i].y * a[1] + d[1], v[i].z * a[2] + d[2], v[i].w * a[3] + d[3]};
+    if (silu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.f + __expf(-y[k]));
+    }
+    const u32x2_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+    __builtin_amdgcn_raw_buffer_store_b64(o, rO, voff >> 1, ((uint32_t)i * sstep) >> 1, 0);
+    if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // (two rows at a time: an unbounded interleave of the 35 rows spilled)
+  }
+}
+
+extern "C" int pd_groupnorm_onepass = 1;         // A/B: 0 = always the statistics + apply pair of launches
+
 extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, const float* ss_scale,
                                  const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo, int B, int S,
                                  int C, int G, int ld_out, float eps, int silu, pd_stream_t stream) {
@@ -422,6 +516,13 @@ extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float
   const bool vec = (C % 4 == 0) && CV <= 256 && (256 % CV == 0) && (cpg % 4 == 0) && ld_out == C && G <= 256 &&
                    (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && (((uintptr_t)out | (uintptr_t)out_lo) & 7) == 0 &&
                    (!ss_scale || ((ld_ss % 4 == 0) && (((uintptr_t)ss_scale | (uintptr_t)ss_shift) & 15) == 0));
+  // bf16 engine (no lo half), 16-channel chunks holding whole groups, at most 26 x 128 rows: everything of a (sample, chunk) in registers
+  if (vec && pd_groupnorm_onepass && !out_lo && C % 32 == 0 && 16 % cpg == 0 && S <= 128 * 26 && ((int64_t)B * C / 16) % 16 == 0) {
+    if (S <= 64 * 16) hipLaunchKernelGGL((gn_onepass_kernel<16, 512, 32>), dim3(B * (C / 32)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, out, S, C, G, eps, silu);
+    else hipLaunchKernelGGL((gn_onepass_kernel<26, 512, 16>), dim3(B * (C / 16)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, out, S, C, G, eps, silu);
+    PD_CHECK_LAUNCH();
+    return PD_OK;
+  }
   if (vec) {
     hipLaunchKernelGGL(gn_stats_vec_kernel, dim3(nchunk, B), dim3(256), 0, s, x, partials, S, C, G);
     PD_CHECK_LAUNCH();

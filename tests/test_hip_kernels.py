@@ -238,6 +238,43 @@ def test_groupnorm_silu(B, S, Cn, G, silu):
         assert float(out[:, Cn:].float().abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,S,Cn,G,ss", [(2, 3328, 256, 32, False), (1, 3328, 256, 32, True), (2, 3000, 256, 32, False),
+                                         (3, 832, 512, 32, True), (2, 700, 256, 32, False), (2, 1024, 128, 32, False)])
+def test_groupnorm_silu_one_pass(B, S, Cn, G, ss):
+    """pd_groupnorm_silu with bf16 rows only (the bf16 engine's call): the one-pass kernel (a workgroup keeps a sample's S x 16 / 32
+    values in registers: statistics and normalised rows from one read of x) against torch's fp32 GroupNorm -> SiLU at the rounding
+    of the bf16 output, and against the statistics + apply pair of launches it replaces (fp64 partial sums there, a two-pass fp32
+    mean / centred variance here): the two agree on all but a few last-place roundings.  v1 level-0 / level-1 shapes, row tails,
+    per-sample scale / shift."""
+    import ctypes
+    g = torch.Generator(device="cpu").manual_seed(S + Cn + B)
+    x = (torch.randn(B, S, Cn, generator=g) * 2 + 0.7).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(Cn, generator=g)).to(DEV), torch.randn(Cn, generator=g).to(DEV)
+    sst = (0.3 * torch.randn(B, 2 * Cn, generator=g)).to(DEV) if ss else None
+    kw = dict(ss_scale=sst, ss_shift=sst[:, Cn:], ld_ss=2 * Cn) if ss else {}
+    part = torch.zeros(B * L.groupnorm_nchunk(S, Cn) * G * 2, dtype=torch.float64, device=DEV)
+    flag = ctypes.c_int.in_dll(L.lib(), "pd_groupnorm_onepass")
+    outs = []
+    try:
+        for mode in (1, 0):
+            flag.value = mode
+            out = torch.full((B * S, Cn), 7.0, dtype=torch.bfloat16, device=DEV)
+            L.groupnorm_silu(x, gamma, beta, part, out, None, B, S, Cn, G, Cn, 1e-5, silu=True, **kw)
+            torch.cuda.synchronize()
+            outs.append(out.float())
+    finally:
+        flag.value = 1
+    ref = F.group_norm(x.permute(0, 2, 1), G, gamma, beta, 1e-5)
+    if ss:
+        ref = ref * (1 + sst[:, :Cn, None]) + sst[:, Cn:, None]
+    ref = F.silu(ref).permute(0, 2, 1).reshape(B * S, Cn)
+    e1, e0 = rel_l2(outs[0], ref), rel_l2(outs[1], ref)
+    same = float((outs[0] == outs[1]).float().mean())
+    print(f"[groupnorm one pass B={B} S={S} C={Cn}] vs torch {e1:.3e} (two launches {e0:.3e}); identical elements {same:.5f}")
+    assert e1 < 3e-3 and abs(e1 - e0) < 2e-5
+    assert same > 0.995 and rel_l2(outs[0], outs[1]) < 3e-4
+
+
 @pytest.mark.parametrize("Cn", [64, 128])          # 64: generic kernels, 128: vectorised fast path
 def test_groupnorm_scale_shift(Cn):
     B, S, G = 2, 128, 32
