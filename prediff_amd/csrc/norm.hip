@@ -419,8 +419,8 @@ __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restri
 template <int RMAX, int NT, int CH>
 __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ ss_scale,
-                                                         const float* __restrict__ ss_shift, int ld_ss, pd_bf16* __restrict__ out, int S,
-                                                         int C, int G, float eps, int silu) {
+                                                         const float* __restrict__ ss_shift, int ld_ss, double* __restrict__ partials,
+                                                         int nchunk, pd_bf16* __restrict__ out, int S, int C, int G, float eps, int silu) {
   constexpr int TPR = CH / 4, NWV = NT / 64, RP = NT / TPR;          // threads per row segment, waves, rows per sweep
   __shared__ float sred[2][NWV][TPR];
   // (sample, chunk) of this workgroup.  With 16-channel chunks a 128-byte line of a row is shared by TWO workgroups: they get ids 8
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict_
   {
     const int per_row = C / CH;
     int id = blockIdx.x;
-    if (CH == 16) {
+    if (CH == 16 && id < ((int)gridDim.x & ~15)) {                     // (whole blocks of 16 ids; a tail keeps its order)
       const int h = (id >> 3) & 1, p = ((id >> 4) << 3) | (id & 7);    // pair index p, half h
       id = 2 * p + h;
     }
@@ -478,7 +478,17 @@ __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict_
       q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
   }
-  const float rstd = 1.0f / sqrtf(group_sum(q, 1) / cnt + eps);
+  const float var = group_sum(q, 1) / cnt;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  // `partials` keeps its contract -- the (sample, group)'s statistics as fp64 partial sums [b][chunk][g][sum, sum of squares], which
+  // pd_groupnorm_silu_bwd reduces again: everything in chunk 0 (mean * n and (var + mean^2) * n reproduce this kernel's mean and
+  // variance exactly in fp64), zeros in the others
+  if (rl == 0 && slot % spg == 0) {
+    double* pp = partials + (int64_t)b * nchunk * G * 2 + (c / cpg) * 2;
+    pp[0] = (double)mean * (double)cnt;
+    pp[1] = ((double)var + (double)mean * (double)mean) * (double)cnt;
+    for (int k = 1; k < nchunk; ++k) { pp[(int64_t)k * G * 2] = 0.0; pp[(int64_t)k * G * 2 + 1] = 0.0; }
+  }
   const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
   float a[4] = {rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w};
   float d[4] = {be.x - mean * a[0], be.y - mean * a[1], be.z - mean * a[2], be.w - mean * a[3]};
@@ -517,9 +527,9 @@ extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float
                    (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && (((uintptr_t)out | (uintptr_t)out_lo) & 7) == 0 &&
                    (!ss_scale || ((ld_ss % 4 == 0) && (((uintptr_t)ss_scale | (uintptr_t)ss_shift) & 15) == 0));
   // bf16 engine (no lo half), 16-channel chunks holding whole groups, at most 26 x 128 rows: everything of a (sample, chunk) in registers
-  if (vec && pd_groupnorm_onepass && !out_lo && C % 32 == 0 && 16 % cpg == 0 && S <= 128 * 26 && ((int64_t)B * C / 16) % 16 == 0) {
-    if (S <= 64 * 16) hipLaunchKernelGGL((gn_onepass_kernel<16, 512, 32>), dim3(B * (C / 32)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, out, S, C, G, eps, silu);
-    else hipLaunchKernelGGL((gn_onepass_kernel<26, 512, 16>), dim3(B * (C / 16)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, out, S, C, G, eps, silu);
+  if (vec && pd_groupnorm_onepass && !out_lo && C % 32 == 0 && 16 % cpg == 0 && S <= 128 * 26) {
+    if (S <= 64 * 16) hipLaunchKernelGGL((gn_onepass_kernel<16, 512, 32>), dim3(B * (C / 32)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, partials, nchunk, out, S, C, G, eps, silu);
+    else hipLaunchKernelGGL((gn_onepass_kernel<26, 512, 16>), dim3(B * (C / 16)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, partials, nchunk, out, S, C, G, eps, silu);
     PD_CHECK_LAUNCH();
     return PD_OK;
   }

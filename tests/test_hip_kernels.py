@@ -254,16 +254,23 @@ def test_groupnorm_silu_one_pass(B, S, Cn, G, ss):
     kw = dict(ss_scale=sst, ss_shift=sst[:, Cn:], ld_ss=2 * Cn) if ss else {}
     part = torch.zeros(B * L.groupnorm_nchunk(S, Cn) * G * 2, dtype=torch.float64, device=DEV)
     flag = ctypes.c_int.in_dll(L.lib(), "pd_groupnorm_onepass")
-    outs = []
+    outs, sums = [], []
     try:
         for mode in (1, 0):
             flag.value = mode
             out = torch.full((B * S, Cn), 7.0, dtype=torch.bfloat16, device=DEV)
+            part.fill_(float("nan"))
             L.groupnorm_silu(x, gamma, beta, part, out, None, B, S, Cn, G, Cn, 1e-5, silu=True, **kw)
             torch.cuda.synchronize()
             outs.append(out.float())
+            sums.append(part.reshape(B, -1, G, 2).sum(1))          # what pd_groupnorm_silu_bwd reduces `partials` to
     finally:
         flag.value = 1
+    # the partial-sum contract of `partials` holds on both paths: (sum, sum of squares) per (sample, group)
+    xg = x.double().reshape(B, S, G, Cn // G)
+    want = torch.stack([xg.sum((1, 3)), (xg * xg).sum((1, 3))], -1)
+    for sm in sums:
+        assert bool(torch.isfinite(sm).all()) and float(((sm - want).abs() / want.abs().clamp_min(1.0)).max()) < 1e-5
     ref = F.group_norm(x.permute(0, 2, 1), G, gamma, beta, 1e-5)
     if ss:
         ref = ref * (1 + sst[:, :Cn, None]) + sst[:, Cn:, None]
