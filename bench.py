@@ -366,6 +366,7 @@ def main():
     ap.add_argument("--no-fused-attn", action="store_true")
     ap.add_argument("--no-pair", action="store_true", help="A/B: the level-0 (attention, FFN) pairs as the two round-3 launches instead of pd_attn_ffn_pair")
     ap.add_argument("--igemm-debug", type=int, default=0, help="A/B: OR-ed into every pd_igemm launch's debug_flags")
+    ap.add_argument("--gn-two-launches", action="store_true", help="A/B: GroupNorm as the statistics + apply pair of launches instead of the one-pass kernel")
     ap.add_argument("--pair-form", type=int, default=0, choices=[0, 1, 2, 8],
                     help="A/B: form of pd_attn_ffn_pair at units 256 (1 / 2 = groups per wave with four waves, 8 = eight waves of one group; 0 = automatic)")
     ap.add_argument("--min-k-256", type=int, default=-1, help="A/B: shortest K (taps * Cin) the auto tile choice gives to the 256x256 kernel")
@@ -428,6 +429,9 @@ def main():
     if args.igemm_debug:
         import ctypes
         ctypes.c_int.in_dll(L.lib(), "pd_igemm_debug_or").value = args.igemm_debug
+    if args.gn_two_launches:
+        import ctypes
+        ctypes.c_int.in_dll(L.lib(), "pd_groupnorm_onepass").value = 0
     if args.pair_form:
         import ctypes
         ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc").value = args.pair_form
