@@ -56,6 +56,9 @@ CONV3D_LAUNCHES_PER_STEP = 34
 CONV3D_KERNEL_LABEL = "igemm256_kernel<2,8> | igemm_kernel<128,128,64,2,false,2,2,1> per launch (Conv3d 3x3x3 implicit GEMM)"
 
 
+AB_OPTS = {}        # prediff_amd._lib.CallOpts members set on every denoiser this run builds (--igemm-debug, --pair-form, ...)
+
+
 def v1_model(precision, device, workload="v1"):
     from prediff_amd import presets
     from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
@@ -63,6 +66,8 @@ def v1_model(precision, device, workload="v1"):
     from prediff_amd.seeding import seeded_state_dict
     w = WORKLOADS[workload]
     net = CuboidTransformerUNet(**getattr(presets, w["unet"]), precision=precision)
+    for k, v in AB_OPTS.items():          # A/B switches of the command line: per-module options (the library has no process-wide state)
+        setattr(net.opts, k, v)
     net.load_state_dict(seeded_state_dict(net.state_dict(), 1234))
     ldm = LatentDiffusion(torch_nn_module=net, first_stage_model=None, cond_stage_model=None, **getattr(presets, w["ldm"]))
     return ldm.to(device).eval()
@@ -349,7 +354,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="latent trajectories (ensemble members) per GPU")
     ap.add_argument("--streams", type=int, default=2, help="lanes: the batch advances as this many equal sub-batches on concurrent HIP streams")
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp32", "fp8", "fp8_conv"],
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32", "fp8", "fp8_conv"],
                     help="operand type; default: the one BASELINE.json quotes the workload on (v1: bf16, fullres: fp8)")
     ap.add_argument("--config", default="v1", choices=sorted(WORKLOADS), help="v1 = BASELINE configs[1] (the metric); fullres = configs[4] geometry, bf16")
     ap.add_argument("--no-graph", action="store_true")
@@ -427,24 +432,18 @@ def main():
     B = args.batch
     global CONV3D_KERNEL_LABEL
     if args.igemm_debug:
-        import ctypes
-        ctypes.c_int.in_dll(L.lib(), "pd_igemm_debug_or").value = args.igemm_debug
+        AB_OPTS["igemm_debug_or"] = args.igemm_debug
     if args.gn_two_launches:
-        import ctypes
-        ctypes.c_int.in_dll(L.lib(), "pd_groupnorm_onepass").value = 0
+        AB_OPTS["groupnorm_two_launches"] = 1
     if args.pair_form:
-        import ctypes
-        ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc").value = args.pair_form
+        AB_OPTS["pair_form"] = args.pair_form
     if args.min_k_256 >= 0:
-        import ctypes
-        ctypes.c_int.in_dll(L.lib(), "pd_igemm_256_min_k").value = args.min_k_256
+        AB_OPTS["igemm_min_k_256"] = max(args.min_k_256, 1)
     if args.splitk_max_tiles >= 0:
-        import ctypes
-        ctypes.c_int.in_dll(L.lib(), "pd_igemm_splitk_max_tiles").value = args.splitk_max_tiles
+        AB_OPTS["igemm_splitk_max_tiles"] = args.splitk_max_tiles if args.splitk_max_tiles > 0 else -1
     if args.no_tile256:
         CONV3D_KERNEL_LABEL = "igemm_kernel<128,128,64,2,false,2,2,1> (Conv3d 3x3x3 implicit GEMM)"
-        import ctypes
-        ctypes.c_int.in_dll(L.lib(), "pd_igemm_disable_256").value = 1
+        AB_OPTS["igemm_disable_256"] = 1
     ldm = v1_model(args.precision, device, args.config)
     ldm.torch_nn_module.fuse_ffn = not args.no_fused_ffn
     ldm.torch_nn_module.fuse_attn = not args.no_fused_attn
@@ -563,6 +562,21 @@ def main():
         ldm = ldm_bf16
         torch.cuda.empty_cache()
 
+    # ---- the same engine on IEEE-half operands (precision="fp16": 11-bit significands at the bf16 MFMA rate -- the TF32 class of the
+    #      reference's own GPU setting): full timed region of the headline configuration ----
+    fp16_line = None
+    if not args.no_extra and not args.no_graph and args.config == "v1" and args.precision == "bf16" and world == 1:
+        ldm_bf16 = ldm
+        ldm = v1_model("fp16", device, args.config)
+        k16 = min(args.steps, 20)
+        el16, S16 = timed_steps(B, args.streams, k16, 3)
+        fp16_line = {"value": round(B * k16 / el16, 2), "unit": "steps/s", "dtype": "fp16 operands, fp32 accumulate (TF32-class accuracy)",
+                     "steps": k16, "ms_per_step": round(el16 / k16 * 1e3, 4), "trajectories_per_gpu": B, "lanes": S16,
+                     "parity": "v1 DDIM-50 vs the oracle loop: tests/test_hip_configs.py::test_v1_ddim50_vs_oracle prints it beside the other modes"}
+        del ldm
+        ldm = ldm_bf16
+        torch.cuda.empty_cache()
+
     if rank == 0:
         n_gpus = world
         value = n_gpus * B * args.steps / elapsed
@@ -583,7 +597,7 @@ def main():
         line = {
             "metric": "denoising_steps_per_sec", "value": round(value, 2), "unit": "steps/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "bf16x3", "fp8": "fp8", "fp8_conv": "fp8"}[args.precision],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16", "fp32": "bf16x3", "fp8": "fp8", "fp8_conv": "fp8"}[args.precision],
             "data": "synthetic (seeded random weights of the v1 architecture, N(0,1) latents/context)",
             "config": {"workload": WL["label"],
                        **({"operands": "e4m3 x e4m3 (scaled K=128 MFMA) for the 3x3x3 Conv3d launches and for the K >= 512 linears of the blocks that do not run "
@@ -659,6 +673,8 @@ def main():
             line["small_batch"] = small                   # B in {1..16} beside the headline batch
         if fp32_line is not None:
             line["precision_fp32"] = fp32_line
+        if fp16_line is not None:
+            line["precision_fp16"] = fp16_line
         if not args.no_extra and args.config == "v1" and n_gpus == 1:
             line["vae"] = vae_times(device, trajectories=min(B, 32))
         if not args.no_cpu_baseline and n_gpus == 1 and args.config == "v1":

@@ -24,6 +24,29 @@ typedef uint16_t pd_bf16;    /* raw bfloat16 bits */
 
 enum pd_status { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_UNSUPPORTED = -2, PD_ERR_LAUNCH = -3 };
 enum pd_act { PD_ACT_NONE = 0, PD_ACT_GELU = 1, PD_ACT_SILU = 2, PD_ACT_LEAKY = 3, PD_ACT_RELU = 4 };
+/* Type of the 16-bit MFMA operands a call reads and writes (`pd_bf16` pointers then carry IEEE half bits): bfloat16 (8-bit mantissa, the
+ * throughput engine) or IEEE half (11-bit significand at the same MFMA rate: the TF32-class engine -- the reference runs fp32 with
+ * float32_matmul_precision "high", scripts/prediff/sevirlr/prediff_sevirlr_v1.yaml:63).  Weights must be packed in the same type.
+ * The hi/lo split (fp32-class) forms exist for bfloat16 only. */
+enum pd_operand { PD_OPERAND_BF16 = 0, PD_OPERAND_F16 = 1 };
+
+/* Per-call options of the entry points that read / write 16-bit operands or have an A/B switch: passed on every call, NULL = all
+ * defaults (bfloat16, production settings).  Nothing in this library is process-global: two engines in one process (the two-lane mode
+ * runs two, each from its own host thread) cannot see each other's settings.  All-zero = defaults. */
+typedef struct pd_call_opts {
+  int32_t operand;                  /* enum pd_operand */
+  int32_t attn_block_table_ids;     /* pd_attn_block_fused_ex: != 0 = load the token table even when an affine form is given (A/B; bit-identical) */
+  int32_t ffn_rows128;              /* pd_ffn_fused at units 256: != 0 = the 128-row kernel instead of ffn64_kernel (A/B) */
+  int32_t groupnorm_two_launches;   /* pd_groupnorm_silu: != 0 = always the statistics + apply pair of launches (A/B) */
+  int32_t pair_form;                /* pd_attn_ffn_pair at units 256: 1 / 2 = groups per wave with four waves (64- / 128-row tiles), 8 = eight
+                                       waves of one group (128-row tiles), whatever the grid; 0 = automatic */
+  int32_t ffn_debug_flags;          /* profiling ablations of the fused FFN (scripts/bench_ffn.py); 0 in production */
+  int32_t attn_block_debug_flags;   /* profiling ablations of the fused attention block (scripts/bench_attn_block.py) */
+  int32_t reserved;
+  unsigned long long* trace;        /* device buffer for per-phase clock stamps of the fused kernels (pd_ffn_fused, pd_attn_block_fused_ex,
+                                       pd_attn_ffn_pair in a -DPD_PAIR_DEBUG=1 build), or NULL (production) */
+} pd_call_opts;
+int pd_sizeof_call_opts(void);
 
 int pd_abi_version(void);
 const char* pd_last_error(void);
@@ -79,13 +102,17 @@ typedef struct pd_igemm_args {
   int32_t out_fp8_log2;    /* k > 0: out_bf16 points to OCP e4m3 BYTES (ld_outb counts bytes) and receives e4m3(v * 2^k), round to nearest
                               even, saturating at +-448 -- the A operand of a following fp8 launch (8-column vector epilogue: N % 8 == 0,
                               no out_bf16_lo; such a launch is never K-split, with or without `splitk_ws`).  0: bf16 output */
+  int32_t operand;         /* enum pd_operand: type of A, W and out_bf16 (no `split`, no `fp8` with PD_OPERAND_F16) */
+  int32_t disable_256;     /* A/B: != 0 = never hand this launch to the 256 x 256 kernel */
+  int32_t min_k_256;       /* A/B: smallest K (taps * Cin) of a launch the automatic choice gives to the 256 x 256 kernel; 0 = default (1024) */
+  int32_t splitk_max_tiles;/* A/B: split-K only for grids of at most this many 256 x 256 tiles; 0 = default (128), < 0 = never split */
 } pd_igemm_args;
 int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
 
 /* nn.LayerNorm(eps, affine) over the last dim C of fp32 rows -> bf16 (hi[, lo]) rows of ld_out elements
  * (pad columns [C, ld_out) are written as zero).  cuboid_transformer.py:813 (attn pre-norm), :197 (FFN pre-norm). */
 int pd_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
-                 int64_t rows, int C, int ld_out, float eps, pd_stream_t stream);
+                 int64_t rows, int C, int ld_out, float eps, const pd_call_opts* opts, pd_stream_t stream);
 
 /* pd_layernorm with an OCP e4m3 output (the A operand of an fp8 pd_igemm launch): out[row, c] = e4m3(y * fp8_scale), round to nearest
  * even, saturating at +-448; rows of ld_out bytes (pad columns zero). */
@@ -97,11 +124,11 @@ int pd_layernorm_fp8(const float* x, const float* gamma, const float* beta, uint
 int pd_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
                              int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
                              pd_stream_t stream);
-/* The same with the padding rule of the gather: pad_nearest != 0 = PatchMerging3D(padding_type="nearest") on a shape the down-sampling
+/* The same with per-call options and the padding rule of the gather: pad_nearest != 0 = PatchMerging3D(padding_type="nearest") on a shape the down-sampling
  * does not divide (models/utils.py:228-256: the padded grid is the nearest-neighbour resize of the tensor); 0 = zero padding. */
 int pd_patch_merge_layernorm_ex(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
                              int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps, int pad_nearest,
-                             pd_stream_t stream);
+                             const pd_call_opts* opts, pd_stream_t stream);
 
 /* nn.GroupNorm(G, C, eps) [+ optional (1+scale)*y+shift] [+ SiLU] over channels-last x (B, S, C) fp32 -> bf16 rows of
  * ld_out elements.  `partials` is caller workspace of B*nchunk*G*2 doubles (nchunk from pd_groupnorm_nchunk).
@@ -109,7 +136,7 @@ int pd_patch_merge_layernorm_ex(const float* x, const float* gamma, const float*
 int pd_groupnorm_nchunk(int S, int C);
 int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, const float* ss_scale,
                       const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo,
-                      int B, int S, int C, int G, int ld_out, float eps, int silu, pd_stream_t stream);
+                      int B, int S, int C, int G, int ld_out, float eps, int silu, const pd_call_opts* opts, pd_stream_t stream);
 
 /* The statistics pass of pd_groupnorm_silu alone: stats[b][g] = {mean, rstd} (fp32) of nn.GroupNorm(G, C, eps) over channels-last
  * x (B, S, C); partials as for pd_groupnorm_silu.  For consumers that normalise on the fly (pd_conv2d_gn_silu). */
@@ -123,7 +150,8 @@ int pd_groupnorm_stats(const float* x, double* partials, float* stats, int B, in
  * otherwise use pd_groupnorm_silu + pd_igemm. */
 int pd_conv2d_gn_silu_supported(int H, int W, int Cin, int Cout, int G);
 int pd_conv2d_gn_silu(const float* x, const float* stats, const float* gamma, const float* beta, const pd_bf16* W, const float* bias,
-                      const float* residual, float* out, int N, int H, int W_, int Cin, int Cout, int G, pd_stream_t stream);
+                      const float* residual, float* out, int N, int H, int W_, int Cin, int Cout, int G, const pd_call_opts* opts,
+                      pd_stream_t stream);
 
 /* pd_groupnorm_silu with an OCP e4m3 output (the A operand of an fp8 pd_igemm launch): out[b, s, c] = e4m3(y * fp8_scale),
  * round to nearest even, saturating at +-448; rows of C bytes.  C % 4 == 0, C/4 divides 256, 4 | C/G. */
@@ -143,7 +171,7 @@ int pd_groupnorm_silu_bwd(const float* x, const float* dy, const float* gamma, c
  * each rows_per_sample_in block) and zero padded columns.  Used for un-normalised GEMM inputs
  * (cuboid_transformer_unet.py:492 x[:, in_len:], time_embed.py:169 skip_connection input, cuboid_transformer.py:373). */
 int pd_cast_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t n_samples, int rows_per_sample_in, int row_off,
-                 int rows_per_sample_out, int C, int ld_in, int ld_out, pd_stream_t stream);
+                 int rows_per_sample_out, int C, int ld_in, int ld_out, const pd_call_opts* opts, pd_stream_t stream);
 
 /* Cuboid self-attention core: softmax(scale * q k^T + rel_pos_bias [masked]) v per (sample, cuboid, head).
  * qkv: (B, ntok, 3*C) rows [q | k | v], head h at columns h*hd; tok_index[(nc, vol)] = flat token id or -1 for a padded
@@ -168,6 +196,8 @@ typedef struct pd_cuboid_attn_args {
                                 RECEIVES the slot's result, -1 = nobody -- padding_type "nearest" on a non-divisible shape, where the padded grid
                                 is a nearest-neighbour resize of the tokens (several slots read one token) and the un-padding resizes back
                                 (models/utils.py:228-270).  Runs on the generic core. */
+  int32_t operand;           /* enum pd_operand: type of qkv_bf16 / out_bf16 (MFMA cores; the generic core reads either) */
+  int32_t reserved;
 } pd_cuboid_attn_args;
 int pd_cuboid_attention(const pd_cuboid_attn_args* a, pd_stream_t stream);
 
@@ -181,7 +211,7 @@ int pd_cuboid_attention_bwd(const float* qkv, const float* d_out, const int32_t*
 
 /* Row softmax of fp32 scores (rows, n) -> bf16 probabilities (taming/attention.py:176, computed in fp32). */
 int pd_softmax_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t rows, int n, int ld_in, int ld_out,
-                    pd_stream_t stream);
+                    const pd_call_opts* opts, pd_stream_t stream);
 
 /* Denoiser stem: cat([cond, x], T) + observation-indicator channel -> fp32 (B, T_in+T_out, H, W, C+1) rows of ld_out
  * elements.  cuboid_transformer_unet.py:425-428. */
@@ -227,7 +257,8 @@ int pd_nhwc_to_nchw(const float* x, float* out, int N, int C, int HW, int ld_in,
  * Supported when pd_ffn_fused_supported(C, Hd) (C in {64,128,256}, Hd % 64 == 0); otherwise use pd_layernorm + 2 x pd_igemm. */
 int pd_ffn_fused_supported(int C, int Hd);
 int pd_ffn_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* W1, const float* b1,
-                 const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, pd_stream_t stream);
+                 const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, const pd_call_opts* opts,
+                 pd_stream_t stream);
 
 /* Fused cuboid self-attention block, bf16 engine:  out = x + proj(attention(qkv(LayerNorm(x))))  for head_dim 64 and cuboid volume
  * <= 64 (CuboidSelfAttentionLayer.forward cuboid_transformer.py:812-966 + the residual of :1151), in place allowed (out == x).
@@ -245,7 +276,7 @@ int pd_attn_block_fused(const float* x, float* out, const float* gamma, const fl
 int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv, const float* bqkv,
                            const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias, const uint8_t* mask,
                            int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps, const int32_t* tok_affine,
-                           pd_stream_t stream);
+                           const pd_call_opts* opts, pd_stream_t stream);
 /* One (CuboidSelfAttentionLayer, PositionwiseFFN) pair of StackCuboidSelfAttentionBlock.forward (cuboid_transformer.py:1147-1156:
  * x = x + attn(x); x = ffn(x) with the FFN's own residual; attention :812-966, FFN :182-208) in ONE launch, bf16 engine, GELU, cuboid
  * volume <= 16, no qkv bias, no attention mask, for units 256 (4 heads of 64, hidden 1024: every level-0 axial layer of the SEVIR-LR
@@ -263,24 +294,7 @@ int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol, int act);
 int pd_attn_ffn_pair_cuboids_per_group(int vol);
 int pd_attn_ffn_pair(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
                      const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn,
-                     float eps_ffn, pd_stream_t stream);
-
-/* ---- Diagnostic / tuning globals (exported DATA symbols; bench.py, scripts/ and tests poke them through ctypes.in_dll for A/B
- * measurements -- production callers leave them alone).  Every one is process-global and read at launch time. */
-extern int pd_fused_opts;              /* bit 2: arithmetic token ids for affine cuboid tables in pd_attn_block_fused_ex (default 4 = on) */
-extern int pd_igemm_default_tile;      /* 0 = automatic tile choice, else the tile code forced for every pd_igemm launch */
-extern int pd_igemm_debug_or;          /* OR-ed into pd_igemm_args.debug_flags (bit 8: dense tap loop instead of tap skipping) */
-extern int pd_igemm_disable_256;       /* != 0: never hand a launch to the 256 x 256 kernel */
-extern int pd_igemm_256_min_k;         /* smallest K of a row-wise linear launch the 256 x 256 kernel takes */
-extern int pd_igemm_splitk_max_tiles;  /* split-K only for grids of at most this many 256 x 256 tiles */
-extern int pd_ffn_use_64;              /* != 0 (default): units-256 FFNs run ffn64_kernel (64-row tiles) */
-extern int pd_ffn_debug_flags;         /* profiling ablations of the fused FFN (scripts/bench_ffn.py) */
-extern int pd_attn_block_debug_flags;  /* profiling ablations of the fused attention block (scripts/bench_attn_block.py) */
-extern unsigned long long* pd_ffn_trace;         /* device buffer for per-phase clock stamps, or NULL (production) */
-extern unsigned long long* pd_attn_block_trace;  /* likewise */
-extern unsigned long long* pd_pair_trace;        /* likewise (pd_attn_ffn_pair; profiling builds) */
-extern int pd_groupnorm_onepass;       /* pd_groupnorm_silu: 0 = always the statistics + apply pair of launches (A/B); default 1 = one pass where the shape allows */
-extern int pd_pair_force_nc;           /* pd_attn_ffn_pair at units 256: 1 / 2 = groups per wave with four waves (64- / 128-row tiles), 8 = eight waves of one group (128-row tiles), whatever the grid; 0 = automatic */
+                     float eps_ffn, const pd_call_opts* opts, pd_stream_t stream);
 
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
  * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]

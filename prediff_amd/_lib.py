@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PD_LIB_PATH: another build of the same library (A/B of compiler flags); the default is the in-tree build
 LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libprediff_hip.so")
 
+ABI_VERSION = 2          # pd_abi_version() of the library this binding was written for
+
 ACT = {"none": 0, None: 0, "identity": 0, "gelu": 1, "silu": 2, "leaky": 3, "relu": 4}
 
 
@@ -32,14 +34,44 @@ class IgemmArgs(C.Structure):
                  "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw", "ut", "uh", "uw", "vT", "vH", "vW",
                  "rows_per_sample", "ld_rowvec", "ld_res", "res_period", "ld_mul", "act", "ld_out", "ld_outb", "split")] + \
                [("alpha", C.c_float), ("tile", C.c_int32), ("vec_epilogue", C.c_int32), ("a_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("debug_flags", C.c_int32), ("ksplit", C.c_int32),
-                ("splitk_ws", C.c_void_p), ("splitk_ws_elems", C.c_int64), ("fp8", C.c_int32), ("out_fp8_log2", C.c_int32)]
+                ("splitk_ws", C.c_void_p), ("splitk_ws_elems", C.c_int64), ("fp8", C.c_int32), ("out_fp8_log2", C.c_int32),
+                ("operand", C.c_int32), ("disable_256", C.c_int32), ("min_k_256", C.c_int32), ("splitk_max_tiles", C.c_int32)]
 
 
 class CuboidAttnArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("qkv_bf16", "qkv_f32", "tok_index", "bias", "mask", "out_bf16", "out_bf16_lo", "out_f32")] + \
                [(n, C.c_int32) for n in ("B", "ntok", "C", "heads", "nc", "vol", "ld_qkv", "ld_out")] + \
-               [("scale", C.c_float), ("force_generic", C.c_int32), ("out_fp8_log2", C.c_int32), ("tok_out", C.c_void_p)]
+               [("scale", C.c_float), ("force_generic", C.c_int32), ("out_fp8_log2", C.c_int32), ("tok_out", C.c_void_p),
+                ("operand", C.c_int32), ("reserved", C.c_int32)]
+
+
+OPERAND = {"bf16": 0, "fp16": 1}            # enum pd_operand
+
+
+class CallOpts(C.Structure):
+    """pd_call_opts: the per-call options of the library (operand type + A/B switches + profiling hooks).  A module owns one instance and
+    passes it on every launch: nothing is process-global.  All-zero = bfloat16 operands, production settings.  `igemm_*` are host-side
+    defaults the `igemm` wrapper copies into pd_igemm_args (the library's own struct has no such members)."""
+    _fields_ = [(n, C.c_int32) for n in ("operand", "attn_block_table_ids", "ffn_rows128", "groupnorm_two_launches", "pair_form",
+                                         "ffn_debug_flags", "attn_block_debug_flags", "reserved")] + [("trace", C.c_void_p)]
+
+    def __init__(self, operand="bf16", **kw):
+        super().__init__()
+        self.operand = OPERAND[operand] if isinstance(operand, str) else int(operand)
+        # pd_igemm_args members a caller may preset for every pd_igemm launch made with these options (A/B switches of bench.py / scripts)
+        self.igemm_tile = self.igemm_debug_or = self.igemm_disable_256 = self.igemm_min_k_256 = self.igemm_splitk_max_tiles = 0
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def dtype(self):
+        """torch dtype of the 16-bit operand buffers these options describe"""
+        return torch.float16 if self.operand == OPERAND["fp16"] else torch.bfloat16
+
+
+def _opts_ref(opts):
+    return C.byref(opts) if opts is not None else None
 
 
 _lib = None
@@ -49,23 +81,24 @@ _PROTOS = {
     "pd_last_error": (C.c_char_p, []),
     "pd_sizeof_igemm_args": (C.c_int, []),
     "pd_sizeof_cuboid_attn_args": (C.c_int, []),
+    "pd_sizeof_call_opts": (C.c_int, []),
     "pd_igemm": (C.c_int, [C.POINTER(IgemmArgs), C.c_void_p]),
-    "pd_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "pd_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.POINTER(CallOpts), C.c_void_p]),
     "pd_layernorm_fp8": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "pd_patch_merge_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_void_p]),
-    "pd_patch_merge_layernorm_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_int, C.c_void_p]),
+    "pd_patch_merge_layernorm_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_int, C.POINTER(CallOpts), C.c_void_p]),
     "pd_groupnorm_nchunk": (C.c_int, [C.c_int, C.c_int]),
     "pd_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 +
-                          [C.c_float, C.c_int, C.c_void_p]),
+                          [C.c_float, C.c_int, C.POINTER(CallOpts), C.c_void_p]),
     "pd_groupnorm_stats": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "pd_conv2d_gn_silu_supported": (C.c_int, [C.c_int] * 5),
-    "pd_conv2d_gn_silu": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_void_p]),
+    "pd_conv2d_gn_silu": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.POINTER(CallOpts), C.c_void_p]),
     "pd_groupnorm_silu_fp8": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "pd_groupnorm_silu_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
-    "pd_cast_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 6 + [C.c_void_p]),
+    "pd_cast_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 6 + [C.POINTER(CallOpts), C.c_void_p]),
     "pd_cuboid_attention": (C.c_int, [C.POINTER(CuboidAttnArgs), C.c_void_p]),
     "pd_cuboid_attention_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 9 + [C.c_float, C.c_void_p]),
-    "pd_softmax_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 3 + [C.c_void_p]),
+    "pd_softmax_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 3 + [C.POINTER(CallOpts), C.c_void_p]),
     "pd_unet_build_input": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]),
     "pd_timestep_embedding": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
     "pd_linear_small": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
@@ -78,11 +111,11 @@ _PROTOS = {
     "pd_ffn_fused_supported": (C.c_int, [C.c_int, C.c_int]),
     "pd_attn_block_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pd_attn_block_fused": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),
-    "pd_attn_block_fused_ex": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
-    "pd_ffn_fused": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "pd_attn_block_fused_ex": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p, C.POINTER(CallOpts), C.c_void_p]),
+    "pd_ffn_fused": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(CallOpts), C.c_void_p]),
     "pd_attn_ffn_pair_supported": (C.c_int, [C.c_int] * 5),
     "pd_attn_ffn_pair_cuboids_per_group": (C.c_int, [C.c_int]),
-    "pd_attn_ffn_pair": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float] * 3 + [C.c_void_p]),
+    "pd_attn_ffn_pair": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float] * 3 + [C.POINTER(CallOpts), C.c_void_p]),
     "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -101,11 +134,10 @@ def lib():
             f = getattr(l, name)      # AttributeError if a declared symbol is missing
             f.restype = res
             f.argtypes = args
-        if l.pd_sizeof_igemm_args() != C.sizeof(IgemmArgs) or l.pd_sizeof_cuboid_attn_args() != C.sizeof(CuboidAttnArgs):
-            raise PrediffHipError(f"{LIB_PATH} is stale: its argument structs do not match prediff_amd/_lib.py "
+        if (l.pd_sizeof_igemm_args() != C.sizeof(IgemmArgs) or l.pd_sizeof_cuboid_attn_args() != C.sizeof(CuboidAttnArgs)
+                or l.pd_sizeof_call_opts() != C.sizeof(CallOpts) or l.pd_abi_version() != ABI_VERSION):
+            raise PrediffHipError(f"{LIB_PATH} is stale: its ABI version / argument structs do not match prediff_amd/_lib.py "
                                   f"(rebuild with `make -C prediff_amd/csrc`)")
-        if os.environ.get("PD_FUSED_OPTS"):       # A/B measurements: engine switch of the fused level-0 kernels
-            C.c_int.in_dll(l, "pd_fused_opts").value = int(os.environ["PD_FUSED_OPTS"])
         _lib = l
     return _lib
 
@@ -154,10 +186,15 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
           A_lo=None, W_lo=None, bias=None, rowvec=None, rows_per_sample=0, residual=None, res_period=0,
           ld_res=None, mul=None, act="none", alpha=1.0, out_f32=None, out_bf16=None, out_bf16_lo=None,
           ld_out=None, ld_outb=None, nbatch=1, a_batch_stride=0, w_batch_stride=0, out_batch_stride=0,
-          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None, fp8=False, out_fp8_log2=0):
+          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None, fp8=False, out_fp8_log2=0, opts=None):
     """Thin wrapper around pd_igemm.  `geom` = dict(B,Ti,Hi,Wi,To,Ho,Wo,KT,KH,KW,st,sh,sw,pt,ph,pw,ut,uh,uw) or None
-    for a plain linear layer."""
+    for a plain linear layer.  `opts` (CallOpts): the operand type of A / W / out_bf16 and the caller's A/B presets for this launch."""
     a = IgemmArgs()
+    if opts is not None:
+        a.operand = 0 if fp8 else opts.operand          # (e4m3 operands: the 16-bit OUTPUT of such a launch is bfloat16)
+        tile = tile or opts.igemm_tile
+        debug_flags |= opts.igemm_debug_or
+        a.disable_256, a.min_k_256, a.splitk_max_tiles = opts.igemm_disable_256, opts.igemm_min_k_256, opts.igemm_splitk_max_tiles
     a.A, a.A_lo, a.W, a.W_lo = ptr(A), ptr(A_lo), ptr(W), ptr(W_lo)
     a.bias, a.rowvec, a.residual, a.mul = ptr(bias), ptr(rowvec), ptr(residual), ptr(mul)
     a.out_f32, a.out_bf16, a.out_bf16_lo = ptr(out_f32), ptr(out_bf16), ptr(out_bf16_lo)
@@ -204,8 +241,8 @@ def conv_geom(B, in_thw, kernel, stride=(1, 1, 1), pad=(1, 1, 1), up=(1, 1, 1), 
                 sw=stride[2], pt=pad[0], ph=pad[1], pw=pad[2], ut=up[0], uh=up[1], uw=up[2])
 
 
-def layernorm(x, gamma, beta, out, out_lo, rows, Cn, ld_out, eps=1e-5):
-    _check(lib().pd_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(out_lo), rows, Cn, ld_out, eps, stream_ptr()),
+def layernorm(x, gamma, beta, out, out_lo, rows, Cn, ld_out, eps=1e-5, opts=None):
+    _check(lib().pd_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(out_lo), rows, Cn, ld_out, eps, _opts_ref(opts), stream_ptr()),
            "pd_layernorm")
 
 
@@ -215,9 +252,10 @@ def layernorm_fp8(x, gamma, beta, out, rows, Cn, ld_out, fp8_scale, eps=1e-5):
            "pd_layernorm_fp8")
 
 
-def patch_merge_layernorm(x, gamma, beta, out, out_lo, B, T, H, W, Cn, ds, ld_out, eps=1e-5, pad_nearest=False):
+def patch_merge_layernorm(x, gamma, beta, out, out_lo, B, T, H, W, Cn, ds, ld_out, eps=1e-5, pad_nearest=False, opts=None):
     _check(lib().pd_patch_merge_layernorm_ex(ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(out_lo), B, T, H, W, Cn,
-                                             ds[0], ds[1], ds[2], ld_out, eps, 1 if pad_nearest else 0, stream_ptr()), "pd_patch_merge_layernorm")
+                                             ds[0], ds[1], ds[2], ld_out, eps, 1 if pad_nearest else 0, _opts_ref(opts), stream_ptr()),
+           "pd_patch_merge_layernorm")
 
 
 def groupnorm_nchunk(S, Cn):
@@ -225,9 +263,9 @@ def groupnorm_nchunk(S, Cn):
 
 
 def groupnorm_silu(x, gamma, beta, partials, out, out_lo, B, S, Cn, G, ld_out, eps, silu=True, ss_scale=None,
-                   ss_shift=None, ld_ss=0):
+                   ss_shift=None, ld_ss=0, opts=None):
     _check(lib().pd_groupnorm_silu(ptr(x), ptr(gamma), ptr(beta), ptr(ss_scale), ptr(ss_shift), ld_ss, ptr(partials),
-                                   ptr(out), ptr(out_lo), B, S, Cn, G, ld_out, eps, 1 if silu else 0, stream_ptr()),
+                                   ptr(out), ptr(out_lo), B, S, Cn, G, ld_out, eps, 1 if silu else 0, _opts_ref(opts), stream_ptr()),
            "pd_groupnorm_silu")
 
 
@@ -240,10 +278,10 @@ def conv2d_gn_silu_supported(H, W, Cin, Cout, G):
     return bool(lib().pd_conv2d_gn_silu_supported(H, W, Cin, Cout, G))
 
 
-def conv2d_gn_silu(x, stats, gamma, beta, W, bias, residual, out, N, H, Wd, Cin, Cout, G):
+def conv2d_gn_silu(x, stats, gamma, beta, W, bias, residual, out, N, H, Wd, Cin, Cout, G, opts=None):
     """GroupNorm -> SiLU -> Conv2d 3x3 (+ bias, + fp32 residual) in one launch (csrc/conv2d_gn.hip): the VAE ResBlock body."""
     _check(lib().pd_conv2d_gn_silu(ptr(x), ptr(stats), ptr(gamma), ptr(beta), ptr(W), ptr(bias), ptr(residual), ptr(out), N, H, Wd, Cin,
-                                   Cout, G, stream_ptr()), "pd_conv2d_gn_silu")
+                                   Cout, G, _opts_ref(opts), stream_ptr()), "pd_conv2d_gn_silu")
 
 
 def groupnorm_silu_fp8(x, gamma, beta, partials, out, B, S, Cn, G, eps, fp8_scale, silu=True, ss_scale=None, ss_shift=None, ld_ss=0):
@@ -256,14 +294,16 @@ def groupnorm_silu_bwd(x, dy, gamma, beta, fwd_partials, bwd_partials, dx, B, S,
                                        eps, 1 if silu else 0, stream_ptr()), "pd_groupnorm_silu_bwd")
 
 
-def cast_rows(x, out, out_lo, n_samples, rows_in, row_off, rows_out, Cn, ld_in, ld_out):
+def cast_rows(x, out, out_lo, n_samples, rows_in, row_off, rows_out, Cn, ld_in, ld_out, opts=None):
     _check(lib().pd_cast_rows(ptr(x), ptr(out), ptr(out_lo), n_samples, rows_in, row_off, rows_out, Cn, ld_in, ld_out,
-                              stream_ptr()), "pd_cast_rows")
+                              _opts_ref(opts), stream_ptr()), "pd_cast_rows")
 
 
 def cuboid_attention(*, qkv_bf16=None, qkv_f32=None, tok_index, bias, mask, out_bf16=None, out_bf16_lo=None,
-                     out_f32=None, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out, scale, force_generic=False, out_fp8_log2=0, tok_out=None):
+                     out_f32=None, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out, scale, force_generic=False, out_fp8_log2=0, tok_out=None,
+                     opts=None):
     a = CuboidAttnArgs()
+    a.operand = opts.operand if opts is not None else 0
     a.qkv_bf16, a.qkv_f32, a.tok_index, a.bias, a.mask = ptr(qkv_bf16), ptr(qkv_f32), ptr(tok_index), ptr(bias), ptr(mask)
     a.out_bf16, a.out_bf16_lo, a.out_f32 = ptr(out_bf16), ptr(out_bf16_lo), ptr(out_f32)
     a.B, a.ntok, a.C, a.heads, a.nc, a.vol, a.ld_qkv, a.ld_out = B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out
@@ -279,8 +319,8 @@ def cuboid_attention_bwd(*, qkv, d_out, tok_index, bias, mask, d_qkv, B, ntok, C
                                          vol, ld_qkv, ld_dout, ld_dqkv, scale, stream_ptr()), "pd_cuboid_attention_bwd")
 
 
-def softmax_rows(x, out, out_lo, rows, n, ld_in, ld_out):
-    _check(lib().pd_softmax_rows(ptr(x), ptr(out), ptr(out_lo), rows, n, ld_in, ld_out, stream_ptr()), "pd_softmax_rows")
+def softmax_rows(x, out, out_lo, rows, n, ld_in, ld_out, opts=None):
+    _check(lib().pd_softmax_rows(ptr(x), ptr(out), ptr(out_lo), rows, n, ld_in, ld_out, _opts_ref(opts), stream_ptr()), "pd_softmax_rows")
 
 
 def unet_build_input(x, cond, out, B, T_in, T_out, HW, Cn, ld_out):
@@ -340,30 +380,22 @@ def attn_block_fused_supported(Cn, heads, vol):
 
 
 def attn_block_fused(x, out, gamma, beta, Wqkv, bqkv, Wp, bp, tok_index, bias, mask, B, ntok, Cn, heads, nc, vol, scale, eps=1e-5,
-                     tok_affine=None):
+                     tok_affine=None, opts=None):
     """tok_affine: (n_inner, outer, inner, slot) from cuboid_geometry.affine_form(tok_index), or None (the kernel loads the table)."""
     aff = (C.c_int32 * 4)(*tok_affine) if tok_affine is not None else None
     _check(lib().pd_attn_block_fused_ex(ptr(x), ptr(out), ptr(gamma), ptr(beta), ptr(Wqkv), ptr(bqkv), ptr(Wp), ptr(bp), ptr(tok_index),
                                         ptr(bias), ptr(mask), B, ntok, Cn, heads, nc, vol, scale, eps,
-                                        C.cast(aff, C.c_void_p) if aff is not None else None, stream_ptr()), "pd_attn_block_fused")
-
-
-def fused_opts(value=None):
-    """pd_fused_opts (bit 2: arithmetic token ids for affine cuboid tables); returns the previous value."""
-    v = C.c_int.in_dll(lib(), "pd_fused_opts")
-    old = v.value
-    if value is not None:
-        v.value = int(value)
-    return old
+                                        C.cast(aff, C.c_void_p) if aff is not None else None, _opts_ref(opts), stream_ptr()),
+           "pd_attn_block_fused")
 
 
 def ffn_fused_supported(Cn, Hd):
     return bool(lib().pd_ffn_fused_supported(Cn, Hd))
 
 
-def ffn_fused(x, out, gamma, beta, W1, b1, W2, b2, M, Cn, Hd, act="gelu", eps=1e-5):
+def ffn_fused(x, out, gamma, beta, W1, b1, W2, b2, M, Cn, Hd, act="gelu", eps=1e-5, opts=None):
     _check(lib().pd_ffn_fused(ptr(x), ptr(out), ptr(gamma), ptr(beta), ptr(W1), ptr(b1), ptr(W2), ptr(b2), M, Cn, Hd, ACT[act], eps,
-                              stream_ptr()), "pd_ffn_fused")
+                              _opts_ref(opts), stream_ptr()), "pd_ffn_fused")
 
 
 def attn_ffn_pair_supported(Cn, heads, hidden, vol, act="gelu"):
@@ -374,10 +406,11 @@ def attn_ffn_pair_cuboids_per_group(vol):
     return 2 if 1 <= vol <= 8 else 1              # == pd_attn_ffn_pair_cuboids_per_group (tests/test_host_logic.py compares)
 
 
-def attn_ffn_pair(x, out, wstream, vecs, tok_index, B, ntok, nc, vol, scale, eps_attn=1e-5, eps_ffn=1e-5, tok_affine=None, units=256):
+def attn_ffn_pair(x, out, wstream, vecs, tok_index, B, ntok, nc, vol, scale, eps_attn=1e-5, eps_ffn=1e-5, tok_affine=None, units=256,
+                  opts=None):
     """One (CuboidSelfAttentionLayer, PositionwiseFFN) pair of a block (units 256 or 512) in one launch (csrc/pair_block.hip).
     wstream / vecs: packing.pack_pair_block / pack_pair_vecs."""
     aff = (C.c_int32 * 4)(*tok_affine) if tok_affine is not None else None
     _check(lib().pd_attn_ffn_pair(ptr(x), ptr(out), ptr(wstream), ptr(vecs), ptr(tok_index),
                                   C.cast(aff, C.c_void_p) if aff is not None else None, B, ntok, nc, vol, units, scale, eps_attn,
-                                  eps_ffn, stream_ptr()), "pd_attn_ffn_pair")
+                                  eps_ffn, _opts_ref(opts), stream_ptr()), "pd_attn_ffn_pair")

@@ -133,10 +133,15 @@ class AutoencoderKL(nn.Module):
         super().__init__()
         if act_fn not in ("silu", "swish"):
             raise NotImplementedError(f"act_fn={act_fn!r}: only SiLU is fused in the GroupNorm kernel")
-        if precision not in ("bf16", "fp32", "fp8", "fp8_conv"):
-            raise ValueError("precision must be 'bf16', 'fp32', 'fp8' or 'fp8_conv'")
-        # "fp8" is a denoiser option (e4m3 operands for its 3x3x3 convolutions); the VAE has no such launches and runs its bf16 engine
-        self.precision = "bf16" if precision.startswith("fp8") else precision
+        if precision not in ("bf16", "fp16", "fp32", "fp8", "fp8_conv"):
+            raise ValueError("precision must be 'bf16', 'fp16', 'fp32', 'fp8' or 'fp8_conv'")
+        # "fp8" is a denoiser option (e4m3 operands for its 3x3x3 convolutions); the VAE has no such launches and runs its bf16 engine.
+        # "fp16": the bf16 engine on IEEE-half operands (see CuboidTransformerUNet)
+        self.operand = "fp16" if precision == "fp16" else "bf16"
+        self.opts = L.CallOpts(self.operand)          # per-call options of every launch of this module (nothing is process-global)
+        self.op_dtype = self.opts.dtype
+        self.precision = "bf16" if (precision.startswith("fp8") or precision == "fp16") else precision
+        self.precision_name = precision
         self.fuse_resblock = True     # bf16 engine: GroupNorm -> SiLU -> Conv2d 3x3 of the ResBlocks as one launch (csrc/conv2d_gn.hip)
         self.latent_channels, self.norm_num_groups = latent_channels, norm_num_groups
         self.encoder = Encoder(in_channels, latent_channels, down_block_types, block_out_channels, layers_per_block, norm_num_groups)
@@ -153,10 +158,10 @@ class AutoencoderKL(nn.Module):
         P = {}
         for name, m in self.named_modules():
             if isinstance(m, nn.Conv2d):
-                P[name + ".w"] = pack_conv(m.weight.to(device), split)
+                P[name + ".w"] = pack_conv(m.weight.to(device), split, dtype=self.op_dtype)
                 P[name + ".b"] = m.bias.detach().float().contiguous().to(device)
             elif isinstance(m, nn.Linear):
-                P[name + ".w"] = pack_linear(m.weight.to(device), split)
+                P[name + ".w"] = pack_linear(m.weight.to(device), split, dtype=self.op_dtype)
                 P[name + ".b"] = m.bias.detach().float().contiguous().to(device)
             elif isinstance(m, nn.GroupNorm):
                 P[name + ".g"] = m.weight.detach().float().contiguous().to(device)
@@ -164,7 +169,7 @@ class AutoencoderKL(nn.Module):
         return P
 
     def _ensure_packed(self, device):
-        key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (str(device), self.precision, self.operand) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if key != self._packed_key:
             L.lib()
             self._packed, self._packed_key = self._pack(device), key
@@ -179,7 +184,7 @@ class AutoencoderKL(nn.Module):
         return t
 
     def _bf(self, name, rows, cols, device):
-        hi = self._buf(name, (rows, cols), torch.bfloat16, device)
+        hi = self._buf(name, (rows, cols), self.op_dtype, device)
         lo = self._buf(name + ".lo", (rows, cols), torch.bfloat16, device) if self.precision == "fp32" else None
         return hi, lo
 
@@ -187,14 +192,14 @@ class AutoencoderKL(nn.Module):
     def _cast(self, x, rows, C, name, dev):
         ld = pad64(C)
         a, alo = self._bf(name, rows, ld, dev)
-        L.cast_rows(x, a, alo, 1, rows, 0, rows, C, C, ld)
+        L.cast_rows(x, a, alo, 1, rows, 0, rows, C, C, ld, opts=self.opts)
         return a, alo, ld
 
     def _gn(self, P, name, x, N, S, C, dev, silu=True):
         ld = pad64(C)
         a, alo = self._bf("gn.a", N * S, ld, dev)
         part = self._buf("gn.part", (N * L.groupnorm_nchunk(S, C) * self.norm_num_groups * 2,), torch.float64, dev)
-        L.groupnorm_silu(x, P[name + ".g"], P[name + ".beta"], part, a, alo, N, S, C, self.norm_num_groups, ld, VAE_EPS, silu=silu)
+        L.groupnorm_silu(x, P[name + ".g"], P[name + ".beta"], part, a, alo, N, S, C, self.norm_num_groups, ld, VAE_EPS, silu=silu, opts=self.opts)
         return a, alo, ld
 
     def _conv(self, P, name, a, alo, ld, N, hw, Cout, out, dev, k=3, mode="same", residual=None):
@@ -214,7 +219,7 @@ class AutoencoderKL(nn.Module):
         else:
             raise ValueError(mode)
         L.igemm(a, w, A_lo=alo, W_lo=wlo, M=N * Ho * Wo, N=Cout, Cin=ld, taps=taps, w_tap_stride=Cout * ld, geom=geom,
-                bias=P[name + ".b"], residual=residual, out_f32=out)
+                bias=P[name + ".b"], residual=residual, out_f32=out, opts=self.opts)
         return Ho, Wo
 
     def _gn_conv(self, P, gn_name, conv_name, x, N, hw, Cin, Cout, out, dev, residual=None):
@@ -229,7 +234,7 @@ class AutoencoderKL(nn.Module):
             stats = self._buf("gn.stats", (N, G, 2), torch.float32, dev)
             L.groupnorm_stats(x, part, stats, N, S, Cin, G, VAE_EPS)
             L.conv2d_gn_silu(x, stats, P[gn_name + ".g"], P[gn_name + ".beta"], P[conv_name + ".w"][0], P[conv_name + ".b"], residual, out,
-                             N, H, W, Cin, Cout, G)
+                             N, H, W, Cin, Cout, G, opts=self.opts)
             return
         a, alo, ld = self._gn(P, gn_name, x, N, H * W, Cin, dev)
         self._conv(P, conv_name, a, alo, ld, N, hw, Cout, out, dev, residual=residual)
@@ -259,22 +264,22 @@ class AutoencoderKL(nn.Module):
         k, klo = self._bf("at.k", N * S, C, dev)
         for nm, (o, olo) in (("query", (q, qlo)), ("key", (k, klo))):
             w, wlo = P[f"{name}.{nm}.w"]
-            L.igemm(h, w, A_lo=hlo, W_lo=wlo, M=N * S, N=C, Cin=ld, bias=P[f"{name}.{nm}.b"], out_bf16=o, out_bf16_lo=olo)
+            L.igemm(h, w, A_lo=hlo, W_lo=wlo, M=N * S, N=C, Cin=ld, bias=P[f"{name}.{nm}.b"], out_bf16=o, out_bf16_lo=olo, opts=self.opts)
         # V^T per frame: vt[c, s] = sum_k Wv[c, k] h[s, k]   (the value bias is added after P V: softmax rows sum to 1)
         vt, vtlo = self._bf("at.vt", N * C, S, dev)
         wv, wvlo = P[name + ".value.w"]
         L.igemm(wv, h, A_lo=wvlo, W_lo=hlo, M=C, N=S, Cin=ld, lda=ld, ldw=ld, nbatch=N, a_batch_stride=0, w_batch_stride=S * ld,
-                out_bf16=vt, out_bf16_lo=vtlo, ld_outb=S, outb_batch_stride=C * S)
+                out_bf16=vt, out_bf16_lo=vtlo, ld_outb=S, outb_batch_stride=C * S, opts=self.opts)
         sc = self._buf("at.sc", (N * S, S), torch.float32, dev)
         L.igemm(q, k, A_lo=qlo, W_lo=klo, M=S, N=S, Cin=C, nbatch=N, a_batch_stride=S * C, w_batch_stride=S * C,
-                alpha=1.0 / math.sqrt(C), out_f32=sc, out_batch_stride=S * S)
+                alpha=1.0 / math.sqrt(C), out_f32=sc, out_batch_stride=S * S, opts=self.opts)
         p, plo = self._bf("at.p", N * S, S, dev)
-        L.softmax_rows(sc, p, plo, N * S, S, S, S)
+        L.softmax_rows(sc, p, plo, N * S, S, S, S, opts=self.opts)
         o, olo = self._bf("at.o", N * S, C, dev)
         L.igemm(p, vt, A_lo=plo, W_lo=vtlo, M=S, N=C, Cin=S, nbatch=N, a_batch_stride=S * S, w_batch_stride=C * S,
-                bias=P[name + ".value.b"], out_bf16=o, out_bf16_lo=olo, outb_batch_stride=S * C)
+                bias=P[name + ".value.b"], out_bf16=o, out_bf16_lo=olo, outb_batch_stride=S * C, opts=self.opts)
         wp, wplo = P[name + ".proj_attn.w"]
-        L.igemm(o, wp, A_lo=olo, W_lo=wplo, M=N * S, N=C, Cin=C, bias=P[name + ".proj_attn.b"], residual=x, out_f32=x)
+        L.igemm(o, wp, A_lo=olo, W_lo=wplo, M=N * S, N=C, Cin=C, bias=P[name + ".proj_attn.b"], residual=x, out_f32=x, opts=self.opts)
         return x
 
     def _mid(self, P, name, mid: UNetMidBlock2D, x, N, hw, C, dev):

@@ -19,6 +19,8 @@
 //    odd head sizes.
 #include "common.h"
 
+namespace PD_NS {
+
 // ------------------------------------------------------------------------------------------------- MFMA path
 // combine over the four 16-lane rows of the wave (v_permlane16_swap / v_permlane32_swap: one VALU instruction per exchange)
 __device__ __forceinline__ float attn_rows4_max(float v) {
@@ -68,13 +70,13 @@ __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_a
     s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int d0 = 0; d0 < hd; d0 += 32) {
-    bf16x8 qf = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (qtok >= 0) qf = *(const bf16x8*)(qrow + d0 + 8 * g);
+    op8 qf = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qtok >= 0) qf = *(const op8*)(qrow + d0 + 8 * g);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ktok[kt] >= 0) kf = *(const bf16x8*)(base + (int64_t)ktok[kt] * p.ld_qkv + p.C + d0 + 8 * g);
-      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s[kt], 0, 0, 0);
+      op8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ktok[kt] >= 0) kf = *(const op8*)(base + (int64_t)ktok[kt] * p.ld_qkv + p.C + d0 + 8 * g);
+      s[kt] = mfma_16x16x32(kf, qf, s[kt]);
     }
   }
   // lane: query `query`, keys kt*16 + 4g .. +3
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_a
     for (int r = 0; r < 4; ++r) {
       float v = s[kt][r] * inv;
       if (sc[kt][r] <= -1e18f) v = 0.f;   // masked_softmax multiplies by the mask after the softmax
-      pf[kt][r] = (short)f2bf(v);
+      pf[kt][r] = (short)f2op(v);
     }
 
   // ---- O^T[d][query] = sum_key V[key][d] P[query][key] ----
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_a
       s16x4 vf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) vf[r] = vtok[kt][r] >= 0 ? (short)vbase[(int64_t)vtok[kt][r] * p.ld_qkv + d0] : (short)0;
-      o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf[kt], o, 0, 0, 0);
+      o = mfma_16x16x16(vf, pf[kt], o);
     }
     // the result feeds inline asm (v_cvt_pk_bf16_f32) directly: hipcc does not insert the XDL-write -> VALU-read wait states for asm
     asm volatile("s_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
@@ -146,8 +148,8 @@ __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_a
         w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o[2] * f8s, -448.f), 448.f), fminf(fmaxf(o[3] * f8s, -448.f), 448.f), w, true);
         *(int*)((uint8_t*)p.out_bf16 + ((int64_t)b * p.ntok + qtok) * p.ld_out + h * hd + 4 * g + d0) = w;
       } else {
-        const uint32_t lo = pack_bf16x2(o[0], o[1]);
-        const uint32_t hi = pack_bf16x2(o[2], o[3]);
+        const uint32_t lo = pack_op2(o[0], o[1]);
+        const uint32_t hi = pack_op2(o[2], o[3]);
         *(uint2*)(orow + d0) = make_uint2(lo, hi);
       }
     }
@@ -180,11 +182,11 @@ __global__ void __launch_bounds__(256) cuboid_attn_flash_kernel(const pd_cuboid_
   const int* tokc = p.tok_index + (int64_t)c * vol;
   const int qtok = query < vol ? tokc[query] : -1;
   const pd_bf16* base = p.qkv_bf16 + (int64_t)b * p.ntok * p.ld_qkv + h * hd;
-  bf16x8 qf[hd / 32];
+  op8 qf[hd / 32];
 #pragma unroll
   for (int i = 0; i < hd / 32; ++i) {
-    qf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (qtok >= 0) qf[i] = *(const bf16x8*)(base + (int64_t)qtok * p.ld_qkv + 32 * i + 8 * g);
+    qf[i] = op8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (qtok >= 0) qf[i] = *(const op8*)(base + (int64_t)qtok * p.ld_qkv + 32 * i + 8 * g);
   }
   f32x4 o[NDT];
 #pragma unroll
@@ -199,9 +201,9 @@ __global__ void __launch_bounds__(256) cuboid_attn_flash_kernel(const pd_cuboid_
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < hd / 32; ++i) {
-      bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ktok >= 0) kf = *(const bf16x8*)(base + (int64_t)ktok * p.ld_qkv + p.C + 32 * i + 8 * g);
-      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i], s, 0, 0, 0);
+      op8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ktok >= 0) kf = *(const op8*)(base + (int64_t)ktok * p.ld_qkv + p.C + 32 * i + 8 * g);
+      s = mfma_16x16x32(kf, qf[i], s);
     }
     float sc[4], tmax = -3.0e38f;
     int vtok[4];
@@ -229,7 +231,7 @@ __global__ void __launch_bounds__(256) cuboid_attn_flash_kernel(const pd_cuboid_
     for (int r = 0; r < 4; ++r) {
       const float e = expf(sc[r] - m_new);          // exp(-inf) = 0 for non-existent keys
       tsum += e;
-      pf[r] = (short)f2bf(sc[r] <= -1e18f ? 0.f : e);
+      pf[r] = (short)f2op(sc[r] <= -1e18f ? 0.f : e);
     }
     l = l * alpha + attn_rows4_sum(tsum);
     m = m_new;
@@ -240,7 +242,7 @@ __global__ void __launch_bounds__(256) cuboid_attn_flash_kernel(const pd_cuboid_
       for (int r = 0; r < 4; ++r) vf[r] = vtok[r] >= 0 ? (short)vbase[(int64_t)vtok[r] * p.ld_qkv + 16 * i] : (short)0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[i][r] *= alpha;
-      o[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, o[i], 0, 0, 0);
+      o[i] = mfma_16x16x16(vf, pf, o[i]);
     }
   }
   if (qtok < 0) return;
@@ -250,7 +252,7 @@ __global__ void __launch_bounds__(256) cuboid_attn_flash_kernel(const pd_cuboid_
   for (int i = 0; i < NDT; ++i) {
     // lane: query, d = 16 i + 4g + r  (the accumulators are read by ordinary VALU code here: hipcc pads the MFMA hazard itself)
     const float v0 = o[i][0] * inv, v1 = o[i][1] * inv, v2 = o[i][2] * inv, v3 = o[i][3] * inv;
-    *(uint2*)(orow + 16 * i) = make_uint2((uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16));
+    *(uint2*)(orow + 16 * i) = make_uint2((uint32_t)f2op(v0) | ((uint32_t)f2op(v1) << 16), (uint32_t)f2op(v2) | ((uint32_t)f2op(v3) << 16));
   }
 }
 
@@ -260,7 +262,7 @@ __device__ __forceinline__ float ldq(const QT* p);
 template <>
 __device__ __forceinline__ float ldq<float>(const float* p) { return *p; }
 template <>
-__device__ __forceinline__ float ldq<pd_bf16>(const pd_bf16* p) { return bf2f(*p); }
+__device__ __forceinline__ float ldq<pd_bf16>(const pd_bf16* p) { return op2f(*p); }
 
 constexpr int GA_MAXVOL = 64;
 
@@ -329,15 +331,22 @@ __global__ void __launch_bounds__(256) cuboid_attn_generic_kernel(const pd_cuboi
         f2bf_split(a, hi, lo);
         p.out_bf16[o] = hi; p.out_bf16_lo[o] = lo;
       } else {
-        p.out_bf16[o] = f2bf(a);
+        p.out_bf16[o] = f2op(a);
       }
     }
   }
 }
 
-extern "C" int pd_cuboid_attention(const pd_cuboid_attn_args* pa, pd_stream_t stream) {
+#if !PD_IS_F16
+extern "C" int pd_f16_cuboid_attention(const pd_cuboid_attn_args*, pd_stream_t);
+extern "C" int pd_f16_softmax_rows(const float*, pd_bf16*, pd_bf16*, int64_t, int, int, int, const pd_call_opts*, pd_stream_t);
+#endif
+
+extern "C" int PD_ENTRY(cuboid_attention)(const pd_cuboid_attn_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(pa != nullptr, "pd_cuboid_attention: null args");
+  PD_FORWARD_F16(pa->operand == PD_OPERAND_F16, pd_f16_cuboid_attention(pa, stream));
   const pd_cuboid_attn_args a = *pa;
+  PD_CHECK_ARG(!PD_IS_F16 || !a.out_bf16_lo, "pd_cuboid_attention: the hi/lo split exists for bfloat16 operands only");
   PD_CHECK_ARG((a.qkv_bf16 != nullptr) != (a.qkv_f32 != nullptr), "pd_cuboid_attention: exactly one of qkv_bf16 / qkv_f32");
   PD_CHECK_ARG(a.tok_index && a.bias && (a.out_bf16 || a.out_f32), "pd_cuboid_attention: null pointer");
   PD_CHECK_ARG(a.heads > 0 && a.C % a.heads == 0 && a.vol > 0 && a.nc > 0, "pd_cuboid_attention: bad geometry");
@@ -397,6 +406,7 @@ extern "C" int pd_cuboid_attention(const pd_cuboid_attn_args* pa, pd_stream_t st
   return PD_OK;
 }
 
+#if !PD_IS_F16
 // ------------------------------------------------------------------------------------------------- data gradient (guidance network)
 // d(loss)/d(q, k, v) of the cuboid attention above, fp32 throughout, one workgroup per (sample, cuboid, head).  The probabilities are
 // recomputed from q, k and the bias (nothing but qkv is kept from the forward); with P = softmax(s q k^T + bias) (masked entries 0):
@@ -511,6 +521,8 @@ extern "C" int pd_cuboid_attention_bwd(const float* qkv, const float* d_out, con
   return PD_OK;
 }
 
+#endif   // !PD_IS_F16 (fp32 backward: one copy)
+
 // ------------------------------------------------------------------------------------------------- row softmax (VAE mid attention)
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ x, pd_bf16* __restrict__ out,
                                                            pd_bf16* __restrict__ out_lo, int64_t rows, int n, int ld_in, int ld_out) {
@@ -532,13 +544,15 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restri
       f2bf_split(v, hi, lo);
       out[row * ld_out + i] = hi; out_lo[row * ld_out + i] = lo;
     } else {
-      out[row * ld_out + i] = f2bf(v);
+      out[row * ld_out + i] = f2op(v);
     }
   }
 }
 
-extern "C" int pd_softmax_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t rows, int n, int ld_in, int ld_out,
-                               pd_stream_t stream) {
+extern "C" int PD_ENTRY(softmax_rows)(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t rows, int n, int ld_in, int ld_out,
+                                      const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_softmax_rows(x, out, out_lo, rows, n, ld_in, ld_out, opts, stream));
+  PD_CHECK_ARG(!PD_IS_F16 || !out_lo, "pd_softmax_rows: the hi/lo split exists for bfloat16 operands only");
   PD_CHECK_ARG(x && out && n > 0 && ld_in >= n && ld_out >= n, "pd_softmax_rows: bad args");
   if (rows <= 0) return PD_OK;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, out_lo, rows, n,
@@ -546,3 +560,5 @@ extern "C" int pd_softmax_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, in
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
+
+}  // namespace PD_NS

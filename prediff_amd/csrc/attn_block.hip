@@ -42,6 +42,8 @@
 #endif
 #include "ln_tile.h"
 
+namespace PD_NS {
+
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
 
@@ -229,10 +231,10 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
   // 16x16x32 fragments of the wave's 16 rows: [k-step of 32 (C/32)]; lane = (row l16, 8-element k group lg)
   const int l16 = lane & 15, lg = lane >> 4;
   const int swz16 = (l16 >> 1) & 7;
-  bf16x8 areg[KS * 2];
+  op8 areg[KS * 2];
 #pragma unroll
   for (int ks = 0; ks < KS * 2; ++ks)
-    areg[ks] = *(const bf16x8*)(sA + (ks >> 1) * (BM * 128) + (tq * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+    areg[ks] = *(const op8*)(sA + (ks >> 1) * (BM * 128) + (tq * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
   // validity of this lane's slots: q/k tiles = row tq*16 + l16; v tile = rows tq*16 + 4 lg + (0..3)
   const bool row_ok = sTok[tq * 16 + l16] >= 0;
   uint32_t vrow_ok = 0;
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
           // Hand-placed fragment pipeline (PF k-steps ahead).  Left to itself hipcc keeps ONE fragment register set and waits
           // lgkmcnt(0) in front of every MFMA pair (it re-serialises a source-level double buffer, too).  Opaque ds_reads +
           // counted waits + sched_barrier pin the order.
-          bf16x8 w[PF + 1][2];
+          op8 w[PF + 1][2];
           const uint32_t wb = (uint32_t)(uintptr_t)ring(s) + w_lane_off;
           WFRAG_PROLOGUE(w, wb)
 #pragma unroll
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
             WFRAG_STEP(w, wb, ks)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-              acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks % (PF + 1)][dt], areg[kh * NSTEP + ks], acc1[dt], 0, 0, 0);
+              acc1[dt] = mfma_16x16x32(w[ks % (PF + 1)][dt], areg[kh * NSTEP + ks], acc1[dt]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
           const int trow = tq * 16 + l16h;
           float v0 = acc1[dt][0] + bb[0], v1 = acc1[dt][1] + bb[1], v2 = acc1[dt][2] + bb[2], v3 = acc1[dt][3] + bb[3];
           if (!row_ok) v0 = v1 = v2 = v3 = 0.f;                 // a padded slot is a zero token (as in the un-fused path)
-          const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
+          const uint64_t pk = (uint64_t)(pack_op2(v0, v1)) | ((uint64_t)(pack_op2(v2, v3)) << 32);
           const int off = trow * 128 + (((d >> 3) ^ ((trow >> 1) & 7)) << 4) + ((d & 7) << 1);
           // opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell that the tiles and
           // the DMA destinations are disjoint LDS regions), which would serialise the prefetch at every step
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
       for (int kh = 0; kh < KH; ++kh) {
         const int s = NCH * h + 2 * KH + kh;
         if (!(p.dbg & 2)) {
-          bf16x8 w[PF + 1][2];
+          op8 w[PF + 1][2];
           const uint32_t wb = (uint32_t)(uintptr_t)ring(s) + w_lane_off;
           WFRAG_PROLOGUE(w, wb)
 #pragma unroll
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
             WFRAG_STEP(w, wb, ks)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-              acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[kh * NSTEP + ks], w[ks % (PF + 1)][dt], acc1[dt], 0, 0, 0);
+              acc1[dt] = mfma_16x16x32(areg[kh * NSTEP + ks], w[ks % (PF + 1)][dt], acc1[dt]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -353,7 +355,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
           if (!(vrow_ok & 2u)) v1 = 0.f;
           if (!(vrow_ok & 4u)) v2 = 0.f;
           if (!(vrow_ok & 8u)) v3 = 0.f;
-          const uint64_t pk = (uint64_t)(pack_bf16x2(v0, v1)) | ((uint64_t)(pack_bf16x2(v2, v3)) << 32);
+          const uint64_t pk = (uint64_t)(pack_op2(v0, v1)) | ((uint64_t)(pack_op2(v2, v3)) << 32);
           const int c4 = tq * 4 + lgh;                                             // 4-row group of the [d][64 rows] tile
           const int off = d * 128 + ((c4 ^ (d & 15)) << 3);                        // group XOR: conflict-free 8 B reads by (d, 4-row group)
           asm volatile("ds_write_b64 %0, %1" ::"v"(vt_lds + (uint32_t)off), "v"(pk) : "memory");
@@ -394,7 +396,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
         const int cbase = (wq / QPC) * RPC;               // first row of its cuboid
         const int qi = (wq % QPC) * 16 + q;               // query index inside the cuboid
         const int rswz = (row >> 1) & 7;
-        bf16x8 qf[2];
+        op8 qf[2];
 #pragma unroll
         for (int st = 0; st < 2; ++st)
           asm volatile("ds_read_b128 %0, %1" : "=v"(qf[st]) : "v"(q_lds + (uint32_t)(row * 128 + (((g + 4 * st) ^ rswz) << 4))));
@@ -407,15 +409,15 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
         for (int kt = 0; kt < KT; ++kt) {
           const int krow = cbase + kt * 16 + q;
           const int kswz = (krow >> 1) & 7;
-          bf16x8 kf[2];
+          op8 kf[2];
 #pragma unroll
           for (int st = 0; st < 2; ++st)
             asm volatile("ds_read_b128 %0, %1" : "=v"(kf[st]) : "v"(k_lds + (uint32_t)(krow * 128 + (((g + 4 * st) ^ kswz) << 4))));
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], z, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[1], t, 0, 0, 0);
+          f32x4 t = mfma_16x16x32(kf[0], qf[0], z);
+          t = mfma_16x16x32(kf[1], qf[1], t);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kt * 16 + 4 * g + r;
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
           for (int r = 0; r < 4; ++r) {
             float v = sc4[kt][r] * inv;
             if (masked & (1u << (kt * 4 + r))) v = 0.f;       // masked_softmax multiplies by the mask after the softmax
-            pf[kt][r] = (short)f2bf(v);
+            pf[kt][r] = (short)f2op(v);
           }
         // O^T[d][query] = sum over the key tiles of V^T (lane: d = 16 i + q, keys of 4-row group cbase/4 + 4 kt + g) x P^T
         f32x4 o[2];
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
           __builtin_amdgcn_sched_barrier(0);
           o[ii] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kt = 0; kt < KT; ++kt) o[ii] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[kt], pf[kt], o[ii], 0, 0, 0);
+          for (int kt = 0; kt < KT; ++kt) o[ii] = mfma_16x16x16(vf[kt], pf[kt], o[ii]);
         }
         // the waves of a pair read the same Q rows above and overwrite them with O below: everyone is past its Q reads first
         asm volatile("s_nop 15" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[0][3]), "+v"(o[1][0]), "+v"(o[1][1]), "+v"(o[1][2]), "+v"(o[1][3]));
@@ -471,7 +473,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
           const int dd = 16 * (2 * dhalf + ii) + 4 * g;
-          const uint64_t pk = (uint64_t)(pack_bf16x2(o[ii][0], o[ii][1])) | ((uint64_t)(pack_bf16x2(o[ii][2], o[ii][3])) << 32);
+          const uint64_t pk = (uint64_t)(pack_op2(o[ii][0], o[ii][1])) | ((uint64_t)(pack_op2(o[ii][2], o[ii][3])) << 32);
           const int off = row * 128 + (((dd >> 3) ^ rswz) << 4) + ((dd & 7) << 1);
           asm volatile("ds_write_b64 %0, %1" ::"v"(q_lds + (uint32_t)off), "v"(pk) : "memory");
         }
@@ -486,7 +488,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
       const int rswz = (row >> 1) & 7;
       // every fragment of the core in flight at once, through opaque reads (a visible LDS load makes hipcc drain the weight DMA
       // queue first -- vmcnt(0) -- because it cannot tell the tiles from the DMA destinations); consumed behind counted waits
-      bf16x8 kf[2], qf[2];
+      op8 kf[2], qf[2];
       f32x4 bq4;
       s16x4 vf[HD / 16];
 #pragma unroll
@@ -499,10 +501,10 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
       f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
       asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], sc4, 0, 0, 0);
+      sc4 = mfma_16x16x32(kf[0], qf[0], sc4);
       asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      sc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[1], sc4, 0, 0, 0);
+      sc4 = mfma_16x16x32(kf[1], qf[1], sc4);
       __builtin_amdgcn_sched_barrier(0);
       // V^T fragments (lane: d = 16 i + q, keys 4g..4g+3) do not depend on the softmax: requested once the K / Q fragments are
       // dead, their latency hides behind the softmax
@@ -544,7 +546,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
       for (int r = 0; r < 4; ++r) {
         float v = pr[r] * inv;
         if (sc[r] <= -1e18f) v = 0.f;   // masked_softmax multiplies by the mask after the softmax
-        pf[r] = (short)f2bf(v);
+        pf[r] = (short)f2op(v);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // the V^T fragments
       __builtin_amdgcn_sched_barrier(0);
@@ -554,7 +556,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
 #pragma unroll
       for (int i = 0; i < HD / 16; ++i) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        o[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[i], pf, z, 0, 0, 0);
+        o[i] = mfma_16x16x16(vf[i], pf, z);
       }
       // the MFMA results go straight into inline asm (v_cvt_pk_bf16_f32): hipcc's hazard recogniser does not look inside asm, so
       // the XDL-write -> VALU-read wait states have to be spelled out (the "+v" ties keep this between the MFMAs and the packs)
@@ -565,7 +567,7 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
       for (int i = 0; i < HD / 16; ++i) {
         // lane: query q, features 16 i + 4g + (0..3) -> O tile (the Q tile: these 16 rows belong to this wave only)
         const int dd = 16 * i + 4 * g;
-        const uint64_t pk = (uint64_t)(pack_bf16x2(o[i][0], o[i][1])) | ((uint64_t)(pack_bf16x2(o[i][2], o[i][3])) << 32);
+        const uint64_t pk = (uint64_t)(pack_op2(o[i][0], o[i][1])) | ((uint64_t)(pack_op2(o[i][2], o[i][3])) << 32);
         const int off = row * 128 + (((dd >> 3) ^ rswz) << 4) + ((dd & 7) << 1);
         asm volatile("ds_write_b64 %0, %1" ::"v"(q_lds + (uint32_t)off), "v"(pk) : "memory");
       }
@@ -579,17 +581,17 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
       const int s = NCH * h + 3 * KH + oh;
       const char* cW = ring(s);
       if (!(p.dbg & 8)) {
-        bf16x8 fa[2], fb[2];                       // two-deep fragment pipeline
+        op8 fa[2], fb[2];                       // two-deep fragment pipeline
         auto ldp = [&](int kk, int slot) {
           const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-          fa[slot] = *(const bf16x8*)(sQ + g2_a_row + pos);
-          fb[slot] = *(const bf16x8*)(cW + g2_b_row + pos);
+          fa[slot] = *(const op8*)(sQ + g2_a_row + pos);
+          fb[slot] = *(const op8*)(cW + g2_b_row + pos);
         };
         ldp(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           if (kk + 1 < 4) ldp(kk + 1, (kk + 1) & 1);
-          acc2[oh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1], acc2[oh], 0, 0, 0);
+          acc2[oh] = mfma_32x32x16(fa[kk & 1], fb[kk & 1], acc2[oh]);
         }
       }
       step_end(s);
@@ -658,22 +660,26 @@ static int launch_attn_block(const pd_attn_block_args_k& a, hipStream_t s) {
   return PD_OK;
 }
 
-extern "C" int pd_attn_block_debug_flags = 0;
-extern "C" unsigned long long* pd_attn_block_trace = nullptr;   // profiling ablations only (scripts/bench_attn_block.py)
-
+#if !PD_IS_F16
 extern "C" int pd_attn_block_fused_supported(int C, int heads, int vol) {
   return (C == 256 || C == 128) && heads * 64 == C && vol >= 1 && vol <= 64;
 }
+extern "C" int pd_f16_attn_block_fused_ex(const float*, float*, const float*, const float*, const pd_bf16*, const float*, const pd_bf16*, const float*,
+                                          const int32_t*, const float*, const uint8_t*, int, int, int, int, int, int, float, float, const int32_t*,
+                                          const pd_call_opts*, pd_stream_t);
+#else
+extern "C" int pd_attn_block_fused_supported(int C, int heads, int vol);
+#endif
 
-// Engine switch (A/B and tests): bit 2 = arithmetic token ids for affine cuboid tables (default on; neutral in time, removes a dependent
-// load).  Bits 0 (atomic in-place epilogue) and 1 (deep weight ring for small grids) of round 3 were measured slower / neutral
-// (profiles/r03_b_fused_opts_ab.log: 122 -> 159 us, 25.6 -> 27.3 us) and have been removed from the kernels.
-extern "C" int pd_fused_opts = 4;
-
-extern "C" int pd_attn_block_fused_ex(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
-                                      const float* bqkv, const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias,
-                                      const uint8_t* mask, int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps,
-                                      const int32_t* tok_affine, pd_stream_t stream) {
+// opts->attn_block_table_ids (A/B and tests): load the token table even when the affine form of the cuboid table is given (arithmetic
+// token ids are the default: neutral in time, one dependent load less).  The atomic in-place epilogue and the deep weight ring for small
+// grids of round 3 were measured slower / neutral (profiles/r03_b_fused_opts_ab.log: 122 -> 159 us, 25.6 -> 27.3 us) and are gone.
+extern "C" int PD_ENTRY(attn_block_fused_ex)(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
+                                             const float* bqkv, const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias,
+                                             const uint8_t* mask, int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps,
+                                             const int32_t* tok_affine, const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_attn_block_fused_ex(x, out, gamma, beta, Wqkv, bqkv, Wp, bp, tok_index, bias, mask, B, ntok, C, heads, nc,
+                                                               vol, scale, eps, tok_affine, opts, stream));
   PD_CHECK_ARG(x && out && gamma && beta && Wqkv && Wp && tok_index && bias, "pd_attn_block_fused: null pointer");
   PD_CHECK_ARG(pd_attn_block_fused_supported(C, heads, vol), "pd_attn_block_fused: unsupported units=%d heads=%d cuboid volume=%d "
                "(units in {128,256}, head_dim 64, volume <= 64)", C, heads, vol);
@@ -684,9 +690,9 @@ extern "C" int pd_attn_block_fused_ex(const float* x, float* out, const float* g
   a.B = B; a.ntok = ntok; a.nc = nc; a.vol = vol; a.scale = scale; a.eps = eps;
   a.wqkv_bytes = (uint32_t)((int64_t)3 * C * C * 2);
   a.wp_bytes = (uint32_t)((int64_t)C * C * 2);
-  a.dbg = pd_attn_block_debug_flags;
-  a.trace = pd_attn_block_trace;
-  a.aff_on = (tok_affine && (pd_fused_opts & 4) && tok_affine[0] > 0) ? 1 : 0;
+  a.dbg = opts ? opts->attn_block_debug_flags : 0;     // (profiling ablations / per-phase clock stamps: scripts/bench_attn_block.py)
+  a.trace = opts ? opts->trace : nullptr;
+  a.aff_on = (tok_affine && !(opts && opts->attn_block_table_ids) && tok_affine[0] > 0) ? 1 : 0;
   a.aff_ninner = a.aff_on ? tok_affine[0] : 1;
   a.aff_outer = a.aff_on ? tok_affine[1] : 0;
   a.aff_inner = a.aff_on ? tok_affine[2] : 0;
@@ -703,10 +709,14 @@ extern "C" int pd_attn_block_fused_ex(const float* x, float* out, const float* g
   return kt == 3 ? launch_attn_block<128, 3, 64>(a, s) : launch_attn_block<128, 4>(a, s);
 }
 
+#if !PD_IS_F16
 extern "C" int pd_attn_block_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* Wqkv,
                                    const float* bqkv, const pd_bf16* Wp, const float* bp, const int32_t* tok_index, const float* bias,
                                    const uint8_t* mask, int B, int ntok, int C, int heads, int nc, int vol, float scale, float eps,
                                    pd_stream_t stream) {
   return pd_attn_block_fused_ex(x, out, gamma, beta, Wqkv, bqkv, Wp, bp, tok_index, bias, mask, B, ntok, C, heads, nc, vol, scale, eps,
-                                nullptr, stream);
+                                nullptr, nullptr, stream);
 }
+#endif
+
+}  // namespace PD_NS

@@ -5,10 +5,39 @@
 #include <stdio.h>
 #include "../../include/prediff_hip.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// ---- the 16-bit MFMA operand type of this translation unit ---------------------------------------------------------------------------
+// Every kernel source that touches 16-bit operands is compiled TWICE (Makefile): as is -- bfloat16 operands, namespace pdk_bf16, the public
+// pd_* entry points -- and with -DPD_BUILD_F16 -- IEEE half operands (10-bit mantissa: what the reference's float32_matmul_precision
+// "high" = TF32 keeps on its GPUs, prediff_sevirlr_v1.yaml:63; same MFMA rate as bf16), namespace pdk_f16, entry points pd_f16_* that the
+// public ones forward to when the caller's pd_call_opts / args struct says operand = PD_OPERAND_F16.  The two builds share every line;
+// the differences are the typedefs and the helpers below (conversion, the three MFMA shapes).  fp16's range is 65504: the packers
+// saturate (activations behind a norm / softmax / GELU are O(1..30), the residual stream stays fp32).
+#ifdef PD_BUILD_F16
+#define PD_NS pdk_f16
+#define PD_ENTRY(name) pd_f16_##name
+#define PD_IS_F16 1
+typedef _Float16 op_t;
+#else
+#define PD_NS pdk_bf16
+#define PD_ENTRY(name) pd_##name
+#define PD_IS_F16 0
+typedef __bf16 op_t;
+#endif
+typedef __attribute__((ext_vector_type(8))) op_t op8;      // one lane's operand of a K = 32 MFMA
+typedef __attribute__((ext_vector_type(4))) op_t op4v;
+typedef __attribute__((ext_vector_type(2))) op_t op2v;
+// bf16 TU: forward to the fp16 build of the same entry point
+#if PD_IS_F16
+#define PD_FORWARD_F16(is_f16, call)
+#else
+#define PD_FORWARD_F16(is_f16, call) do { if (is_f16) return call; } while (0)
+#endif
+#define PD_OPTS_F16(opts) ((opts) && (opts)->operand == PD_OPERAND_F16)
 
 extern "C" void pd_set_error(const char* fmt, ...);
 
@@ -38,20 +67,78 @@ static inline int pd_cur_device() {
     }                                                                     \
   } while (0)
 
-// fp32 -> bf16 bits, round to nearest even (NaN kept quiet).
+// fp32 -> bf16 bits, round to nearest even (NaN kept quiet).  (bf16 whatever the operand type: the hi/lo split below is bf16 only)
 __device__ __forceinline__ uint16_t f2bf(float f) {
   uint32_t u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-// two fp32 -> packed bf16x2 (lo | hi << 16), round to nearest even, ONE instruction (gfx950 v_cvt_pk_bf16_f32; no builtin)
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  uint32_t r;
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+namespace PD_NS {
+// four / two fp32 -> operand type (RNE).  fp16: v_cvt_pk_f16_f32 + saturation at +-65504 (v_pk_min/max_f16; a NaN saturates too).
+__device__ __forceinline__ op4v cvt_op4(const f32x4& a) {
+#if PD_IS_F16
+  op4v h = __builtin_convertvector(a, op4v);
+  h = __builtin_elementwise_min(h, (op4v)(_Float16)65504.f);
+  return __builtin_elementwise_max(h, (op4v)(_Float16)(-65504.f));
+#else
+  return __builtin_convertvector(a, op4v);     // v_cvt_pk_bf16_f32 with the MFMA hazards handled by the compiler
+#endif
+}
+// two fp32 -> packed operand pair (lo | hi << 16), round to nearest even
+__device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {
+#if PD_IS_F16
+  op2v h = __builtin_convertvector(f32x2{lo, hi}, op2v);
+  h = __builtin_elementwise_min(h, (op2v)(_Float16)65504.f);
+  h = __builtin_elementwise_max(h, (op2v)(_Float16)(-65504.f));
+  return __builtin_bit_cast(uint32_t, h);
+#else
+  uint32_t r;                                   // ONE instruction (gfx950 v_cvt_pk_bf16_f32; no scalar builtin)
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
+#endif
 }
-__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// one fp32 -> operand bits / back
+__device__ __forceinline__ uint16_t f2op(float f) {
+#if PD_IS_F16
+  return __builtin_bit_cast(uint16_t, (_Float16)fminf(fmaxf(f, -65504.f), 65504.f));
+#else
+  return f2bf(f);
+#endif
+}
+__device__ __forceinline__ float op2f(uint16_t h) {
+#if PD_IS_F16
+  return (float)__builtin_bit_cast(_Float16, h);
+#else
+  return bf2f(h);
+#endif
+}
+// the three MFMA shapes in use, fp32 accumulate.  16x16x16 takes its operands as raw 16-bit lanes (s16x4) in both builds.
+__device__ __forceinline__ f32x4 mfma_16x16x32(const op8& a, const op8& b, const f32x4& c) {
+#if PD_IS_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 mfma_16x16x16(const s16x4& a, const s16x4& b, const f32x4& c) {
+#if PD_IS_F16
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(op4v, a), __builtin_bit_cast(op4v, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(const op8& a, const op8& b, const f32x16& c) {
+#if PD_IS_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+}  // namespace PD_NS
+using namespace PD_NS;
 
 // hi/lo bf16 decomposition: x ~= hi + lo with ~16 mantissa bits.
 __device__ __forceinline__ void f2bf_split(float f, uint16_t& hi, uint16_t& lo) {

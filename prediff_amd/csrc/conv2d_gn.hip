@@ -34,6 +34,8 @@
 #include <algorithm>
 #include "common.h"
 
+namespace PD_NS {
+
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
 
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_gn_kernel(const pd_conv2d_gn_ar
       float y0v = silu(fmaf(v[i].x, sc0, sh0)), y1v = silu(fmaf(v[i].y, sc1, sh1));
       float y2v = silu(fmaf(v[i].z, sc2, sh2)), y3v = silu(fmaf(v[i].w, sc3, sh3));
       if (!inb[i]) y0v = y1v = y2v = y3v = 0.f;      // zero padding of the convolution input
-      *(uint2*)(sX + row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) << 4) + ((c4 & 1) << 3)) = make_uint2(pack_bf16x2(y0v, y1v), pack_bf16x2(y2v, y3v));
+      *(uint2*)(sX + row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) << 4) + ((c4 & 1) << 3)) = make_uint2(pack_op2(y0v, y1v), pack_op2(y2v, y3v));
     }
     // ---------------- nine taps: A fragments from the halo tile at shifted offsets, weights from the ring ----------------
     for (int tap = 0; tap < 9; ++tap) {
@@ -162,21 +164,21 @@ __global__ void __launch_bounds__(256, 2) conv2d_gn_kernel(const pd_conv2d_gn_ar
       const char* wt = sW + (s % RS) * WT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[4], bw[4];
+        op8 a[4], bw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = (wm * 4 + i + dy) * HC + l16 + dx;
-          a[i] = *(const bf16x8*)(sX + row * 128 + (((ks * 4 + lg) ^ ((row >> 1) & 7)) << 4));
+          a[i] = *(const op8*)(sX + row * 128 + (((ks * 4 + lg) ^ ((row >> 1) & 7)) << 4));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int nr = wn * 64 + j * 16 + l16;
-          bw[j] = *(const bf16x8*)(wt + nr * 128 + (((ks * 4 + lg) ^ ((nr >> 1) & 7)) << 4));
+          bw[j] = *(const op8*)(wt + nr * 128 + (((ks * 4 + lg) ^ ((nr >> 1) & 7)) << 4));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bw[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32(a[i], bw[j], acc[i][j]);
       }
     }
   }
@@ -207,14 +209,21 @@ __global__ void __launch_bounds__(256, 2) conv2d_gn_kernel(const pd_conv2d_gn_ar
 #endif
 }
 
+#if !PD_IS_F16
 extern "C" int pd_conv2d_gn_silu_supported(int H, int W, int Cin, int Cout, int G) {
   return H > 0 && W > 0 && H % 8 == 0 && W % 16 == 0 && Cin % 64 == 0 && Cout % 128 == 0 && G > 0 && G <= 256 && Cin % G == 0 &&
          (Cin / G) % 4 == 0;
 }
+extern "C" int pd_f16_conv2d_gn_silu(const float*, const float*, const float*, const float*, const pd_bf16*, const float*, const float*, float*, int, int,
+                                     int, int, int, int, const pd_call_opts*, pd_stream_t);
+#else
+extern "C" int pd_conv2d_gn_silu_supported(int H, int W, int Cin, int Cout, int G);
+#endif
 
-extern "C" int pd_conv2d_gn_silu(const float* x, const float* stats, const float* gamma, const float* beta, const pd_bf16* W,
-                                 const float* bias, const float* residual, float* out, int N, int H, int Wd, int Cin, int Cout, int G,
-                                 pd_stream_t stream) {
+extern "C" int PD_ENTRY(conv2d_gn_silu)(const float* x, const float* stats, const float* gamma, const float* beta, const pd_bf16* W,
+                                        const float* bias, const float* residual, float* out, int N, int H, int Wd, int Cin, int Cout, int G,
+                                        const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_conv2d_gn_silu(x, stats, gamma, beta, W, bias, residual, out, N, H, Wd, Cin, Cout, G, opts, stream));
   PD_CHECK_ARG(x && stats && gamma && beta && W && out, "pd_conv2d_gn_silu: null pointer");
   if (!pd_conv2d_gn_silu_supported(H, Wd, Cin, Cout, G)) {
     pd_set_error("pd_conv2d_gn_silu: unsupported geometry H=%d W=%d Cin=%d Cout=%d G=%d (H %% 8, W %% 16, Cin %% 64, Cout %% 128, 4 | Cin/G)",
@@ -247,3 +256,5 @@ extern "C" int pd_conv2d_gn_silu(const float* x, const float* stats, const float
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
+
+}  // namespace PD_NS

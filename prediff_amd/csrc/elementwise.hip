@@ -10,9 +10,10 @@ extern "C" void pd_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* pd_last_error(void) { return g_err; }
-extern "C" int pd_abi_version(void) { return 1; }
+extern "C" int pd_abi_version(void) { return 2; }   // 2: per-call options (pd_call_opts), IEEE-half operand builds, no exported data symbols
 extern "C" int pd_sizeof_igemm_args(void) { return (int)sizeof(pd_igemm_args); }
 extern "C" int pd_sizeof_cuboid_attn_args(void) { return (int)sizeof(pd_cuboid_attn_args); }
+extern "C" int pd_sizeof_call_opts(void) { return (int)sizeof(pd_call_opts); }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)min((int64_t)8192, (n + 255) / 256); }
 

@@ -23,6 +23,8 @@
 #include "common.h"
 #include "ln_tile.h"
 
+namespace PD_NS {
+
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
 
@@ -125,11 +127,11 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
   // ---- this wave's GEMM-1 B operand (its 32 token rows, all of K) lives in registers for the whole kernel ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                        // A tile written by all waves; W1 of chunk 0 landed
-  bf16x8 areg[KS * 4];
+  op8 areg[KS * 4];
 #pragma unroll
   for (int s = 0; s < KS; ++s)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) areg[s * 4 + kk] = *(const bf16x8*)(sA + s * (BM * 128) + g1_b_row + (((kk * 2 + lhalf) ^ swz) * 16));
+    for (int kk = 0; kk < 4; ++kk) areg[s * 4 + kk] = *(const op8*)(sA + s * (BM * 128) + g1_b_row + (((kk * 2 + lhalf) ^ swz) * 16));
   __syncthreads();                                        // A-tile region is now free: it becomes weight-buffer set 1
 
   // ---- slot loop.  A chunk j of a group is: MFMA slot [GEMM-2 of chunk j-1, GEMM-1 of chunk j] then VALU slot [bias,
@@ -155,16 +157,16 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
       const bool do2 = j >= 1 && !(p.dbg & 8), do1 = j < NJ;
       const char* cW2 = w2buf((j - 1) & 1);
       const char* cW1 = w1buf(j & 1);
-      bf16x8 fa[2], fb[2][TN2], fw[2][4];
+      op8 fa[2], fb[2][TN2], fw[2][4];
       auto load2 = [&](int kk, int buf) {
         const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-        fa[buf] = *(const bf16x8*)(sHg + g2_a_row + pos);
+        fa[buf] = *(const op8*)(sHg + g2_a_row + pos);
 #pragma unroll
-        for (int t = 0; t < TN2; ++t) fb[buf][t] = *(const bf16x8*)(cW2 + g2_b_row + t * 32 * 128 + pos);
+        for (int t = 0; t < TN2; ++t) fb[buf][t] = *(const op8*)(cW2 + g2_b_row + t * 32 * 128 + pos);
       };
       auto load1 = [&](int ks, int buf) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fw[buf][kk] = *(const bf16x8*)(cW1 + ks * 8192 + g1_a_row + (((kk * 2 + lhalf) ^ swz) * 16));
+        for (int kk = 0; kk < 4; ++kk) fw[buf][kk] = *(const op8*)(cW1 + ks * 8192 + g1_a_row + (((kk * 2 + lhalf) ^ swz) * 16));
       };
       if (do2) load2(0, 0);
       if (do2) {
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
           if (kk < 3) load2(kk + 1, (kk + 1) & 1);
           else if (do1) load1(0, 0);
 #pragma unroll
-          for (int t = 0; t < TN2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][t], acc2[t], 0, 0, 0);
+          for (int t = 0; t < TN2; ++t) acc2[t] = mfma_32x32x16(fa[kk & 1], fb[kk & 1][t], acc2[t]);
         }
       } else if (do1) {
         load1(0, 0);
@@ -194,8 +196,8 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
           if (ks + 1 < KS) load1(ks + 1, (ks + 1) & 1);
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
-            if (kk & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][kk], areg[ks * 4 + kk], acc1b, 0, 0, 0);
-            else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][kk], areg[ks * 4 + kk], acc1, 0, 0, 0);
+            if (kk & 1) acc1b = mfma_32x32x16(fw[ks & 1][kk], areg[ks * 4 + kk], acc1b);
+            else acc1 = mfma_32x32x16(fw[ks & 1][kk], areg[ks * 4 + kk], acc1);
           }
         }
       }
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
         const int off = hrow * 128 + (((nl >> 3) ^ hswz) << 4) + ((nl & 7) << 1);
         // Written with an opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell
         // that H and the DMA destinations are disjoint LDS regions), which would serialise the prefetch every chunk.
-        const uint64_t pk = (uint64_t)(pack_bf16x2(h0, h1)) | ((uint64_t)(pack_bf16x2(h2, h3)) << 32);
+        const uint64_t pk = (uint64_t)(pack_op2(h0, h1)) | ((uint64_t)(pack_op2(h2, h3)) << 32);
         asm volatile("ds_write_b64 %0, %1" ::"v"(h_lds + (uint32_t)off), "v"(pk) : "memory");
       }
     }
@@ -339,10 +341,10 @@ __global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ff
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                 // A tile written by all waves; W1_0 landed
-  bf16x8 areg[NSTEP];                              // this wave's 16 token rows, all of K, for the whole kernel
+  op8 areg[NSTEP];                              // this wave's 16 token rows, all of K, for the whole kernel
 #pragma unroll
   for (int ks = 0; ks < NSTEP; ++ks)
-    areg[ks] = *(const bf16x8*)(sS0 + (ks >> 1) * (BM * 128) + (tq * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
+    areg[ks] = *(const op8*)(sS0 + (ks >> 1) * (BM * 128) + (tq * 16 + l16) * 128 + ((((ks & 1) * 4 + lg) ^ swz16) << 4));
   __syncthreads();                                 // the A-tile region is free: weight slot 0
   issue(NS - 1);                                   // -> slot 0
 
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ff
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
         asm volatile("ds_read_b128 %0, %1" : "=v"(bb[dt]) : "v"(b1_lds + (uint32_t)((j * HC + tn * 32 + dt * 16 + 4 * lg) * 4)));
-      bf16x8 w[PF + 1][2];
+      op8 w[PF + 1][2];
 #pragma unroll
       for (int i = 0; i < PF; ++i) {
         FFN64_WLD(w[i][0], w_lane, i, 0);
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ff
           if (ks == 0) { acc1[0] = bb[0]; acc1[1] = bb[1]; }      // (the bias reads are older than every fragment read: landed)
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks % (PF + 1)][dt], areg[ks], acc1[dt], 0, 0, 0);
+            acc1[dt] = mfma_16x16x32(w[ks % (PF + 1)][dt], areg[ks], acc1[dt]);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ff
           const int d = tn * 32 + dt * 16 + 4 * lg;
           const float h0 = act_apply(acc1[dt][0], ACT), h1 = act_apply(acc1[dt][1], ACT);
           const float h2 = act_apply(acc1[dt][2], ACT), h3 = act_apply(acc1[dt][3], ACT);
-          const uint64_t pk = (uint64_t)(pack_bf16x2(h0, h1)) | ((uint64_t)(pack_bf16x2(h2, h3)) << 32);
+          const uint64_t pk = (uint64_t)(pack_op2(h0, h1)) | ((uint64_t)(pack_op2(h2, h3)) << 32);
           const int off = trow * 128 + (((d >> 3) ^ ((trow >> 1) & 7)) << 4) + ((d & 7) << 1);
           // opaque ds_write: a visible LDS store would make hipcc drain the in-flight weight DMA first
           asm volatile("ds_write_b64 %0, %1" ::"v"(h_lds + (uint32_t)off), "v"(pk) : "memory");
@@ -415,7 +417,7 @@ __global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ff
     // ---------------- step B: acc += H_j W2_j^T ----------------
     {
       if (!(p.dbg & 8)) {
-        bf16x8 fa[2], fb[2][2];                                         // [pipeline slot][output half]: two k-sub-steps in flight
+        op8 fa[2], fb[2][2];                                         // [pipeline slot][output half]: two k-sub-steps in flight
         const uint32_t xs = (uint32_t)((lhalf ^ swz) << 4);              // 16 B slot of k-sub-step 0; sub-step kk: ^ (kk << 5)
         const uint32_t a2 = h_lds + (uint32_t)g2_a + xs;
         const uint32_t b2 = (uint32_t)(uintptr_t)slot_of(2 * j + 1) + (uint32_t)g2_b + xs;
@@ -434,8 +436,8 @@ __global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ff
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           }
           __builtin_amdgcn_sched_barrier(0);
-          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][0], acc2[0], 0, 0, 0);
-          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1], fb[kk & 1][1], acc2[1], 0, 0, 0);
+          acc2[0] = mfma_32x32x16(fa[kk & 1], fb[kk & 1][0], acc2[0]);
+          acc2[1] = mfma_32x32x16(fa[kk & 1], fb[kk & 1][1], acc2[1]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -512,16 +514,20 @@ static int launch_ffn(const pd_ffn_args_k& a, hipStream_t s) {
   return PD_OK;
 }
 
-extern "C" int pd_ffn_use_64 = 1;   // units = 256: the 64-row, two-workgroups-per-CU kernel (0: the 128-row kernel; A/B switch)
-extern "C" int pd_ffn_debug_flags = 0;
-extern "C" unsigned long long* pd_ffn_trace = nullptr;   // profiling ablations only (scripts/bench_ffn.py)
-
+#if !PD_IS_F16
 extern "C" int pd_ffn_fused_supported(int C, int Hd) {
   return (C == 64 || C == 128 || C == 256) && Hd > 0 && Hd % 64 == 0 && Hd <= 3072;   // LDS: 144 KB tiles + 4*Hd bytes of bias
 }
+extern "C" int pd_f16_ffn_fused(const float*, float*, const float*, const float*, const pd_bf16*, const float*, const pd_bf16*, const float*, int64_t, int,
+                                int, int, float, const pd_call_opts*, pd_stream_t);
+#else
+extern "C" int pd_ffn_fused_supported(int C, int Hd);
+#endif
 
-extern "C" int pd_ffn_fused(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* W1, const float* b1,
-                            const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, pd_stream_t stream) {
+extern "C" int PD_ENTRY(ffn_fused)(const float* x, float* out, const float* gamma, const float* beta, const pd_bf16* W1, const float* b1,
+                                   const pd_bf16* W2, const float* b2, int64_t M, int C, int Hd, int act, float eps, const pd_call_opts* opts,
+                                   pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_ffn_fused(x, out, gamma, beta, W1, b1, W2, b2, M, C, Hd, act, eps, opts, stream));
   PD_CHECK_ARG(x && out && gamma && beta && W1 && b1 && W2 && b2, "pd_ffn_fused: null pointer");
   PD_CHECK_ARG(pd_ffn_fused_supported(C, Hd), "pd_ffn_fused: unsupported units=%d hidden=%d (units in {64,128,256}, hidden %% 64 == 0)", C, Hd);
   PD_CHECK_ARG(M > 0 && M < (1ll << 31), "pd_ffn_fused: bad M");
@@ -530,11 +536,12 @@ extern "C" int pd_ffn_fused(const float* x, float* out, const float* gamma, cons
   a.M = (int)M; a.Hd = Hd; a.act = act; a.eps = eps;
   a.w1_bytes = (uint32_t)((int64_t)Hd * C * 2);
   a.w2_bytes = (uint32_t)((int64_t)C * Hd * 2);
-  a.dbg = pd_ffn_debug_flags;
-  a.trace = pd_ffn_trace;
+  a.dbg = opts ? opts->ffn_debug_flags : 0;           // (profiling ablations / per-phase clock stamps: scripts/bench_ffn.py)
+  a.trace = opts ? opts->trace : nullptr;
+  const bool use_64 = !(opts && opts->ffn_rows128);     // units 256: the 64-row, two-workgroups-per-CU kernel (A/B switch: the 128-row kernel)
   hipStream_t s = (hipStream_t)stream;
 #define PD_FFN(ACT)                                  \
-  if (C == 256 && pd_ffn_use_64 && Hd * 4 + 2 * 32768 + 8192 <= 80 * 1024) return launch_ffn64<ACT>(a, s);   \
+  if (C == 256 && use_64 && Hd * 4 + 2 * 32768 + 8192 <= 80 * 1024) return launch_ffn64<ACT>(a, s);   \
   if (C == 256) return launch_ffn<256, ACT>(a, s);   \
   if (C == 128) return launch_ffn<128, ACT>(a, s);   \
   return launch_ffn<64, ACT>(a, s);
@@ -548,3 +555,5 @@ extern "C" int pd_ffn_fused(const float* x, float* out, const float* gamma, cons
   }
 #undef PD_FFN
 }
+
+}  // namespace PD_NS

@@ -21,6 +21,8 @@
 #include "common.h"
 #include "igemm_epilogue.h"
 
+namespace PD_NS {
+
 __device__ __attribute__((aligned(64))) uint32_t g_pd_zero_page[32];   // 128 B of zeros (never written)
 
 #ifndef PD_BIG_TILE_DEFAULT
@@ -184,26 +186,26 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
 #pragma unroll
     for (int kk = 0; kk < KSUB; ++kk) {                 // 32-deep k-steps
       const int pos = ((kk * 4 + lg) ^ swz) * 16;
-      bf16x8 a[TM16], b[TN16], al[TM16], bl[TN16];
+      op8 a[TM16], b[TN16], al[TM16], bl[TN16];
 #pragma unroll
       for (int i = 0; i < TM16; ++i) {
-        a[i] = *(const bf16x8*)(sA + a_row_b + i * 16 * ROWB + pos);
-        if (SPLIT) al[i] = *(const bf16x8*)(sA + A_TILE + a_row_b + i * 16 * ROWB + pos);
+        a[i] = *(const op8*)(sA + a_row_b + i * 16 * ROWB + pos);
+        if (SPLIT) al[i] = *(const op8*)(sA + A_TILE + a_row_b + i * 16 * ROWB + pos);
       }
 #pragma unroll
       for (int j = 0; j < TN16; ++j) {
-        b[j] = *(const bf16x8*)(sB + b_row_b + j * 16 * ROWB + pos);
-        if (SPLIT) bl[j] = *(const bf16x8*)(sB + B_TILE + b_row_b + j * 16 * ROWB + pos);
+        b[j] = *(const op8*)(sB + b_row_b + j * 16 * ROWB + pos);
+        if (SPLIT) bl[j] = *(const op8*)(sB + B_TILE + b_row_b + j * 16 * ROWB + pos);
       }
 #pragma unroll
       for (int i = 0; i < TM16; ++i)
 #pragma unroll
         for (int j = 0; j < TN16; ++j) {
           if (SPLIT) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_16x16x32(al[i], b[j], acc[i][j]);
+            acc[i][j] = mfma_16x16x32(a[i], bl[j], acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_16x16x32(a[i], b[j], acc[i][j]);
         }
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
@@ -274,18 +276,21 @@ static int dispatch_igemm(const pd_igemm_args& a, int tile, hipStream_t s) {
 bool pd_igemm256_supported(const pd_igemm_args& a, int kind);
 int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s);
 
-extern "C" int pd_igemm_default_tile = 0;   // bench / tuning override of the auto choice (0 = built-in heuristic)
-extern "C" int pd_igemm_debug_or = 0;       // bench A/B switch: OR-ed into every launch's debug_flags
-extern "C" int pd_igemm_disable_256 = 0;    // bench A/B switch: keep the auto choice away from the 256 x 256 kernel
-extern "C" int pd_igemm_256_min_k = 1024;   // shortest K (taps * Cin) the auto choice gives to the 256 x 256 kernel (bench A/B switch: 512 wins 25 % on stand-alone full-resolution level-1 launches and nothing end to end, two lanes running)
-extern "C" int pd_igemm_splitk_max_tiles = 128;   // split-K only for launches of at most this many 256 x 256 tiles (0 disables it)
 int pd_igemm256_ksplit(const pd_igemm_args& a, int kind);
 int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s);
 
-extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
+#if !PD_IS_F16
+extern "C" int pd_f16_igemm(const pd_igemm_args*, pd_stream_t);
+#endif
+
+extern "C" int PD_ENTRY(igemm)(const pd_igemm_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(pa != nullptr, "pd_igemm: null args");
+  PD_FORWARD_F16(pa->operand == PD_OPERAND_F16, pd_f16_igemm(pa, stream));
   pd_igemm_args a = *pa;
-  a.debug_flags |= pd_igemm_debug_or;
+  PD_CHECK_ARG(!PD_IS_F16 || (!a.split && !a.fp8 && !a.out_bf16_lo), "pd_igemm: IEEE-half operands: no hi/lo split, no e4m3 operands");
+  // A/B switches of the caller (0 = the defaults)
+  const int min_k_256 = a.min_k_256 > 0 ? a.min_k_256 : 1024;   // shortest K (taps * Cin) the automatic choice gives to the 256 x 256 kernel (512 wins
+                                                                // 25 % on stand-alone full-resolution level-1 launches and nothing end to end, two lanes running)
   PD_CHECK_ARG(a.A && a.W, "pd_igemm: A/W null");
   PD_CHECK_ARG(a.M > 0 && a.N > 0 && a.taps > 0, "pd_igemm: bad M/N/taps (%d,%d,%d)", a.M, a.N, a.taps);
   PD_CHECK_ARG(a.Cin > 0 && (a.Cin & 63) == 0, "pd_igemm: Cin=%d must be a positive multiple of 64 (zero padded)", a.Cin);
@@ -321,12 +326,13 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     PD_CHECK_ARG(a.vec_epilogue == 2 && !a.out_bf16_lo && !a.split && a.out_fp8_log2 <= 16,
                  "pd_igemm: an e4m3 output needs the 8-column vector epilogue (out_bf16 only, N %% 8 == 0, ld_outb %% 8 == 0, 16 B aligned), no split");
   }
-  int tile = a.tile ? a.tile : pd_igemm_default_tile;
+  int tile = a.tile;
   // a 1-tap, stride-1, unpadded, un-upsampled "convolution" is a plain row-wise linear layer: row m reads A row m
   const bool pointwise = a.taps == 1 && a.st == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.ph == 0 && a.pw == 0 && a.ut == 1 &&
                          a.uh == 1 && a.uw == 1 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && a.vT <= 0 && a.vH <= 0 && a.vW <= 0;
   const int kind = pointwise ? 0 : ((a.KT == 1 && a.Ti == 1 && a.To == 1) ? 1 : 2);
   a.ksplit = 1;
+#if !PD_IS_F16
   if (a.fp8) {
     if (!pd_igemm256_supported(a, kind) || kind == 1) {
       pd_set_error("pd_igemm: fp8 operands are built for row-wise linear layers and stride-1, un-upsampled Conv3d launches only");
@@ -334,14 +340,15 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     }
     // small grids: K-slices as extra workgroups -- never with an e4m3 OUTPUT: the split-K reduce kernel stores 2-byte bf16 rows, which
     // would overrun the caller's 1-byte e4m3 buffer (the un-split epilogue is the only e4m3 producer)
-    const int ks = (a.tile == 0 && !pd_igemm_disable_256 && a.out_fp8_log2 <= 0) ? pd_igemm256_ksplit(a, kind) : 0;
+    const int ks = (a.tile == 0 && !a.disable_256 && a.out_fp8_log2 <= 0) ? pd_igemm256_ksplit(a, kind) : 0;
     if (ks >= 2) {
       a.ksplit = ks;
       return pd_igemm256_launch_splitk(a, kind, s);
     }
     return pd_igemm256_launch(a, kind, s);
   }
-  if (tile == 0 && !pd_igemm_disable_256) {
+#endif
+  if (tile == 0 && !a.disable_256) {
     // small grids (few trajectories per launch) with a long K loop: 256 x 256 tiles x K-slices fill the CUs (igemm256.hip)
     const int ks = pd_igemm256_ksplit(a, kind);
     if (ks >= 2) {
@@ -357,7 +364,7 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     // long K: the 256 x 256 eight-wave kernel does a round of 256 tiles (one per CU of the MI355X) in ~1.65x the time the
     // 128 x 128 kernel needs for a round of 512 (two per CU) inside the sampling loop -- twice the work; take it when its whole
     // rounds are the cheaper ones (Conv3d at 32 trajectories: 317 us in 2 rounds against 385 us in 4)
-    if (tile == PD_BIG_TILE_DEFAULT && !pd_igemm_disable_256 && !a.split && (int64_t)a.taps * a.Cin >= pd_igemm_256_min_k && pd_igemm256_supported(a, kind)) {
+    if (tile == PD_BIG_TILE_DEFAULT && !a.disable_256 && !a.split && (int64_t)a.taps * a.Cin >= min_k_256 && pd_igemm256_supported(a, kind)) {
       const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.nbatch > 0 ? a.nbatch : 1);
       const int64_t r128 = (t128 + 511) / 512, r256 = (t256 + 255) / 256;
       if (r256 * 33 <= r128 * 20) tile = 7;
@@ -368,12 +375,16 @@ extern "C" int pd_igemm(const pd_igemm_args* pa, pd_stream_t stream) {
     if (pd_igemm256_supported(a, kind)) return pd_igemm256_launch(a, kind, s);
     tile = PD_BIG_TILE_DEFAULT;
   }
+#if !PD_IS_F16
   if (a.split) {
     if (kind == 0) return dispatch_igemm<true, 0>(a, tile, s);
     if (kind == 1) return dispatch_igemm<true, 1>(a, tile, s);
     return dispatch_igemm<true, 2>(a, tile, s);
   }
+#endif
   if (kind == 0) return dispatch_igemm<false, 0>(a, tile, s);
   if (kind == 1) return dispatch_igemm<false, 1>(a, tile, s);
   return dispatch_igemm<false, 2>(a, tile, s);
 }
+
+}  // namespace PD_NS

@@ -35,6 +35,8 @@
 #include "common.h"
 #include "igemm_epilogue.h"
 
+namespace PD_NS {
+
 #define BLDS16(rsrc, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(ldsptr), 16, (voff), (soff), 0, 0)
 #define PD_OOB 0xffffff00u
@@ -53,10 +55,10 @@ namespace {
 // 8-register tuple so that no copies are needed)
 template <bool F8>
 struct Frag256 {
-  bf16x8 v[2];
+  op8 v[2];
   __device__ __forceinline__ void load(const char* base, int lg, int swz) {
-    v[0] = *(const bf16x8*)(base + ((lg ^ swz) * 16));
-    v[1] = *(const bf16x8*)(base + (((4 + lg) ^ swz) * 16));
+    v[0] = *(const op8*)(base + ((lg ^ swz) * 16));
+    v[1] = *(const op8*)(base + (((4 + lg) ^ swz) * 16));
   }
 };
 template <>
@@ -71,10 +73,10 @@ __device__ __forceinline__ f32x4 mfma_f8(const Frag256<true>& a, const Frag256<t
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a.v, b.v, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);   // e4m3 x e4m3, block scales 2^0
 }
 __device__ __forceinline__ f32x4 mfma_f8(const Frag256<false>&, const Frag256<false>&, f32x4 c) { return c; }
-__device__ __forceinline__ f32x4 mfma_bf16(const Frag256<false>& a, const Frag256<false>& b, int ks, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[ks], b.v[ks], c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma_op16(const Frag256<false>& a, const Frag256<false>& b, int ks, f32x4 c) {
+  return mfma_16x16x32(a.v[ks], b.v[ks], c);
 }
-__device__ __forceinline__ f32x4 mfma_bf16(const Frag256<true>&, const Frag256<true>&, int, f32x4 c) { return c; }
+__device__ __forceinline__ f32x4 mfma_op16(const Frag256<true>&, const Frag256<true>&, int, f32x4 c) { return c; }
 constexpr int HT = 128 * 128;   // bytes of one half tile: 128 rows x 64 bf16
 constexpr int KBUF = 4 * HT;    // one K-tile buffer: A half 0, A half 1, W half 0, W half 1
 
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                      \
       _Pragma("unroll") for (int i = 0; i < (NR); ++i)                                                                    \
         _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                     \
-          acc[(R0) + i][(C0) + c] = mfma_bf16(a[i], bfrag[c], ks, acc[(R0) + i][(C0) + c]);                               \
+          acc[(R0) + i][(C0) + c] = mfma_op16(a[i], bfrag[c], ks, acc[(R0) + i][(C0) + c]);                               \
   }
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const pd_igemm
       for (int e = 0; e < 4; ++e) {
         uint16_t h, l;
         f2bf_split(v[e], h, l);
-        p.out_bf16[(int64_t)m * p.ld_outb + n + e] = p.out_bf16_lo ? h : (uint16_t)f2bf(v[e]);
+        p.out_bf16[(int64_t)m * p.ld_outb + n + e] = p.out_bf16_lo ? h : (uint16_t)f2op(v[e]);
         if (p.out_bf16_lo) p.out_bf16_lo[(int64_t)m * p.ld_outb + n + e] = l;
       }
     }
@@ -441,18 +443,20 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind);
 // K-slices for a launch of `tiles` 256 x 256 tiles and nk K-tiles on the 256 CUs of the MI355X (0 = do not split): split when the
 // tiles cover at most half of the CUs, into as many slices as fit one round, each at least 8 K-tiles long, within the workspace.
 int pd_igemm256_ksplit(const pd_igemm_args& a, int kind) {
-  extern int pd_igemm_splitk_max_tiles;
+  const int max_tiles = a.splitk_max_tiles > 0 ? a.splitk_max_tiles : a.splitk_max_tiles < 0 ? 0 : 128;   // (A/B switch of the caller)
   if (!a.splitk_ws || a.split || (a.N & 3) || (a.nbatch > 1) || !pd_igemm256_supported(a, kind)) return 0;
   const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int nk = a.taps * (a.Cin >> (a.fp8 ? 7 : 6));       // K-tiles of 128 B per row
-  if (tiles > pd_igemm_splitk_max_tiles || nk < 32) return 0;
+  if (tiles > max_tiles || nk < 32) return 0;
   int64_t ks = std::min<int64_t>(256 / tiles, nk / 8);
   ks = std::min<int64_t>(ks, a.splitk_ws_elems / ((int64_t)a.M * a.N));
   return ks >= 2 ? (int)ks : 0;
 }
 
 int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s) {
+#if !PD_IS_F16
   if (a.fp8) return kind == 0 ? launch256_splitk<0, true>(a, s) : launch256_splitk<2, true>(a, s);
+#endif
   return kind == 0 ? launch256_splitk<0>(a, s) : launch256_splitk<2>(a, s);
 }
 
@@ -486,6 +490,10 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind) {
 }
 
 int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s) {
+#if !PD_IS_F16
   if (a.fp8) return kind == 0 ? launch256<0, 8, true>(a, s) : launch256<2, 8, true>(a, s);
+#endif
   return kind == 0 ? launch256<0, 8>(a, s) : launch256<2, 8>(a, s);
 }
+
+}  // namespace PD_NS

@@ -88,7 +88,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const pd_igemm_args& p, cons
             hi[e] = h0 | ((uint32_t)h1 << 16);
             lo[e] = l0 | ((uint32_t)l1 << 16);
           } else {
-            hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            hi[e] = pack_op2(v[2 * e], v[2 * e + 1]);
           }
         }
         if constexpr (CW == 8) {

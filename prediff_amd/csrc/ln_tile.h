@@ -72,7 +72,7 @@ __device__ __forceinline__ void ln_block_to_tile(const float* __restrict__ x, co
       if (!ok) y0 = y1 = y2 = y3 = 0.f;
       // columns 4j + 64i .. +3: slab i, 16 B chunk j >> 1, half j & 1
       const int off = i * (BM * 128) + row * 128 + (((j >> 1) ^ ((row >> 1) & 7)) << 4) + ((j & 1) << 3);
-      *(uint2*)(sA + off) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+      *(uint2*)(sA + off) = make_uint2(pack_op2(y0, y1), pack_op2(y2, y3));
     }
   }
 }

@@ -2,6 +2,8 @@
 // one pass over the row (LayerNorm) or two passes over the sample (GroupNorm: stats, then apply+SiLU+cast).
 #include "common.h"
 
+namespace PD_NS {
+
 // -------------------------------------------------------------------------------------------------
 // LayerNorm over C (affine), one wave per row, two-pass in registers (exact mean / centered variance).
 // cuboid_transformer.py:813 / :197 (nn.LayerNorm eps 1e-5, models/utils.py:192-221)
@@ -49,9 +51,13 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
           int tt = to * dt + it, hh = ho * dh + ih, ww = wo * dw + iw;
           if (nearest) {
             // padding_type "nearest" (models/utils.py:228-256): the padded grid is F.interpolate(x, size = padded size), i.e. padded
-            // coordinate p reads source floor(p * size / padded size) -- always inside the tensor
+            // coordinate p reads a source coordinate inside the tensor
+            // -- with torch's own arithmetic: min(floor(p * float32(size / padded size)), size - 1), which is not the integer floor
+            // (22 padded to 26: position 13 reads 10, not 11)
             const int Tp = ((T + dt - 1) / dt) * dt, Hp = ((H + dh - 1) / dh) * dh, Wp = ((W + dw - 1) / dw) * dw;
-            tt = tt * T / Tp; hh = hh * H / Hp; ww = ww * W / Wp;
+            tt = min((int)floorf((float)tt * ((float)T / (float)Tp)), T - 1);
+            hh = min((int)floorf((float)hh * ((float)H / (float)Hp)), H - 1);
+            ww = min((int)floorf((float)ww * ((float)W / (float)Wp)), W - 1);
           }
           if (tt < T && hh < H && ww < W)
             t = *(const float4*)(x + ((((gb * T + tt) * H + hh) * W + ww) * (int64_t)Cs + cs));
@@ -112,7 +118,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         *(uint2*)(out_lo + row * (int64_t)ld_out + c) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
       } else {
         *(uint2*)(out + row * (int64_t)ld_out + c) =
-            make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+            make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
       }
     }
   }
@@ -134,8 +140,19 @@ static void launch_layernorm(const float* x, const float* gamma, const float* be
 #undef PD_LN
 }
 
-extern "C" int pd_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
-                            int64_t rows, int C, int ld_out, float eps, pd_stream_t stream) {
+#if !PD_IS_F16
+extern "C" int pd_f16_layernorm(const float*, const float*, const float*, pd_bf16*, pd_bf16*, int64_t, int, int, float, const pd_call_opts*, pd_stream_t);
+extern "C" int pd_f16_patch_merge_layernorm_ex(const float*, const float*, const float*, pd_bf16*, pd_bf16*, int, int, int, int, int, int, int, int, int,
+                                               float, int, const pd_call_opts*, pd_stream_t);
+extern "C" int pd_f16_groupnorm_silu(const float*, const float*, const float*, const float*, const float*, int, double*, pd_bf16*, pd_bf16*, int, int,
+                                     int, int, int, float, int, const pd_call_opts*, pd_stream_t);
+extern "C" int pd_f16_cast_rows(const float*, pd_bf16*, pd_bf16*, int64_t, int, int, int, int, int, int, const pd_call_opts*, pd_stream_t);
+#endif
+
+extern "C" int PD_ENTRY(layernorm)(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                                   int64_t rows, int C, int ld_out, float eps, const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_layernorm(x, gamma, beta, out, out_lo, rows, C, ld_out, eps, opts, stream));
+  PD_CHECK_ARG(!PD_IS_F16 || !out_lo, "pd_layernorm: the hi/lo split exists for bfloat16 operands only");
   PD_CHECK_ARG(x && gamma && beta && out, "pd_layernorm: null pointer");
   PD_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 256 * LN_MAXV, "pd_layernorm: C=%d must be a multiple of 4 and <= %d", C, 256 * LN_MAXV);
   PD_CHECK_ARG(ld_out >= C && (ld_out & 3) == 0 && ld_out <= ((C + 255) / 256) * 256,
@@ -146,6 +163,7 @@ extern "C" int pd_layernorm(const float* x, const float* gamma, const float* bet
   return PD_OK;
 }
 
+#if !PD_IS_F16
 extern "C" int pd_layernorm_fp8(const float* x, const float* gamma, const float* beta, uint8_t* out, int64_t rows, int C, int ld_out,
                                 float eps, float fp8_scale, pd_stream_t stream) {
   PD_CHECK_ARG(x && gamma && beta && out && fp8_scale > 0.f, "pd_layernorm_fp8: null pointer / bad scale");
@@ -159,9 +177,14 @@ extern "C" int pd_layernorm_fp8(const float* x, const float* gamma, const float*
   return PD_OK;
 }
 
-extern "C" int pd_patch_merge_layernorm_ex(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
-                                           int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
-                                           int pad_nearest, pd_stream_t stream) {
+#endif
+
+extern "C" int PD_ENTRY(patch_merge_layernorm_ex)(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
+                                                  int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
+                                                  int pad_nearest, const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_patch_merge_layernorm_ex(x, gamma, beta, out, out_lo, B, T, H, W, C, dt, dh, dw, ld_out, eps,
+                                                                    pad_nearest, opts, stream));
+  PD_CHECK_ARG(!PD_IS_F16 || !out_lo, "pd_patch_merge_layernorm: the hi/lo split exists for bfloat16 operands only");
   PD_CHECK_ARG(x && gamma && beta && out, "pd_patch_merge_layernorm: null pointer");
   const int Cm = C * dt * dh * dw;
   PD_CHECK_ARG((C & 3) == 0 && Cm <= 256 * LN_MAXV, "pd_patch_merge_layernorm: C=%d (merged %d) unsupported", C, Cm);
@@ -172,11 +195,13 @@ extern "C" int pd_patch_merge_layernorm_ex(const float* x, const float* gamma, c
   return PD_OK;
 }
 
+#if !PD_IS_F16
 extern "C" int pd_patch_merge_layernorm(const float* x, const float* gamma, const float* beta, pd_bf16* out, pd_bf16* out_lo,
                                         int B, int T, int H, int W, int C, int dt, int dh, int dw, int ld_out, float eps,
                                         pd_stream_t stream) {
-  return pd_patch_merge_layernorm_ex(x, gamma, beta, out, out_lo, B, T, H, W, C, dt, dh, dw, ld_out, eps, 0, stream);
+  return pd_patch_merge_layernorm_ex(x, gamma, beta, out, out_lo, B, T, H, W, C, dt, dh, dw, ld_out, eps, 0, nullptr, stream);
 }
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // GroupNorm on channels-last (B, S, C): pass 1 partial (sum, sumsq) per (sample, chunk of positions, group),
@@ -185,7 +210,11 @@ extern "C" int pd_patch_merge_layernorm(const float* x, const float* gamma, cons
 // -------------------------------------------------------------------------------------------------
 constexpr int GN_ROWS = 64;   // positions per stats block
 
+#if !PD_IS_F16
 extern "C" int pd_groupnorm_nchunk(int S, int C) { return (S + GN_ROWS - 1) / GN_ROWS; }
+#else
+extern "C" int pd_groupnorm_nchunk(int S, int C);
+#endif
 
 __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, double* __restrict__ partials, int S, int C,
                                                        int G) {
@@ -290,7 +319,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
       f2bf_split(y, hi, lo);
       ob[i] = hi; obl[i] = lo;
     } else {
-      ob[i] = f2bf(y);
+      ob[i] = f2op(y);
     }
   }
 }
@@ -404,7 +433,7 @@ __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restri
       ob[(int64_t)r * CV] = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
       obl[(int64_t)r * CV] = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
     } else {
-      ob[(int64_t)r * CV] = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+      ob[(int64_t)r * CV] = make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
     }
   }
 }
@@ -440,16 +469,18 @@ __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict_
   const int tid = threadIdx.x, slot = tid % TPR, rl = tid / TPR, wave = tid >> 6;
   const int c = chunk * CH + slot * 4, cpg = C / G, spg = cpg >> 2;   // float4 slots per group: 1, 2, 4 (or 8 with 32-channel chunks)
   // buffer addressing: the sample's rows behind one descriptor, lane offset in a VGPR, the sweep's offset in an SGPR -- no per-load
-  // address registers (35 in-flight 64-bit pointers were what spilled), and rows >= S read zeros / drop their stores by the range check
+  // address registers (35 in-flight 64-bit pointers were what spilled); rows >= S get an out-of-range lane offset: zeros / dropped stores
   const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * S * C), 0, (uint32_t)((int64_t)S * C * 4), 0x00020000);
   const auto rO = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * S * C), 0, (uint32_t)((int64_t)S * C * 2), 0x00020000);
   const uint32_t voff = (uint32_t)(rl * C + c) * 4u, sstep = (uint32_t)(RP * C) * 4u;
+  constexpr uint32_t GN_OOB = 0xFFFFF000u;
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
   typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
   float4 v[RMAX];
 #pragma unroll
   for (int i = 0; i < RMAX; ++i) {
-    const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rX, voff, (uint32_t)i * sstep, 0);
+    // rows >= S: an out-of-range LANE offset (whether the hardware's range check also counts the scalar offset is not relied upon)
+    const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rX, rl + RP * i < S ? voff : GN_OOB, (uint32_t)i * sstep, 0);
     v[i] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
   }
   // sum over the workgroup's values of this thread's group: row lanes of the wave (lane bits 3..5), the group's slots (lane bits
@@ -505,17 +536,19 @@ __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.f + __expf(-y[k]));
     }
-    const u32x2_t o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
-    __builtin_amdgcn_raw_buffer_store_b64(o, rO, voff >> 1, ((uint32_t)i * sstep) >> 1, 0);
+    const u32x2_t o = {pack_op2(y[0], y[1]), pack_op2(y[2], y[3])};
+    __builtin_amdgcn_raw_buffer_store_b64(o, rO, rl + RP * i < S ? voff >> 1 : GN_OOB, ((uint32_t)i * sstep) >> 1, 0);
     if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // (two rows at a time: an unbounded interleave of the 35 rows spilled)
   }
 }
 
-extern "C" int pd_groupnorm_onepass = 1;         // A/B: 0 = always the statistics + apply pair of launches
-
-extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, const float* ss_scale,
-                                 const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo, int B, int S,
-                                 int C, int G, int ld_out, float eps, int silu, pd_stream_t stream) {
+extern "C" int PD_ENTRY(groupnorm_silu)(const float* x, const float* gamma, const float* beta, const float* ss_scale,
+                                        const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo, int B, int S,
+                                        int C, int G, int ld_out, float eps, int silu, const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_groupnorm_silu(x, gamma, beta, ss_scale, ss_shift, ld_ss, partials, out, out_lo, B, S, C, G, ld_out,
+                                                          eps, silu, opts, stream));
+  PD_CHECK_ARG(!PD_IS_F16 || !out_lo, "pd_groupnorm_silu: the hi/lo split exists for bfloat16 operands only");
+  const bool onepass = !(opts && opts->groupnorm_two_launches);      // A/B: the statistics + apply pair of launches instead of the one-pass kernel
   PD_CHECK_ARG(x && gamma && beta && partials && out, "pd_groupnorm_silu: null pointer");
   PD_CHECK_ARG(G > 0 && C % G == 0 && ld_out >= C, "pd_groupnorm_silu: bad C/G/ld_out (%d,%d,%d)", C, G, ld_out);
   PD_CHECK_ARG((ss_scale == nullptr) == (ss_shift == nullptr), "pd_groupnorm_silu: scale/shift must come together");
@@ -527,7 +560,7 @@ extern "C" int pd_groupnorm_silu(const float* x, const float* gamma, const float
                    (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && (((uintptr_t)out | (uintptr_t)out_lo) & 7) == 0 &&
                    (!ss_scale || ((ld_ss % 4 == 0) && (((uintptr_t)ss_scale | (uintptr_t)ss_shift) & 15) == 0));
   // bf16 engine (no lo half), 16-channel chunks holding whole groups, at most 26 x 128 rows: everything of a (sample, chunk) in registers
-  if (vec && pd_groupnorm_onepass && !out_lo && C % 32 == 0 && 16 % cpg == 0 && S <= 128 * 26) {
+  if (vec && onepass && !out_lo && C % 32 == 0 && 16 % cpg == 0 && S <= 128 * 26) {
     if (S <= 64 * 16) hipLaunchKernelGGL((gn_onepass_kernel<16, 512, 32>), dim3(B * (C / 32)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, partials, nchunk, out, S, C, G, eps, silu);
     else hipLaunchKernelGGL((gn_onepass_kernel<26, 512, 16>), dim3(B * (C / 16)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, ld_ss, partials, nchunk, out, S, C, G, eps, silu);
     PD_CHECK_LAUNCH();
@@ -568,6 +601,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const double* __restri
   }
 }
 
+#if !PD_IS_F16
 extern "C" int pd_groupnorm_stats(const float* x, double* partials, float* stats, int B, int S, int C, int G, float eps, pd_stream_t stream) {
   PD_CHECK_ARG(x && partials && stats, "pd_groupnorm_stats: null pointer");
   PD_CHECK_ARG(G > 0 && C % G == 0 && G <= 4096 && B > 0 && S > 0, "pd_groupnorm_stats: bad B/S/C/G (%d,%d,%d,%d)", B, S, C, G);
@@ -716,6 +750,8 @@ extern "C" int pd_groupnorm_silu_bwd(const float* x, const float* dy, const floa
   return PD_OK;
 }
 
+#endif   // !PD_IS_F16 (statistics-only, e4m3 and backward entry points: one copy, in the bf16 build)
+
 // -------------------------------------------------------------------------------------------------
 // fp32 -> bf16 row cast with row-slice gather and zero column padding
 // -------------------------------------------------------------------------------------------------
@@ -734,13 +770,16 @@ __global__ void __launch_bounds__(256) cast_rows_kernel(const float* __restrict_
       f2bf_split(v, hi, lo);
       out[i] = hi; out_lo[i] = lo;
     } else {
-      out[i] = f2bf(v);
+      out[i] = f2op(v);
     }
   }
 }
 
-extern "C" int pd_cast_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t n_samples, int rows_per_sample_in, int row_off,
-                            int rows_per_sample_out, int C, int ld_in, int ld_out, pd_stream_t stream) {
+extern "C" int PD_ENTRY(cast_rows)(const float* x, pd_bf16* out, pd_bf16* out_lo, int64_t n_samples, int rows_per_sample_in, int row_off,
+                                   int rows_per_sample_out, int C, int ld_in, int ld_out, const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_cast_rows(x, out, out_lo, n_samples, rows_per_sample_in, row_off, rows_per_sample_out, C, ld_in,
+                                                     ld_out, opts, stream));
+  PD_CHECK_ARG(!PD_IS_F16 || !out_lo, "pd_cast_rows: the hi/lo split exists for bfloat16 operands only");
   PD_CHECK_ARG(x && out, "pd_cast_rows: null pointer");
   PD_CHECK_ARG(row_off >= 0 && row_off + rows_per_sample_out <= rows_per_sample_in && ld_in >= C && ld_out >= C, "pd_cast_rows: bad geometry");
   const int64_t rows = n_samples * rows_per_sample_out;
@@ -752,3 +791,5 @@ extern "C" int pd_cast_rows(const float* x, pd_bf16* out, pd_bf16* out_lo, int64
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
+
+}  // namespace PD_NS

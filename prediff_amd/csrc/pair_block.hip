@@ -32,6 +32,8 @@
 #include <type_traits>
 #include "common.h"
 
+namespace PD_NS {
+
 // No implicit mul + add contraction in this file: the instantiations of the kernel (one / two groups per wave, units 256 / 512) must
 // compute a row with the SAME fp32 operations -- the batch-split-reproducible mode of the engine runs a trajectory through whichever
 // instantiation its launch size selects and promises bit-identical results (tests/test_hip_configs.py::test_v1_lane_split_tolerance;
@@ -117,16 +119,15 @@ __device__ __forceinline__ float pk_rows4_sum(float v) {
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
-// fp32 -> bf16 (RNE) through the compiler's own v_cvt_pk_bf16_f32 (NOT common.h's inline-asm form: hipcc pads no hazard wait states
+// fp32 -> operand type (RNE) through the compiler's own v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (common.h cvt_op4; NOT the inline-asm form: hipcc pads no hazard wait states
 // around an asm statement, and here the conversions sit directly between MFMAs -- an asm v_cvt reading a fresh MFMA result, or an MFMA
 // reading a fresh asm v_cvt result, gets stale registers; measured: wrong O tiles / NaNs in the first build of this kernel)
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-__device__ __forceinline__ bf16x8 pk_pack8(const f32x4& a, const f32x4& b) {
-  const bf16x4 lo = __builtin_convertvector(a, bf16x4), hi = __builtin_convertvector(b, bf16x4);
+__device__ __forceinline__ op8 pk_pack8(const f32x4& a, const f32x4& b) {
+  const op4v lo = cvt_op4(a), hi = cvt_op4(b);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
-  return __builtin_bit_cast(s16x4, __builtin_convertvector(a, bf16x4));
+  return __builtin_bit_cast(s16x4, cvt_op4(a));
 }
 // GELU: common.h gelu_sigmoid / gelu_sigmoid_arg (x * sigmoid(x (a + b x^2 + c x^4)), 2.5e-5 from the erf form)
 #define pk_gelu_arg gelu_sigmoid_arg
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #define PK_TRACE() do {} while (0)
 #endif
   int cc = 0;                                       // chunks consumed by this workgroup
-  bf16x8 w[PFN] = {};                               // fragment pipeline (runs on across chunks, tiles and phases)
+  op8 w[PFN] = {};                               // fragment pipeline (runs on across chunks, tiles and phases)
 
   // One chunk = 32 fragments = 16 groups of two.  Per group: two fragment reads three groups ahead, ONE counted wait, the MFMAs of the
   // group's two fragments (BODY_STMT, once per fragment: `i`, `wf`) and HOOK_STMT (`gi`): independent work for their shadow
@@ -281,8 +282,8 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
                    : "n"(PF + (2 * gi < PF ? (NEXTRA) : 0)));                                     \
       if (gi == PF / 2) { LANDED_STMT; }                                                          \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-      { const int i = 2 * gi; const bf16x8 wf = w[i % PFN]; BODY_STMT; }                          \
-      { const int i = 2 * gi + 1; const bf16x8 wf = w[i % PFN]; BODY_STMT; }                      \
+      { const int i = 2 * gi; const op8 wf = w[i % PFN]; BODY_STMT; }                          \
+      { const int i = 2 * gi + 1; const op8 wf = w[i % PFN]; BODY_STMT; }                      \
       { HOOK_STMT; }                                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
@@ -292,22 +293,22 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #define PK_MFMA_T(ACC, AF, SUB) /* ... a head's Wq / Wk ([HD x C], transposed product): feature tile i % DT, k-step SUB * 32 / DT + i / DT */ \
   if (PK_MFMA_ON) {                                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
-      ACC[c_][i % DT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[c_][(SUB) * (32 / DT) + i / DT], ACC[c_][i % DT], 0, 0, 0); \
+      ACC[c_][i % DT] = mfma_16x16x32(wf, AF[c_][(SUB) * (32 / DT) + i / DT], ACC[c_][i % DT]); \
   }
 #define PK_MFMA_V(ACC, AF, SUB) /* ... a head's Wv (plain product: lane = feature, 4 consecutive tokens) */             \
   if (PK_MFMA_ON) {                                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
-      ACC[c_][i % DT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[c_][(SUB) * (32 / DT) + i / DT], wf, ACC[c_][i % DT], 0, 0, 0); \
+      ACC[c_][i % DT] = mfma_16x16x32(AF[c_][(SUB) * (32 / DT) + i / DT], wf, ACC[c_][i % DT]); \
   }
 #define PK_MFMA_H(ACC, AF, SUB) /* ... W1_j ([64 x C]): hidden tile i & 3, k-step 8 SUB + i / 4 */                      \
   if (PK_MFMA_ON) {                                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
-      ACC[c_][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, AF[c_][(SUB) * 8 + (i >> 2)], ACC[c_][i & 3], 0, 0, 0); \
+      ACC[c_][i & 3] = mfma_16x16x32(wf, AF[c_][(SUB) * 8 + (i >> 2)], ACC[c_][i & 3]); \
   }
 #define PK_MFMA_OUT(OF, SUB) /* ... a [C outputs x k] slice of Wproj / W2 (x^T += W act^T): column tile i % CT, k-step SUB * 32 / CT + i / CT */ \
   if (PK_MFMA_ON) {                                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
-      acc[c_][i % CT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, OF[c_][(SUB) * (32 / CT) + i / CT], acc[c_][i % CT], 0, 0, 0); \
+      acc[c_][i % CT] = mfma_16x16x32(wf, OF[c_][(SUB) * (32 / CT) + i / CT], acc[c_][i % CT]); \
   }
 
   // rows of a tile's 16-slot groups for this lane = (slot q, column group g), as byte offsets into x / out.  A group holds ONE cuboid,
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
       }
     };
 #endif
-    bf16x8 af[NC][KS];                               // LayerNorm output as B-operand fragments: [group][k-step of 32]
+    op8 af[NC][KS];                               // LayerNorm output as B-operand fragments: [group][k-step of 32]
     // LayerNorm over the C columns of a row (C / 4 in this lane, the rest in lanes q + 16 g'), -> af
     auto layer_norm = [&](const f32x4 (&src)[NC][CT], int t_gamma, int t_beta, float eps) {
       float mean[NC], rstd[NC];
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
       constexpr int FM = decltype(fm_tag)::value;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       f32x4 t[NC][DT];
-      bf16x8 qf[NC][HS], kf[NC][HS];
+      op8 qf[NC][HS], kf[NC][HS];
       f32x4 rb;                                     // relative-position bias of (head h, query slot q, key slots 4 g .. 4 g + 3); -inf = no such pair
       const uint32_t vrb_h = vrb + (uint32_t)h * 1024u;
       // ---------------- q^T = Wq_h a^T  (first head: the previous tile's rows leave in its shadow) ----------------
@@ -539,7 +540,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #pragma unroll
         for (int s = 0; s < HS; ++s) {
           kf[c][s] = pk_pack8(t[c][2 * s], t[c][2 * s + 1]);
-          s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c][s], qf[c][s], s4, 0, 0, 0);
+          s4 = mfma_16x16x32(kf[c][s], qf[c][s], s4);
         }
         float sc[4], mx = -3.0e38f;
 #pragma unroll
@@ -571,7 +572,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #define PK_V_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(2 * NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_V(t, af, SUB), (void)0)
       PK_V_CHUNK(0) PK_V_CHUNK(1) PK_V_CHUNK(2) PK_V_CHUNK(3)
       PK_DRAIN();
-      bf16x8 of[NC][HS];
+      op8 of[NC][HS];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         f32x4 o[DT];
@@ -579,7 +580,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
         if (h == 0) dump4(5, c, t[c][0], t[c][1], t[c][2], t[c][3]);
 #endif
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk_pack4(t[c][dt]), pf[c], z4, 0, 0, 0);
+        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_16x16x16(pk_pack4(t[c][dt]), pf[c], z4);
 #if PD_PAIR_DEBUG
         if (h == 0) dump4(6, c, o[0], o[1], o[2], o[3]);
 #endif
@@ -675,7 +676,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
     } else {
       PK_W1_SLICE(hn, vb1_2, PK_GELU_SP(hc, 2, gi), (void)0, PK_GELU_SP(hc, 2, 16 + gi), PK_GELU_SP(hc, 2, 32))
     }
-    bf16x8 hfr[NC][2];
+    op8 hfr[NC][2];
     PK_PACK_H(hc)
     PK_TRACE();   // W1_1 done
     // invariant: hfr = gelu(h_j) as fragments, hn = h_{j+1} (pre-activation), b1n = b1 of slice j + 2
@@ -765,27 +766,36 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   return PD_OK;
 }
 
-extern "C" unsigned long long* pd_pair_trace = nullptr;
-extern "C" int pd_pair_force_nc = 0;             // A/B at units 256: 1 / 2 = 16-slot groups per wave (four waves), 8 = eight waves of one group, whatever the grid; 0 = automatic
 #ifndef PD_PAIR_BIG_FORM
 #define PD_PAIR_BIG_FORM 8                       // the form of the 128-row tiles: 2 (four waves x two groups) or 8 (eight waves x one group)
 #endif
-#if PD_PAIR_DEBUG
-extern "C" float* pd_pair_dbg_buf = nullptr;    // (profiling / debugging builds only: scripts/debug_pair.py)
+#if PD_PAIR_DEBUG && !PD_IS_F16
+extern "C" float* pd_pair_dbg_buf = nullptr;    // (debugging builds only -- never part of the shipped library: scripts/debug_pair.py)
 extern "C" int pd_pair_dbg_stage = 0;
+#elif PD_PAIR_DEBUG
+extern "C" float* pd_pair_dbg_buf;
+extern "C" int pd_pair_dbg_stage;
 #endif
 
+#if !PD_IS_F16
 extern "C" int pd_attn_ffn_pair_supported(int C, int heads, int hidden, int vol, int act) {
   return ((C == 256 && hidden == 1024) || (C == 512 && hidden == 2048)) && heads == 4 && vol >= 1 && vol <= 16 && act == PD_ACT_GELU;
 }
 
 // cuboids of one 16-slot group (the relative-position table of `vecs` is laid out for the same number: packing.pack_pair_vecs)
 extern "C" int pd_attn_ffn_pair_cuboids_per_group(int vol) { return vol >= 1 && 2 * vol <= 16 ? 2 : 1; }
+extern "C" int pd_f16_attn_ffn_pair(const float*, float*, const void*, const float*, const int32_t*, const int32_t*, int, int, int, int, int, float, float,
+                                    float, const pd_call_opts*, pd_stream_t);
+#else
+extern "C" int pd_attn_ffn_pair_cuboids_per_group(int vol);
+#endif
 
-extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
-                                const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn,
-                                float eps_ffn, pd_stream_t stream) {
+extern "C" int PD_ENTRY(attn_ffn_pair)(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
+                                       const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn,
+                                       float eps_ffn, const pd_call_opts* opts, pd_stream_t stream) {
   using namespace pairk;
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_attn_ffn_pair(x, out, wstream, vecs, tok_index, tok_affine, B, ntok, nc, vol, units, scale, eps_attn,
+                                                         eps_ffn, opts, stream));
   PD_CHECK_ARG(x && out && wstream && vecs, "pd_attn_ffn_pair: null pointer");
   PD_CHECK_ARG(units == 256 || units == 512, "pd_attn_ffn_pair: units %d (256 or 512)", units);
   PD_CHECK_ARG(B > 0 && ntok > 0 && (int64_t)B * ntok < (1ll << 31), "pd_attn_ffn_pair: bad sizes");
@@ -797,7 +807,7 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   a.scale = scale; a.eps1 = eps_attn; a.eps2 = eps_ffn;
   a.wbytes = (uint32_t)((units == 256 ? G<1>::CH_ALL : G<2>::CH_ALL) * CHUNK);
   a.xbytes = (uint32_t)((int64_t)B * ntok * (units * 4));
-  a.trace = pd_pair_trace;
+  a.trace = opts ? opts->trace : nullptr;          // (clock stamps: -DPD_PAIR_DEBUG=1 builds only)
 #if PD_PAIR_DEBUG
   a.dbg_buf = pd_pair_dbg_buf;
   a.dbg_stage = pd_pair_dbg_stage;
@@ -820,9 +830,10 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   }
   // 128-row tiles once that leaves no CU idle -- as two groups per wave (four waves, every weight fragment feeds two MFMAs) or as
   // eight waves of one group (two waves per SIMD, 256 registers each: one wave's LayerNorm / softmax / GELU / row traffic runs beside
-  // the other's MFMAs; pd_pair_force_nc = 8); below that ONE group per wave and four waves (64-row tiles): twice the workgroups,
+  // the other's MFMAs; opts->pair_form = 8); below that ONE group per wave and four waves (64-row tiles): twice the workgroups,
   // half the MFMAs per streamed chunk -- the small-batch form
-  const int nc_wave = pd_pair_force_nc ? pd_pair_force_nc : ((groups + 7) / 8 > 128 ? PD_PAIR_BIG_FORM : 1);
+  const int force = opts ? opts->pair_form : 0;      // A/B: 1 / 2 = 16-slot groups per wave (four waves), 8 = eight waves of one group
+  const int nc_wave = force ? force : ((groups + 7) / 8 > 128 ? PD_PAIR_BIG_FORM : 1);
   if (nc_wave == 8) {
     a.ntiles = (int)((groups + 7) / 8);
     return launch_pair<1, 1, 8>(a, (hipStream_t)stream);
@@ -830,3 +841,5 @@ extern "C" int pd_attn_ffn_pair(const float* x, float* out, const void* wstream,
   a.ntiles = (int)((groups + 4 * nc_wave - 1) / (4 * nc_wave));
   return nc_wave == 2 ? launch_pair<2, 1>(a, (hipStream_t)stream) : launch_pair<1, 1>(a, (hipStream_t)stream);
 }
+
+}  // namespace PD_NS

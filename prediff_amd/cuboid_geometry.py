@@ -37,6 +37,14 @@ def relative_position_index(cuboid: Sequence[int]) -> torch.Tensor:
     return torch.from_numpy((dt * (2 * bh - 1) + dh) * (2 * bw - 1) + dw).long()
 
 
+def nearest_source_index(n_in: int, n_out: int) -> np.ndarray:
+    """src[o] = the input index F.interpolate(mode="nearest") reads for output index o when an axis of n_in is resized to n_out
+    (torch: min(floor(o * float32(n_in / n_out)), n_in - 1)), obtained by resizing an index ramp with F.interpolate itself."""
+    import torch.nn.functional as F
+    ramp = torch.arange(n_in, dtype=torch.float32).reshape(1, 1, n_in)
+    return F.interpolate(ramp, size=n_out, mode="nearest").reshape(n_out).long().numpy()
+
+
 def _slot_coords(padded: Tuple[int, int, int], cuboid, strategy):
     """Per axis: (n_cuboids, block) array of padded-space coordinates. 'l' contiguous, 'd' strided by n."""
     out = []
@@ -78,14 +86,16 @@ def attention_tables(shape, cuboid, shift, strategy, padding_type):
     st, s_h, sw = (ct + sh[0]) % P[0], (ch + sh[1]) % P[1], (cw + sh[2]) % P[2]
     tok_out = None
     if padding_type == "nearest" and any(pad):
-        # models/utils.py:228-270: the padded grid is F.interpolate(x, size=P) (nearest): padded position p holds token floor(p * size / P)
-        # per axis -- several slots read one token -- and the un-padding is F.interpolate back to (T, H, W): token o receives the result
-        # of padded position floor(o * P / size).  So the gather table and the table of receivers differ (pd_cuboid_attn_args.tok_out).
-        src = lambda p, n, Pn: (p * n) // Pn
-        tok = _flatten_slots(st, s_h, sw, lambda t, h, w: (src(t, T, P[0]) * H + src(h, H, P[1])) * W + src(w, W, P[2]))
+        # models/utils.py:228-270: the padded grid is F.interpolate(x, size=P) (nearest) -- several slots read one token -- and the
+        # un-padding is F.interpolate back to (T, H, W).  torch's nearest rule is floor(dst * float32(in / out)) clamped to in - 1, which
+        # is NOT floor(dst * in / out) in integers (axis 22 padded to 26: padded position 13 reads token 10, the integer rule says 11),
+        # so both maps come from F.interpolate itself, per axis (nearest resizing is separable): exact by construction.
+        up = [nearest_source_index(n, Pn) for n, Pn in zip((T, H, W), P)]        # padded position -> source token coordinate
+        down = [nearest_source_index(Pn, n) for n, Pn in zip((T, H, W), P)]      # token coordinate -> padded position it receives from
+        tok = _flatten_slots(st, s_h, sw, lambda t, h, w: (up[0][t] * H + up[1][h]) * W + up[2][w])
         recv = np.full(P, -1, dtype=np.int64)                 # padded position -> receiving token
         ot, oh, ow = np.meshgrid(np.arange(T), np.arange(H), np.arange(W), indexing="ij")
-        recv[(ot * P[0]) // T, (oh * P[1]) // H, (ow * P[2]) // W] = (ot * H + oh) * W + ow
+        recv[down[0][ot], down[1][oh], down[2][ow]] = (ot * H + oh) * W + ow
         tok_out = _flatten_slots(st, s_h, sw, lambda t, h, w: recv[t, h, w])
         assert sorted(tok_out[tok_out >= 0].tolist()) == list(range(T * H * W))
     else:

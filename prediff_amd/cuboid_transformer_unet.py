@@ -328,9 +328,19 @@ class CuboidTransformerUNet(nn.Module):
             raise NotImplementedError(f"norm_layer={norm_layer!r}")
         if downsample_type != "patch_merge" or upsample_type != "upsample":
             raise NotImplementedError
-        if precision not in ("bf16", "fp32", "fp8", "fp8_conv"):
-            raise ValueError("precision must be 'bf16' (throughput), 'fp32' (hi/lo split, fp32-class accuracy), 'fp8_conv' (bf16 engine with "
-                             "e4m3 operands for the 3x3x3 convolutions) or 'fp8' (e4m3 for the convolutions and the K >= 512 token linears)")
+        if precision not in ("bf16", "fp16", "fp32", "fp8", "fp8_conv"):
+            raise ValueError("precision must be 'bf16' (throughput), 'fp16' (the same engine on IEEE-half operands: TF32-class accuracy at the "
+                             "bf16 rate), 'fp32' (hi/lo split, fp32-class accuracy), 'fp8_conv' (bf16 engine with e4m3 operands for the 3x3x3 "
+                             "convolutions) or 'fp8' (e4m3 for the convolutions and the K >= 512 token linears)")
+        # "fp16": every kernel of the "bf16" engine with IEEE half as the 16-bit operand type (the library's pd_f16_* builds): 11-bit
+        # significands where bf16 has 8 -- the precision class of the reference's own GPU setting (float32_matmul_precision "high" = TF32,
+        # scripts/prediff/sevirlr/prediff_sevirlr_v1.yaml:63) at the bf16 MFMA rate.  Range 65504: the packers saturate; everything that is
+        # rounded to 16 bits sits behind a LayerNorm / GroupNorm / softmax / GELU, the residual stream stays fp32.
+        self.operand = "fp16" if precision == "fp16" else "bf16"
+        # per-call options handed to every launch of this module (operand type + A/B switches: bench.py / scripts set attributes here;
+        # nothing is process-global, two modules in one process do not see each other's settings)
+        self.opts = L.CallOpts(self.operand)
+        self.op_dtype = self.opts.dtype
         # "fp8_conv": the bf16 engine with the TimeEmbedResBlock convolutions (45 % of the FLOPs, the long-K launches) on OCP e4m3
         # operands through the scaled K = 128 MFMA; everything else as in "bf16".  "fp8" (BASELINE config 5's operand type): also the
         # K >= 512 token linears (qkv / proj / FFN of the level >= 1 blocks), their A operands written as e4m3 by LayerNorm, the attention
@@ -338,7 +348,8 @@ class CuboidTransformerUNet(nn.Module):
         # 6 % with the linears as well (tests/test_hip_configs.py prints both).
         self.fp8_conv = precision in ("fp8", "fp8_conv")
         self.fp8_linear = precision == "fp8"
-        self.precision = "bf16" if self.fp8_conv else precision
+        self.precision = "bf16" if (self.fp8_conv or precision == "fp16") else precision     # "bf16" = the single-pass 16-bit-operand engine
+        self.precision_name = precision
         self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
         self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 64)
         # bf16 mode: one launch per (attention, FFN) pair with the rows register resident (csrc/pair_block.hip) where the block has the
@@ -510,7 +521,7 @@ class CuboidTransformerUNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ packing
     def _params_key(self, device):
-        return (str(device), self.precision, self.fp8_conv, self.fp8_linear) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (str(device), self.precision, self.operand, self.fp8_conv, self.fp8_linear) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _packers(self, P: Dict[str, object], device):
         """The per-module packing functions (writing into P): lin, conv, norm, resblock, stack.  `_pack` runs them over the whole
@@ -521,7 +532,7 @@ class CuboidTransformerUNet(nn.Module):
             return t.detach().float().contiguous().to(device)
 
         def lin(name, m: nn.Linear, fp8_ok=False):
-            P[name + ".w"] = pack_linear(m.weight.to(device), split)
+            P[name + ".w"] = pack_linear(m.weight.to(device), split, dtype=self.op_dtype)
             P[name + ".b"] = f32(m.bias) if m.bias is not None else None
             # precision="fp8": the long-K token linears (K >= 512: the level >= 1 blocks) on e4m3 operands too -- pd_igemm's fp8 form needs
             # K % 128 == 0, and an e4m3-producing epilogue in front of it needs N % 8 == 0
@@ -529,7 +540,7 @@ class CuboidTransformerUNet(nn.Module):
                 P[name + ".w8"] = pack_linear_fp8(m.weight.to(device))                   # (e4m3 (N, K), scale)
 
         def conv(name, m):
-            P[name + ".w"] = pack_conv(m.weight.to(device), split)
+            P[name + ".w"] = pack_conv(m.weight.to(device), split, dtype=self.op_dtype)
             P[name + ".b"] = f32(m.bias) if m.bias is not None else None
 
         def norm(name, m):
@@ -575,7 +586,8 @@ class CuboidTransformerUNet(nn.Module):
                             and L.attn_ffn_pair_supported(at.dim, at.num_heads, ff.ffn_1.out_features, geo["vol"], ff.activation_name)):
                         na, nf = f"{name}.attn{a}", f"{name}.ffn{a}"
                         P[f"{name}.pair{a}"] = (
-                            pack_pair_block(at.qkv.weight.to(device), at.proj.weight.to(device), ff.ffn_1.weight.to(device), ff.ffn_2.weight.to(device)),
+                            pack_pair_block(at.qkv.weight.to(device), at.proj.weight.to(device), ff.ffn_1.weight.to(device), ff.ffn_2.weight.to(device),
+                                            dtype=self.op_dtype),
                             pack_pair_vecs(P[na + ".ln.g"], P[na + ".ln.beta"], P[na + ".proj.b"], P[nf + ".ln.g"], P[nf + ".ln.beta"],
                                            P[nf + ".fc2.b"], P[nf + ".fc1.b"], P[na + ".bias"]),
                             float(at.norm.eps), float(ff.layer_norm.eps))
@@ -639,7 +651,7 @@ class CuboidTransformerUNet(nn.Module):
 
     def _bf(self, name, rows, cols, device):
         """bf16 operand buffer pair (hi, lo-or-None)."""
-        hi = self._buf(name, (rows, cols), torch.bfloat16, device)
+        hi = self._buf(name, (rows, cols), self.op_dtype, device)
         lo = self._buf(name + ".lo", (rows, cols), torch.bfloat16, device) if self.precision == "fp32" else None
         return hi, lo
 
@@ -664,7 +676,7 @@ class CuboidTransformerUNet(nn.Module):
         kw = {}
         if ss is not None:
             kw = dict(ss_scale=ss, ss_shift=ss[:, C:], ld_ss=2 * C)
-        L.groupnorm_silu(x, g, beta, part, hi, lo, B, S, C, G, ld, 1e-5, silu=silu, **kw)
+        L.groupnorm_silu(x, g, beta, part, hi, lo, B, S, C, G, ld, 1e-5, silu=silu, **kw, opts=self.opts)
         return hi, lo, ld
 
     SPLITK_WS_ELEMS = 16 * 1024 * 1024      # fp32 partial-sum workspace (64 MB per workspace set) for split-K Conv3d launches
@@ -692,13 +704,13 @@ class CuboidTransformerUNet(nn.Module):
             w8, sw = P[name + ".conv1.w8"]
             L.igemm(a8, w8, M=B * S, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, bias=P[name + ".conv1.b"],
                     rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h,
-                    alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True, splitk_ws=ws)
+                    alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True, splitk_ws=ws, opts=self.opts)
         else:
             a1, a1lo, ld1 = self._gn(x, P[name + ".gn1.g"], P[name + ".gn1.beta"], B, S, Cin, m.in_groups, "gn.a", dev)
             w1, w1lo = P[name + ".conv1.w"]
             L.igemm(a1, w1, A_lo=a1lo, W_lo=w1lo, M=B * S, N=Cout, Cin=ld1, taps=27, w_tap_stride=Cout * ld1, geom=geom,
                     bias=P[name + ".conv1.b"], rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h,
-                    splitk_ws=ws)
+                    splitk_ws=ws, opts=self.opts)
         ldo = pad64(Cout)
         fp8_2 = (name + ".conv2.w8") in P
         if fp8_2:
@@ -715,19 +727,19 @@ class CuboidTransformerUNet(nn.Module):
         else:
             # 1x1x1 (or 3x3x3 when use_conv) skip on the raw input, written to `out`, then accumulated into by conv2
             xa, xalo = self._bf("skip.a", B * S, ld1, dev)
-            L.cast_rows(x, xa, xalo, B, S, 0, S, Cin, Cin, ld1)
+            L.cast_rows(x, xa, xalo, B, S, 0, S, Cin, Cin, ld1, opts=self.opts)
             wsk, wsklo = P[name + ".skip.w"]
             k = m.skip_connection.kernel_size[0]
             L.igemm(xa, wsk, A_lo=xalo, W_lo=wsklo, M=B * S, N=Cout, Cin=ld1, taps=k ** 3, w_tap_stride=Cout * ld1,
-                    geom=L.conv_geom(B, thw, (k, k, k), pad=(k // 2,) * 3), bias=P[name + ".skip.b"], out_f32=out)
+                    geom=L.conv_geom(B, thw, (k, k, k), pad=(k // 2,) * 3), bias=P[name + ".skip.b"], out_f32=out, opts=self.opts)
             res = out
         if fp8_2:
             w8, sw = P[name + ".conv2.w8"]
             L.igemm(a28, w8, M=B * S, N=Cout, Cin=Cout, taps=27, w_tap_stride=Cout * Cout, geom=geom, bias=P[name + ".conv2.b"],
-                    residual=res, out_f32=out, alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True, splitk_ws=ws)
+                    residual=res, out_f32=out, alpha=1.0 / (self.FP8_ACT_SCALE * sw), fp8=True, splitk_ws=ws, opts=self.opts)
         else:
             L.igemm(a2, w2, A_lo=a2lo, W_lo=w2lo, M=B * S, N=Cout, Cin=ldo, taps=27, w_tap_stride=Cout * ldo, geom=geom,
-                    bias=P[name + ".conv2.b"], residual=res, out_f32=out, splitk_ws=ws)
+                    bias=P[name + ".conv2.b"], residual=res, out_f32=out, splitk_ws=ws, opts=self.opts)
         return out
 
     def _patch_merge(self, P, name, dl: PatchMerging3D, x, B, thw, Cp, Cout, ds, out, dev):
@@ -738,9 +750,9 @@ class CuboidTransformerUNet(nn.Module):
         ldm = pad64(Km)
         a, alo = self._bf("pm.a", B * So, ldm, dev)
         L.patch_merge_layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B, Tp, Hp, Wp, Cp, ds, ldm,
-                                pad_nearest=dl.padding_type == "nearest")
+                                pad_nearest=dl.padding_type == "nearest", opts=self.opts)
         wr, wrlo = P[name + ".red.w"]
-        L.igemm(a, wr, A_lo=alo, W_lo=wrlo, M=B * So, N=Cout, Cin=ldm, out_f32=out)
+        L.igemm(a, wr, A_lo=alo, W_lo=wrlo, M=B * So, N=Cout, Cin=ldm, out_f32=out, opts=self.opts)
 
     def _upsample(self, P, name, x, B, thw, Ci, out_hw, Cn, k, res, out, dev):
         """Upsample3DLayer.forward (cuboid_transformer.py:299-373): nearest x2 in (H, W) + Conv2d k x k per frame [+ fp32 residual]."""
@@ -751,11 +763,11 @@ class CuboidTransformerUNet(nn.Module):
         Si = Ti * Hi * Wi
         ldc = pad64(Ci)
         a, alo = self._bf("up.a", B * Si, ldc, dev)
-        L.cast_rows(x, a, alo, B, Si, 0, Si, Ci, Ci, ldc)
+        L.cast_rows(x, a, alo, B, Si, 0, Si, Ci, Ci, ldc, opts=self.opts)
         geom = L.conv_geom(B * Ti, (1, Hi, Wi), (1, k, k), pad=(0, k // 2, k // 2), up=(1, 2, 2), out_thw=(1, Hn, Wn), virt_thw=(1, Hn, Wn))
         wu, wulo = P[name + ".conv.w"]
         L.igemm(a, wu, A_lo=alo, W_lo=wulo, M=B * Ti * Hn * Wn, N=Cn, Cin=ldc, taps=k * k, w_tap_stride=Cn * ldc, geom=geom,
-                bias=P[name + ".conv.b"], residual=res, out_f32=out)
+                bias=P[name + ".conv.b"], residual=res, out_f32=out, opts=self.opts)
 
     def _attention(self, P, name, at: CuboidSelfAttentionLayer, x, B, S, C, tabs, geo, dev):
         """x += CuboidSelfAttentionLayer(x)  (cuboid_transformer.py:812-966, residual of :1151)."""
@@ -769,7 +781,7 @@ class CuboidTransformerUNet(nn.Module):
             # one launch, q/k/v/attention output never leave the CU (csrc/attn_block.hip)
             L.attn_block_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".qkv.w"][0], P[name + ".qkv.b"],
                                P[name + ".proj.w"][0], P[name + ".proj.b"], tabs["tok"], P[name + ".bias"], tabs["mask"],
-                               B, S, C, at.num_heads, geo["nc"], geo["vol"], float(at.scale), tok_affine=geo.get("affine"))
+                               B, S, C, at.num_heads, geo["nc"], geo["vol"], float(at.scale), tok_affine=geo.get("affine"), opts=self.opts)
             return
         if ((name + ".qkv.w8") in P and (name + ".proj.w8") in P and geo["vol"] <= 64 and (C // at.num_heads) % 32 == 0 and ld == C
                 and tabs.get("tok_out") is None):
@@ -780,16 +792,16 @@ class CuboidTransformerUNet(nn.Module):
             L.layernorm_fp8(x, P[name + ".ln.g"], P[name + ".ln.beta"], a8, B * S, C, C, float(2 ** k8))
             w8, sw = P[name + ".qkv.w8"]
             qkv = self._buf("qkv.bf16", (B * S, 3 * C), torch.bfloat16, dev)
-            L.igemm(a8, w8, M=B * S, N=3 * C, Cin=C, bias=P[name + ".qkv.b"], out_bf16=qkv, alpha=1.0 / (2 ** k8 * sw), fp8=True)
+            L.igemm(a8, w8, M=B * S, N=3 * C, Cin=C, bias=P[name + ".qkv.b"], out_bf16=qkv, alpha=1.0 / (2 ** k8 * sw), fp8=True, opts=self.opts)
             o8 = self._buf("attn.o8", (B * S, C), torch.float8_e4m3fn, dev)
             L.cuboid_attention(qkv_bf16=qkv, out_bf16=o8, tok_index=tabs["tok"], bias=P[name + ".bias"], mask=tabs["mask"], B=B, ntok=S,
                                Cn=C, heads=at.num_heads, nc=geo["nc"], vol=geo["vol"], ld_qkv=3 * C, ld_out=C, scale=float(at.scale),
-                               out_fp8_log2=k8)
+                               out_fp8_log2=k8, opts=self.opts)
             w8, sw = P[name + ".proj.w8"]
-            L.igemm(o8, w8, M=B * S, N=C, Cin=C, bias=P[name + ".proj.b"], residual=x, out_f32=x, alpha=1.0 / (2 ** k8 * sw), fp8=True)
+            L.igemm(o8, w8, M=B * S, N=C, Cin=C, bias=P[name + ".proj.b"], residual=x, out_f32=x, alpha=1.0 / (2 ** k8 * sw), fp8=True, opts=self.opts)
             return
         a, alo = self._bf("ln.a", B * S, ld, dev)
-        L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld)
+        L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld, opts=self.opts)
         wq, wqlo = P[name + ".qkv.w"]
         fp32 = self.precision == "fp32"
         o, olo = self._bf("attn.o", B * S, ld, dev)
@@ -799,15 +811,15 @@ class CuboidTransformerUNet(nn.Module):
         of32 = self._buf("attn.of32", (B * S, ld), torch.float32, dev) if need_f32_out else None
         if fp32:
             qkv = self._buf("qkv.f32", (B * S, 3 * C), torch.float32, dev)
-            L.igemm(a, wq, A_lo=alo, W_lo=wqlo, M=B * S, N=3 * C, Cin=ld, bias=P[name + ".qkv.b"], out_f32=qkv)
-            L.cuboid_attention(qkv_f32=qkv, out_bf16=o, out_bf16_lo=olo, out_f32=of32, **kw)
+            L.igemm(a, wq, A_lo=alo, W_lo=wqlo, M=B * S, N=3 * C, Cin=ld, bias=P[name + ".qkv.b"], out_f32=qkv, opts=self.opts)
+            L.cuboid_attention(qkv_f32=qkv, out_bf16=o, out_bf16_lo=olo, out_f32=of32, **kw, opts=self.opts)
         else:
-            qkv = self._buf("qkv.bf16", (B * S, 3 * C), torch.bfloat16, dev)
-            L.igemm(a, wq, M=B * S, N=3 * C, Cin=ld, bias=P[name + ".qkv.b"], out_bf16=qkv)
-            L.cuboid_attention(qkv_bf16=qkv, out_bf16=o, out_f32=of32, **kw)
+            qkv = self._buf("qkv.bf16", (B * S, 3 * C), self.op_dtype, dev)
+            L.igemm(a, wq, M=B * S, N=3 * C, Cin=ld, bias=P[name + ".qkv.b"], out_bf16=qkv, opts=self.opts)
+            L.cuboid_attention(qkv_bf16=qkv, out_bf16=o, out_f32=of32, **kw, opts=self.opts)
         if at.use_final_proj:
             wp, wplo = P[name + ".proj.w"]
-            L.igemm(o, wp, A_lo=olo, W_lo=wplo, M=B * S, N=C, Cin=ld, bias=P[name + ".proj.b"], residual=x, out_f32=x)
+            L.igemm(o, wp, A_lo=olo, W_lo=wplo, M=B * S, N=C, Cin=ld, bias=P[name + ".proj.b"], residual=x, out_f32=x, opts=self.opts)
         else:
             L.add(x, of32, x, B * S * C) if ld == C else self._raise("use_final_proj=False needs C % 64 == 0")
 
@@ -823,7 +835,7 @@ class CuboidTransformerUNet(nn.Module):
         if self.precision == "bf16" and self.fuse_ffn and not ff.gated and L.ffn_fused_supported(C, Hd):
             # one launch, hidden activations never leave the CU (csrc/ffn.hip)
             L.ffn_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".fc1.w"][0], P[name + ".fc1.b"], P[name + ".fc2.w"][0],
-                        P[name + ".fc2.b"], B * S, C, Hd, act=ff.activation_name)
+                        P[name + ".fc2.b"], B * S, C, Hd, act=ff.activation_name, opts=self.opts)
             return
         if (name + ".fc1.w8") in P and (name + ".fc2.w8") in P and ld == C and ldh == Hd:
             # precision="fp8", long-K level: LayerNorm -> e4m3 -> FFN-1 (activation -> e4m3 in its epilogue) -> FFN-2 (+ residual)
@@ -833,25 +845,25 @@ class CuboidTransformerUNet(nn.Module):
             h8 = self._buf("ffn.h8", (B * S, Hd), torch.float8_e4m3fn, dev)
             w8, sw = P[name + ".fc1.w8"]
             L.igemm(a8, w8, M=B * S, N=Hd, Cin=C, bias=P[name + ".fc1.b"], act=ff.activation_name, out_bf16=h8, ld_outb=Hd,
-                    alpha=1.0 / (2 ** k8 * sw), fp8=True, out_fp8_log2=k8)
+                    alpha=1.0 / (2 ** k8 * sw), fp8=True, out_fp8_log2=k8, opts=self.opts)
             w8, sw = P[name + ".fc2.w8"]
-            L.igemm(h8, w8, M=B * S, N=C, Cin=Hd, bias=P[name + ".fc2.b"], residual=x, out_f32=x, alpha=1.0 / (2 ** k8 * sw), fp8=True)
+            L.igemm(h8, w8, M=B * S, N=C, Cin=Hd, bias=P[name + ".fc2.b"], residual=x, out_f32=x, alpha=1.0 / (2 ** k8 * sw), fp8=True, opts=self.opts)
             return
         a, alo = self._bf("ln.a", B * S, ld, dev)
-        L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld)
+        L.layernorm(x, P[name + ".ln.g"], P[name + ".ln.beta"], a, alo, B * S, C, ld, opts=self.opts)
         h, hlo = self._bf("ffn.h", B * S, ldh, dev)
         w1, w1lo = P[name + ".fc1.w"]
         if ff.gated:
             tmp = self._buf("ffn.tmp", (B * S, Hd), torch.float32, dev)
-            L.igemm(a, w1, A_lo=alo, W_lo=w1lo, M=B * S, N=Hd, Cin=ld, bias=P[name + ".fc1.b"], out_f32=tmp)
+            L.igemm(a, w1, A_lo=alo, W_lo=w1lo, M=B * S, N=Hd, Cin=ld, bias=P[name + ".fc1.b"], out_f32=tmp, opts=self.opts)
             wg, wglo = P[name + ".gate.w"]
             L.igemm(a, wg, A_lo=alo, W_lo=wglo, M=B * S, N=Hd, Cin=ld, bias=P[name + ".gate.b"], act=ff.activation_name,
-                    mul=tmp, out_bf16=h, out_bf16_lo=hlo, ld_outb=ldh)
+                    mul=tmp, out_bf16=h, out_bf16_lo=hlo, ld_outb=ldh, opts=self.opts)
         else:
             L.igemm(a, w1, A_lo=alo, W_lo=w1lo, M=B * S, N=Hd, Cin=ld, bias=P[name + ".fc1.b"], act=ff.activation_name,
-                    out_bf16=h, out_bf16_lo=hlo, ld_outb=ldh)
+                    out_bf16=h, out_bf16_lo=hlo, ld_outb=ldh, opts=self.opts)
         w2, w2lo = P[name + ".fc2.w"]
-        L.igemm(h, w2, A_lo=hlo, W_lo=w2lo, M=B * S, N=C, Cin=ldh, bias=P[name + ".fc2.b"], residual=x, out_f32=x)
+        L.igemm(h, w2, A_lo=hlo, W_lo=w2lo, M=B * S, N=C, Cin=ldh, bias=P[name + ".fc2.b"], residual=x, out_f32=x, opts=self.opts)
 
     def _stack(self, P, name, blk: StackCuboidSelfAttentionBlock, x, B, S, C, level, dev):
         """StackCuboidSelfAttentionBlock.forward, eval branch (cuboid_transformer.py:1147-1156 / 1176-1186)."""
@@ -866,7 +878,7 @@ class CuboidTransformerUNet(nn.Module):
             if pair is not None and C in self.pair_units and (enough or not self.split_k):
                 # x += attn(x); x = ffn(x) in one launch, rows register resident (csrc/pair_block.hip)
                 L.attn_ffn_pair(x, x, pair[0], pair[1], tabs[a]["tok"], B, S, geo["nc"], geo["vol"], float(at.scale), eps_attn=pair[2],
-                                eps_ffn=pair[3], tok_affine=geo.get("affine"), units=C)
+                                eps_ffn=pair[3], tok_affine=geo.get("affine"), units=C, opts=self.opts)
                 continue
             self._attention(P, f"{name}.attn{a}", at, x, B, S, C, tabs[a], self._geom[level][a], dev)
             if blk.use_inter_ffn:
@@ -963,8 +975,8 @@ class CuboidTransformerUNet(nn.Module):
         So = self.out_len * H * W
         ld0 = pad64(C0)
         a, alo = self._bf("final.a", B * So, ld0, dev)
-        L.cast_rows(cur, a, alo, B, S0, self.in_len * H * W, So, C0, C0, ld0)
+        L.cast_rows(cur, a, alo, B, S0, self.in_len * H * W, So, C0, C0, ld0, opts=self.opts)
         out = torch.empty((B, self.out_len, H, W, C_lat), dtype=torch.float32, device=dev)
         wf, wflo = P["final.w"]
-        L.igemm(a, wf, A_lo=alo, W_lo=wflo, M=B * So, N=C_lat, Cin=ld0, bias=P["final.b"], out_f32=out)
+        L.igemm(a, wf, A_lo=alo, W_lo=wflo, M=B * So, N=C_lat, Cin=ld0, bias=P["final.b"], out_f32=out, opts=self.opts)
         return out

@@ -13,24 +13,37 @@ def pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
-def split_bf16(x: torch.Tensor, want_lo: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """x (fp32) -> (hi, lo) bf16 with x ~= hi + lo (about 16 mantissa bits); lo is None unless requested."""
-    hi = x.to(torch.bfloat16)
+F16_MAX = 65504.0
+
+
+def to_operand(x: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    """fp32 -> the engine's 16-bit operand type, round to nearest even; IEEE half saturates at +-65504 like the kernels' packers."""
+    if dtype == torch.float16:
+        return x.float().clamp(-F16_MAX, F16_MAX).to(torch.float16)
+    return x.to(dtype)
+
+
+def split_bf16(x: torch.Tensor, want_lo: bool, dtype=torch.bfloat16) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x (fp32) -> (hi, lo) with x ~= hi + lo (about 16 mantissa bits; bf16 only); lo is None unless requested.  dtype: the operand
+    type of a single-pass engine (torch.bfloat16, or torch.float16 for precision="fp16")."""
+    if want_lo and dtype != torch.bfloat16:
+        raise ValueError("the hi/lo split exists for bfloat16 operands only")
+    hi = to_operand(x, dtype)
     lo = (x - hi.float()).to(torch.bfloat16) if want_lo else None
     return hi.contiguous(), (lo.contiguous() if lo is not None else None)
 
 
-def pack_linear(weight: torch.Tensor, split: bool, k_pad: Optional[int] = None):
-    """nn.Linear weight (N, K) -> bf16 (N, Kp)."""
+def pack_linear(weight: torch.Tensor, split: bool, k_pad: Optional[int] = None, dtype=torch.bfloat16):
+    """nn.Linear weight (N, K) -> 16-bit operands (N, Kp)."""
     N, K = weight.shape
     Kp = k_pad if k_pad is not None else pad64(K)
     w = torch.zeros(N, Kp, dtype=torch.float32, device=weight.device)
     w[:, :K] = weight.detach().float()
-    return split_bf16(w, split)
+    return split_bf16(w, split, dtype)
 
 
-def pack_conv(weight: torch.Tensor, split: bool, c_pad: Optional[int] = None):
-    """Conv weight (N, C, *kernel) -> bf16 (taps, N, Cp) with taps enumerated kernel-index-major (kt, kh, kw)."""
+def pack_conv(weight: torch.Tensor, split: bool, c_pad: Optional[int] = None, dtype=torch.bfloat16):
+    """Conv weight (N, C, *kernel) -> 16-bit operands (taps, N, Cp) with taps enumerated kernel-index-major (kt, kh, kw)."""
     N, Cn = weight.shape[:2]
     taps = 1
     for k in weight.shape[2:]:
@@ -38,7 +51,7 @@ def pack_conv(weight: torch.Tensor, split: bool, c_pad: Optional[int] = None):
     Cp = c_pad if c_pad is not None else pad64(Cn)
     w = torch.zeros(taps, N, Cp, dtype=torch.float32, device=weight.device)
     w[:, :, :Cn] = weight.detach().float().reshape(N, Cn, taps).permute(2, 0, 1)
-    return split_bf16(w, split)
+    return split_bf16(w, split, dtype)
 
 
 # ---------------------------------------------------------------------------------------------------- fp8 (OCP e4m3) operands
@@ -91,7 +104,7 @@ PAIR_VEC_FLOATS = 3584          # units 256; 6144 at units 512
 
 
 def _mfma_frags(w: torch.Tensor) -> torch.Tensor:
-    """bf16 (N, K) -> (N/16, K/32, 64 lanes, 8) fragments of v_mfma_f32_16x16x32_bf16 with the k order of pd_attn_ffn_pair:
+    """16-bit operands (N, K) -> (N/16, K/32, 64 lanes, 8) fragments of v_mfma_f32_16x16x32_{bf16,f16} with the k order of pd_attn_ffn_pair:
     lane = 16 * kg + f holds W[16 F + f][32 KB + 16 (j >> 2) + 4 kg + (j & 3)], j = 0..7 -- the order in which the PREVIOUS stage's
     accumulator registers (lane = (token, 4 consecutive features per 16-feature tile)) line up as the other MFMA operand."""
     N, K = w.shape
@@ -106,7 +119,7 @@ def pair_cuboids_per_group(vol: int) -> int:
     return 2 if vol >= 1 and 2 * vol <= 16 else 1
 
 
-def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
     """The weight stream of pd_attn_ffn_pair for units C = 256 (4 heads of 64, hidden 1024) or 512 (4 heads of 128, hidden 2048):
     chunks of 32 KB = 32 fragments in consumption order.  With CW = C / 256, HD = C / 4, DT = HD / 16, CT = C / 16:
       per head h: Wq_h, Wk_h, Wv_h ([HD x C], CW^2 chunks each: fragment i of chunk s = feature tile i % DT, k-step s * 32 / DT + i / DT),
@@ -120,7 +133,7 @@ def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w
     assert tuple(wqkv.shape) == (3 * Cn, Cn) and tuple(wproj.shape) == (Cn, Cn) and tuple(w1.shape) == (hid, Cn) and tuple(w2.shape) == (Cn, hid)
     HD, CT = Cn // 4, Cn // 16
     DT, HS = HD // 16, HD // 32
-    bf = lambda t: t.detach().to(torch.bfloat16)
+    bf = lambda t: to_operand(t.detach(), dtype)
     fq, fp, f1, f2 = _mfma_frags(bf(wqkv)), _mfma_frags(bf(wproj)), _mfma_frags(bf(w1)), _mfma_frags(bf(w2))
 
     def tile_chunks(fr, F0, nF, K0, nK):

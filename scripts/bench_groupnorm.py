@@ -11,15 +11,13 @@ def timeit(fn,n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/n*1e3
-flag=ctypes.c_int.in_dll(L.lib(),"pd_groupnorm_onepass")
 for B in (1,4,8,32):
   for S,Cn in ((3328,256),(832,512)):
     x=torch.randn(B,S,Cn,device=DEV); g=torch.ones(Cn,device=DEV); b=torch.zeros(Cn,device=DEV)
     part=torch.zeros(B*L.groupnorm_nchunk(S,Cn)*32*2,dtype=torch.float64,device=DEV)
     out=torch.empty(B*S,Cn,dtype=torch.bfloat16,device=DEV)
     r=[]
-    for m in (0,1):
-        flag.value=m
-        r.append(timeit(lambda: L.groupnorm_silu(x,g,b,part,out,None,B,S,Cn,32,Cn,1e-5)))
-    flag.value=1
+    for two in (1,0):
+        o=L.CallOpts(groupnorm_two_launches=two)
+        r.append(timeit(lambda: L.groupnorm_silu(x,g,b,part,out,None,B,S,Cn,32,Cn,1e-5,opts=o)))
     print(f"B={B} S={S} C={Cn}: two launches {r[0]:.1f} us, one pass {r[1]:.1f} us")

@@ -32,11 +32,13 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+# A/B switches from the environment: PD_OPERAND = bf16 | fp16 (operand type: the pd_f16_* builds), PD_PAIR_NC = form of the units-256 kernel
+OPTS = L.CallOpts(os.environ.get("PD_OPERAND", "bf16"), pair_form=int(os.environ.get("PD_PAIR_NC", "0")))
+ODT = OPTS.dtype
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    if os.environ.get("PD_PAIR_NC"):
-        import ctypes
-        ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc").value = int(os.environ["PD_PAIR_NC"])
     shape, Cn, heads, Hd = (13, 16, 16), 256, 4, 1024
     ntok = shape[0] * shape[1] * shape[2]
     g = torch.Generator(device="cpu").manual_seed(1234)
@@ -46,8 +48,8 @@ def main():
     wqkv, wp = r(3 * Cn, Cn, sc=1 / math.sqrt(Cn)), r(Cn, Cn, sc=1 / math.sqrt(Cn))
     w1, w2 = r(Hd, Cn, sc=1 / math.sqrt(Cn)), r(Cn, Hd, sc=1 / math.sqrt(Hd))
     bp, fb1, fb2 = r(Cn, sc=0.1), r(Hd, sc=0.1), r(Cn, sc=0.1)
-    wq_p, wp_p, w1_p, w2_p = (pack_linear(w, False)[0] for w in (wqkv, wp, w1, w2))
-    ws = pack_pair_block(wqkv, wp, w1, w2)
+    wq_p, wp_p, w1_p, w2_p = (pack_linear(w, False, dtype=ODT)[0] for w in (wqkv, wp, w1, w2))
+    ws = pack_pair_block(wqkv, wp, w1, w2, dtype=ODT)
     scale = (Cn // heads) ** -0.5
     for cuboid in ((13, 1, 1), (1, 16, 1), (1, 1, 16)):
         tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
@@ -64,7 +66,7 @@ def main():
             L.ffn_fused(t, t, g2, b2n, w1_p, fb1, w2_p, fb2, B * ntok, Cn, Hd, act="gelu")
 
         def new(t, aff=True):
-            L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"] if aff else None)
+            L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"] if aff else None, opts=OPTS)
 
         ref_a = x.clone(); old_attn(ref_a)
         ref_f = x.clone(); old_ffn(ref_f)
@@ -96,7 +98,7 @@ def level1(B=32):
     wqkv, wp = r(3 * Cn, Cn, sc=Cn ** -0.5), r(Cn, Cn, sc=Cn ** -0.5)
     w1, w2 = r(Hd, Cn, sc=Cn ** -0.5), r(Cn, Hd, sc=Hd ** -0.5)
     bp, fb1, fb2 = r(Cn, sc=0.1), r(Hd, sc=0.1), r(Cn, sc=0.1)
-    ws = pack_pair_block(wqkv, wp, w1, w2)
+    ws = pack_pair_block(wqkv, wp, w1, w2, dtype=ODT)
     scale = (Cn // heads) ** -0.5
     F = torch.nn.functional
     for cuboid in ((13, 1, 1), (1, 8, 1), (1, 1, 8)):
@@ -116,7 +118,7 @@ def level1(B=32):
         y[:, idx] += o
         ref = y + F.gelu(F.layer_norm(y, (Cn,), g2, b2n) @ w1.t() + fb1) @ w2.t() + fb2
         t = x.clone()
-        new = lambda buf, aff=True: L.attn_ffn_pair(buf, buf, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"] if aff else None, units=Cn)
+        new = lambda buf, aff=True: L.attn_ffn_pair(buf, buf, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"] if aff else None, units=Cn, opts=OPTS)
         new(t); torch.cuda.synchronize()
         print(f"cuboid {cuboid}: rel-L2 of the update vs fp32 torch {rel(t - x, ref - x):.3e}   finite {bool(torch.isfinite(t).all())}")
         t2 = x.clone(); new(t2, aff=False); t3 = x.clone(); new(t3); torch.cuda.synchronize()
@@ -135,17 +137,15 @@ def trace(B=32):
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.randn(B, ntok, Cn, generator=g).to(DEV)
     r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
-    ws = pack_pair_block(r(768, 256, sc=1 / 16), r(256, 256, sc=1 / 16), r(1024, 256, sc=1 / 16), r(256, 1024, sc=1 / 32))
+    ws = pack_pair_block(r(768, 256, sc=1 / 16), r(256, 256, sc=1 / 16), r(1024, 256, sc=1 / 16), r(256, 1024, sc=1 / 32), dtype=ODT)
     tabs = attention_tables(shape, (1, 16, 1), (0, 0, 0), LLL, "zeros")
     vecs = pack_pair_vecs(1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), 1 + r(256, sc=.1), r(256, sc=.1), r(256, sc=.1), r(1024, sc=.1), r(4, 16, 16, sc=.5))
     tok = tabs["tok_index"].to(DEV)
     tr = torch.zeros(256, dtype=torch.int64, device=DEV)
     for _ in range(3):
-        L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"])
-    ctypes.c_void_p.in_dll(L.lib(), "pd_pair_trace").value = tr.data_ptr()
-    L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"])
+        L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"], opts=OPTS)
+    L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], 16, 0.125, tok_affine=tabs["affine"], opts=L.CallOpts(trace=tr.data_ptr()))
     torch.cuda.synchronize()
-    ctypes.c_void_p.in_dll(L.lib(), "pd_pair_trace").value = None
     t = tr.cpu().tolist()
     n = max(i for i, v in enumerate(t) if v) + 1
     d = [t[i + 1] - t[i] for i in range(n - 1)]
@@ -163,14 +163,14 @@ def ablate(B=32):
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.randn(B, ntok, Cn, generator=g).to(DEV)
     r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
-    ws = pack_pair_block(r(3 * Cn, Cn, sc=Cn ** -0.5), r(Cn, Cn, sc=Cn ** -0.5), r(Hd, Cn, sc=Cn ** -0.5), r(Cn, Hd, sc=Hd ** -0.5))
+    ws = pack_pair_block(r(3 * Cn, Cn, sc=Cn ** -0.5), r(Cn, Cn, sc=Cn ** -0.5), r(Hd, Cn, sc=Cn ** -0.5), r(Cn, Hd, sc=Hd ** -0.5), dtype=ODT)
     tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
     vol = tabs["vol"]
     vecs = pack_pair_vecs(1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), 1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), r(Hd, sc=.1), r(4, vol, vol, sc=.5))
     tok = tabs["tok_index"].to(DEV)
     out = []
     for rep in range(3):
-        t = timeit(lambda: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], vol, (Cn // 4) ** -0.5, tok_affine=tabs["affine"], units=Cn))
+        t = timeit(lambda: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, tabs["nc"], vol, (Cn // 4) ** -0.5, tok_affine=tabs["affine"], units=Cn, opts=OPTS))
         x.normal_()
         out.append(f"{t:.1f} us")
     print(os.environ.get("PD_LIB_PATH", "default"), f"units {Cn}", " | ".join(out))

@@ -6,12 +6,13 @@ stale data.  This script replays the in-order LDS return queue over the generate
 path of its control-flow graph) and reports any instruction that reads or writes a VGPR which is still
 the destination of an LDS read in flight.  Exit status 1 on a finding.
 
-usage: python scripts/check_async_lds.py [file.s]     (without an argument: compiles pair_block.hip to assembly itself)"""
+usage: python scripts/check_async_lds.py [file.s ...]
+Without an argument it checks prediff_amd/csrc/pair_block.isa.s and pair_block_f16.isa.s: the device assembly the Makefile keeps from the
+very compilations that produced pair_block.o / pair_block_f16.o (hipcc -save-temps with the Makefile's HIPCC, ARCH and CXXFLAGS), i.e. the
+code that is in libprediff_hip.so -- not a re-compilation with flags of its own."""
 import os
 import re
-import subprocess
 import sys
-import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
@@ -107,17 +108,27 @@ def check(path):
 
 def main():
     if len(sys.argv) > 1:
-        path = sys.argv[1]
+        paths = sys.argv[1:]
     else:
-        path = os.path.join(tempfile.mkdtemp(), "pair_block.s")
-        src = os.path.join(ROOT, "prediff_amd", "csrc", "pair_block.hip")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", path],
-                       check=True, stderr=subprocess.DEVNULL)
-    findings, nreads = check(path)
-    for f in findings[:40]:
-        print(f)
-    print(f"check_async_lds: {nreads} LDS reads replayed, {len(findings)} finding(s)")
-    return 1 if findings else 0
+        csrc = os.path.join(ROOT, "prediff_amd", "csrc")
+        paths = [os.path.join(csrc, "pair_block.isa.s"), os.path.join(csrc, "pair_block_f16.isa.s")]
+        for path in paths:
+            obj = path.replace(".isa.s", ".o")
+            if not os.path.exists(path) or (os.path.exists(obj) and os.path.getmtime(path) + 60 < os.path.getmtime(obj)):
+                print(f"check_async_lds: {path} is missing or older than its object: run `make -C prediff_amd/csrc` (the Makefile emits it)")
+                return 1
+    total, nall = 0, 0
+    for path in paths:
+        findings, nreads = check(path)
+        for f in findings[:40]:
+            print(f)
+        if nreads == 0:
+            print(f"check_async_lds: {path}: no pair_kernel instantiation found")
+            return 1
+        total += len(findings)
+        nall += nreads
+    print(f"check_async_lds: {len(paths)} file(s), {nall} LDS reads replayed, {total} finding(s)")
+    return 1 if total else 0
 
 
 if __name__ == "__main__":

@@ -56,5 +56,10 @@ def test_precision_fp8_constructor_flags():
     assert net_c.fp8_conv and not net_c.fp8_linear and net_c.precision == "bf16"   # e4m3 for the convolutions only
     assert not CuboidTransformerUNet(**TINY_UNET_CFGS["axial"], precision="bf16").fp8_conv
     assert AutoencoderKL(**TINY_VAE_CFG, precision="fp8").precision == "bf16"    # the VAE has no fp8 launches
+    # precision="fp16": the bf16 engine's launches with IEEE half as the 16-bit operand type (per-module call options, no fp8)
+    net_h = CuboidTransformerUNet(**TINY_UNET_CFGS["axial"], precision="fp16")
+    assert net_h.precision == "bf16" and net_h.operand == "fp16" and net_h.op_dtype == torch.float16 and net_h.opts.operand == 1
+    assert not net_h.fp8_conv and net.opts.operand == 0 and net.op_dtype == torch.bfloat16
+    assert AutoencoderKL(**TINY_VAE_CFG, precision="fp16").op_dtype == torch.float16
     with pytest.raises(ValueError):
-        CuboidTransformerUNet(**TINY_UNET_CFGS["axial"], precision="fp16")
+        CuboidTransformerUNet(**TINY_UNET_CFGS["axial"], precision="fp64")

@@ -143,17 +143,12 @@ def test_igemm_conv3d_tap_skip_equals_dense(B, T, H, W, Cin, Cout, fp8):
         a, _ = padded_bf16(x.reshape(-1, Cin), False)
         w_p, _ = pack_conv(w, False)
         kw = {}
-    dbg = ctypes.c_int.in_dll(L.lib(), "pd_igemm_debug_or")
     outs = {}
-    try:
-        for flag in (0, 8):
-            dbg.value = flag
-            out = torch.full((M, Cout), float("nan"), device=DEV)
-            L.igemm(a, w_p, M=M, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, bias=bias, out_f32=out, **kw)
-            torch.cuda.synchronize()
-            outs[flag] = out
-    finally:
-        dbg.value = 0
+    for flag in (0, 8):
+        out = torch.full((M, Cout), float("nan"), device=DEV)
+        L.igemm(a, w_p, M=M, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, bias=bias, out_f32=out, debug_flags=flag, **kw)
+        torch.cuda.synchronize()
+        outs[flag] = out
     assert torch.equal(outs[0], outs[8]) or float((outs[0] - outs[8]).abs().max()) == 0.0       # (-0.0 vs +0.0 would still be equal)
     if not fp8:
         ref = F.conv3d(bf(x).permute(0, 4, 1, 2, 3), bf(w), bias, padding=1).permute(0, 2, 3, 4, 1).reshape(M, Cout)
@@ -253,19 +248,14 @@ def test_groupnorm_silu_one_pass(B, S, Cn, G, ss):
     sst = (0.3 * torch.randn(B, 2 * Cn, generator=g)).to(DEV) if ss else None
     kw = dict(ss_scale=sst, ss_shift=sst[:, Cn:], ld_ss=2 * Cn) if ss else {}
     part = torch.zeros(B * L.groupnorm_nchunk(S, Cn) * G * 2, dtype=torch.float64, device=DEV)
-    flag = ctypes.c_int.in_dll(L.lib(), "pd_groupnorm_onepass")
     outs, sums = [], []
-    try:
-        for mode in (1, 0):
-            flag.value = mode
-            out = torch.full((B * S, Cn), 7.0, dtype=torch.bfloat16, device=DEV)
-            part.fill_(float("nan"))
-            L.groupnorm_silu(x, gamma, beta, part, out, None, B, S, Cn, G, Cn, 1e-5, silu=True, **kw)
-            torch.cuda.synchronize()
-            outs.append(out.float())
-            sums.append(part.reshape(B, -1, G, 2).sum(1))          # what pd_groupnorm_silu_bwd reduces `partials` to
-    finally:
-        flag.value = 1
+    for two_launches in (0, 1):
+        out = torch.full((B * S, Cn), 7.0, dtype=torch.bfloat16, device=DEV)
+        part.fill_(float("nan"))
+        L.groupnorm_silu(x, gamma, beta, part, out, None, B, S, Cn, G, Cn, 1e-5, silu=True, opts=L.CallOpts(groupnorm_two_launches=two_launches), **kw)
+        torch.cuda.synchronize()
+        outs.append(out.float())
+        sums.append(part.reshape(B, -1, G, 2).sum(1))          # what pd_groupnorm_silu_bwd reduces `partials` to
     # the partial-sum contract of `partials` holds on both paths: (sum, sum of squares) per (sample, group)
     xg = x.double().reshape(B, S, G, Cn // G)
     want = torch.stack([xg.sum((1, 3)), (xg * xg).sum((1, 3))], -1)
@@ -612,8 +602,8 @@ def test_attn_block_fused_vs_oracle(golden, case):
 @pytest.mark.parametrize("shape,cuboid,Cn,heads,B", [((13, 16, 16), (13, 1, 1), 256, 4, 2), ((13, 16, 16), (1, 16, 1), 256, 4, 6),
                                                       ((13, 16, 16), (1, 1, 16), 256, 4, 1), ((5, 8, 8), (1, 8, 1), 128, 2, 3)])
 def test_fused_engine_switches(shape, cuboid, Cn, heads, B):
-    """pd_fused_opts bit 2 (arithmetic token ids instead of the table load) changes the address path, not the arithmetic: bit-identical
-    rows for the attention block; the FFN (no switch) is deterministic across repeats."""
+    """pd_call_opts.attn_block_table_ids (the token table loaded instead of arithmetic token ids) changes the address path, not the
+    arithmetic: bit-identical rows for the attention block; the FFN (no switch) is deterministic across repeats."""
     from prediff_amd.cuboid_geometry import attention_tables
     T, H, W = shape
     ntok = T * H * W
@@ -633,23 +623,17 @@ def test_fused_engine_switches(shape, cuboid, Cn, heads, B):
     w2p, _ = pack_linear((torch.randn(Cn, Hd, generator=g) / math.sqrt(Hd)).to(DEV), False)
     b1, b2 = torch.randn(Hd, generator=g).to(DEV) * 0.1, torch.randn(Cn, generator=g).to(DEV) * 0.1
     res = {}
-    old = L.fused_opts()
-    try:
-        for opts in (0, 4):
-            L.fused_opts(opts)
-            xa = x.clone()
-            L.attn_block_fused(xa, xa, gamma, beta, wq_p, None, wp_p, bp, tok, bias, None, B, ntok, Cn, heads, nc, vol, (Cn // heads) ** -0.5,
-                               tok_affine=tabs["affine"])
-            xf = x.clone().reshape(B * ntok, Cn)
-            L.ffn_fused(xf, xf, gamma, beta, w1p, b1, w2p, b2, B * ntok, Cn, Hd, act="gelu")
-            torch.cuda.synchronize()
-            res[opts] = (xa, xf)
-    finally:
-        L.fused_opts(old)
+    for table_ids in (1, 0):
+        xa = x.clone()
+        L.attn_block_fused(xa, xa, gamma, beta, wq_p, None, wp_p, bp, tok, bias, None, B, ntok, Cn, heads, nc, vol, (Cn // heads) ** -0.5,
+                           tok_affine=tabs["affine"], opts=L.CallOpts(attn_block_table_ids=table_ids))
+        xf = x.clone().reshape(B * ntok, Cn)
+        L.ffn_fused(xf, xf, gamma, beta, w1p, b1, w2p, b2, B * ntok, Cn, Hd, act="gelu")
+        torch.cuda.synchronize()
+        res[table_ids] = (xa, xf)
     assert bool(torch.isfinite(res[0][0]).all()) and not torch.equal(res[0][0], x)
-    for opts in (4,):
-        assert torch.equal(res[opts][0], res[0][0]), f"attention block: pd_fused_opts = {opts} changes the result"
-        assert torch.equal(res[opts][1], res[0][1]), f"FFN: pd_fused_opts = {opts} changes the result"
+    assert torch.equal(res[1][0], res[0][0]), "attention block: token ids from the table / from the affine form differ"
+    assert torch.equal(res[1][1], res[0][1]), "FFN: not deterministic across repeats"
 
 
 # ------------------------------------------------------------------------------------------------ split-K (small grids)
@@ -968,24 +952,23 @@ def _pair_case(name):
 
 @pytest.fixture
 def pair_nc(request):
-    """pd_pair_force_nc: the form of pd_attn_ffn_pair at units 256 (1 = four waves x one group: 64-row tiles, the small-grid form; 2 = four
-    waves x two groups, 8 = eight waves x one group: 128-row tiles)."""
-    import ctypes
-    v = ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc")
-    old = v.value
-    v.value = request.param
-    yield request.param
-    v.value = old
+    """pd_call_opts.pair_form: the form of pd_attn_ffn_pair at units 256 (1 = four waves x one group: 64-row tiles, the small-grid form;
+    2 = four waves x two groups, 8 = eight waves x one group: 128-row tiles)."""
+    return request.param
 
 
+@pytest.mark.parametrize("operand", ["bf16", "fp16"])
 @pytest.mark.parametrize("pair_nc", [1, 2, 8], indirect=True)
 @pytest.mark.parametrize("name", list(PAIR_CASES))
-def test_attn_ffn_pair_vs_oracle(name, pair_nc):
+def test_attn_ffn_pair_vs_oracle(name, pair_nc, operand):
     """pd_attn_ffn_pair (csrc/pair_block.hip) against the oracle's statement of one (CuboidSelfAttentionLayer, PositionwiseFFN) pair
     of StackCuboidSelfAttentionBlock (reference cuboid_transformer.py:1147-1156: x = x + attn(x); x = ffn(x)), against the two round-3
     kernels it replaces, with the token ids from the table and from its affine form, and twice (bit-equal).  bf16 operands, fp32
-    accumulation: <= 6e-3 rel-L2 on the update, as for the attention block alone."""
+    accumulation: <= 6e-3 rel-L2 on the update, as for the attention block alone; IEEE-half operands (the pd_f16_* build of the same
+    source, 11-bit significands): <= 1e-3."""
     from oracle import unet as OU
+    opts = L.CallOpts(operand, pair_form=pair_nc)
+    odt, tol = opts.dtype, {"bf16": 6e-3, "fp16": 1e-3}[operand]
     from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
     from prediff_amd.packing import pack_pair_block, pack_pair_vecs
     shape, cuboid, B, Cn, heads, Hd, sd_a, sd_f, x = _pair_case(name)
@@ -998,7 +981,7 @@ def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     assert tabs["mask"] is None and tabs["affine"] is not None and L.attn_ffn_pair_supported(Cn, heads, Hd, vol)
     d = lambda t: t.to(DEV)
     bias = relative_position_bias(sd_a["relative_position_bias_table"], sd_a["relative_position_index"], vol).to(DEV)
-    ws = pack_pair_block(d(sd_a["qkv.weight"]), d(sd_a["proj.weight"]), d(sd_f["ffn_1.weight"]), d(sd_f["ffn_2.weight"]))
+    ws = pack_pair_block(d(sd_a["qkv.weight"]), d(sd_a["proj.weight"]), d(sd_f["ffn_1.weight"]), d(sd_f["ffn_2.weight"]), dtype=odt)
     vecs = pack_pair_vecs(d(sd_a["norm.weight"]), d(sd_a["norm.bias"]), d(sd_a["proj.bias"]), d(sd_f["layer_norm.weight"]),
                           d(sd_f["layer_norm.bias"]), d(sd_f["ffn_2.bias"]), d(sd_f["ffn_1.bias"]), bias)
     ntok = shape[0] * shape[1] * shape[2]
@@ -1006,35 +989,36 @@ def test_attn_ffn_pair_vs_oracle(name, pair_nc):
     tok = tabs["tok_index"].to(DEV)
     scale = (Cn // heads) ** -0.5
     out = torch.full_like(xd, float("nan"))
-    L.attn_ffn_pair(xd, out, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"], units=Cn)
+    L.attn_ffn_pair(xd, out, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"], units=Cn, opts=opts)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out).all()), "a row was not written (or written with garbage)"
     e = rel_l2((out - xd).reshape(x.shape).cpu(), y_ref - x)
-    print(f"[attn_ffn_pair {name}, {pair_nc} cuboid(s) per wave] update rel-L2 vs oracle {e:.3e}")
-    assert e < 6e-3
-    assert rel_l2(out.reshape(x.shape).cpu(), y_ref) < 6e-3          # the pair's result (the FFN update is as large as x itself)
+    print(f"[attn_ffn_pair {name}, {pair_nc} cuboid(s) per wave, {operand}] update rel-L2 vs oracle {e:.3e}")
+    assert e < tol
+    assert rel_l2(out.reshape(x.shape).cpu(), y_ref) < tol          # the pair's result (the FFN update is as large as x itself)
     # in place, token ids from the table instead of the affine form, and a repeat: bit-identical
     for aff in (None, tabs["affine"], tabs["affine"]):
         t = xd.clone()
-        L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=aff, units=Cn)
+        L.attn_ffn_pair(t, t, ws, vecs, tok, B, ntok, nc, vol, scale, tok_affine=aff, units=Cn, opts=opts)
         torch.cuda.synchronize()
         assert torch.equal(t, out)
     if Cn != 256:
         return                                          # (the round-3 fused kernels exist for units 256 only)
-    # the two launches it replaces (same bf16 operands; erf GELU there, the 2.5e-5 sigmoid form here; another summation order)
-    wq_p, _ = pack_linear(d(sd_a["qkv.weight"]), False)
-    wp_p, _ = pack_linear(d(sd_a["proj.weight"]), False)
-    w1_p, _ = pack_linear(d(sd_f["ffn_1.weight"]), False)
-    w2_p, _ = pack_linear(d(sd_f["ffn_2.weight"]), False)
+    # the two launches it replaces (same 16-bit operands; erf GELU there, the 2.5e-5 sigmoid form here; another summation order)
+    wq_p, _ = pack_linear(d(sd_a["qkv.weight"]), False, dtype=odt)
+    wp_p, _ = pack_linear(d(sd_a["proj.weight"]), False, dtype=odt)
+    w1_p, _ = pack_linear(d(sd_f["ffn_1.weight"]), False, dtype=odt)
+    w2_p, _ = pack_linear(d(sd_f["ffn_2.weight"]), False, dtype=odt)
     t = xd.clone()
     L.attn_block_fused(t, t, d(sd_a["norm.weight"]), d(sd_a["norm.bias"]), wq_p, None, wp_p, d(sd_a["proj.bias"]), tok, bias, None,
-                       B, ntok, Cn, heads, nc, vol, scale)
+                       B, ntok, Cn, heads, nc, vol, scale, opts=opts)
     L.ffn_fused(t, t, d(sd_f["layer_norm.weight"]), d(sd_f["layer_norm.bias"]), w1_p, d(sd_f["ffn_1.bias"]), w2_p, d(sd_f["ffn_2.bias"]),
-                B * ntok, Cn, Hd, act="gelu")
+                B * ntok, Cn, Hd, act="gelu", opts=opts)
     torch.cuda.synchronize()
     e3 = rel_l2(out - xd, t - xd)
-    print(f"[attn_ffn_pair {name}] update rel-L2 vs pd_attn_block_fused + pd_ffn_fused {e3:.3e}")
-    assert e3 < 1.5e-3
+    e_r3 = rel_l2((t - xd).reshape(x.shape).cpu(), y_ref - x)
+    print(f"[attn_ffn_pair {name}, {operand}] update rel-L2 vs pd_attn_block_fused + pd_ffn_fused {e3:.3e} (those vs the oracle {e_r3:.3e})")
+    assert e3 < 1.5e-3 and e_r3 < tol
 
 
 @pytest.mark.parametrize("Cn,shape,cuboid", [(256, (13, 16, 16), (13, 1, 1)), (256, (13, 16, 16), (1, 1, 16)), (256, (3, 5, 3), (1, 5, 1)),
@@ -1056,9 +1040,9 @@ def test_attn_ffn_pair_batch_independent(Cn, shape, cuboid):
     vecs = pack_pair_vecs(1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), 1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), r(Hd, sc=.1), r(4, vol, vol, sc=.5))
     tok = tabs["tok_index"].to(DEV)
 
-    def run(xx):
+    def run(xx, opts=None):
         o = torch.full_like(xx, float("nan"))
-        L.attn_ffn_pair(xx, o, ws, vecs, tok, xx.shape[0], ntok, tabs["nc"], vol, (Cn // 4) ** -0.5, tok_affine=tabs["affine"], units=Cn)
+        L.attn_ffn_pair(xx, o, ws, vecs, tok, xx.shape[0], ntok, tabs["nc"], vol, (Cn // 4) ** -0.5, tok_affine=tabs["affine"], units=Cn, opts=opts)
         torch.cuda.synchronize()
         return o
     o8 = run(x)
@@ -1066,14 +1050,8 @@ def test_attn_ffn_pair_batch_independent(Cn, shape, cuboid):
     assert torch.equal(o8[:4], run(x[:4].contiguous())) and torch.equal(o8[4:], run(x[4:].contiguous()))
     assert torch.equal(o8[5:6], run(x[5:6].contiguous()))
     if Cn == 256:                                       # the three forms of the units-256 kernel, forced
-        import ctypes
-        v = ctypes.c_int.in_dll(L.lib(), "pd_pair_force_nc")
-        try:
-            for form in (1, 2, 8):
-                v.value = form
-                assert torch.equal(run(x), o8), f"form {form} differs"
-        finally:
-            v.value = 0
+        for form in (1, 2, 8):
+            assert torch.equal(run(x, L.CallOpts(pair_form=form)), o8), f"form {form} differs"
 
 
 def test_attn_ffn_pair_rejects_what_it_does_not_run():

@@ -55,7 +55,7 @@ def test_checkpoint_level_and_unsupported_options():
     with pytest.raises(NotImplementedError):
         CuboidTransformerUNet(**{**cfg, "num_global_vectors": 4})
     with pytest.raises(ValueError):
-        CuboidTransformerUNet(**cfg, precision="fp16")
+        CuboidTransformerUNet(**cfg, precision="fp64")
 
 
 def test_cpu_forward_fails_loudly():
