@@ -116,6 +116,8 @@ _PROTOS = {
     "pd_attn_ffn_pair_supported": (C.c_int, [C.c_int] * 5),
     "pd_attn_ffn_pair_cuboids_per_group": (C.c_int, [C.c_int]),
     "pd_attn_ffn_pair": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float] * 3 + [C.POINTER(CallOpts), C.c_void_p]),
+    "pd_attn_ffn_pair_split_ws_floats": (C.c_int64, [C.c_int] * 3),
+    "pd_attn_ffn_pair_split": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_float] * 3 + [C.c_void_p, C.c_int64, C.POINTER(CallOpts), C.c_void_p]),
     "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -414,3 +416,17 @@ def attn_ffn_pair(x, out, wstream, vecs, tok_index, B, ntok, nc, vol, scale, eps
     _check(lib().pd_attn_ffn_pair(ptr(x), ptr(out), ptr(wstream), ptr(vecs), ptr(tok_index),
                                   C.cast(aff, C.c_void_p) if aff is not None else None, B, ntok, nc, vol, units, scale, eps_attn,
                                   eps_ffn, _opts_ref(opts), stream_ptr()), "pd_attn_ffn_pair")
+
+
+def attn_ffn_pair_split_ws_floats(B, ntok, units):
+    return 2 * 4 * B * ntok * units               # == pd_attn_ffn_pair_split_ws_floats (tests/test_host_logic.py compares)
+
+
+def attn_ffn_pair_split(x, out, wstream, wffn_split, vecs, tok_index, B, ntok, nc, vol, scale, ws, eps_attn=1e-5, eps_ffn=1e-5, tok_affine=None,
+                        units=512, opts=None):
+    """The (attention, FFN) pair at units 512 for small grids: three launches, four workgroups per 64-row tile (csrc/pair_block.hip MODE 1 / 2
+    + pair_split_sum_kernel).  wffn_split: packing.pack_pair_ffn_split; ws: fp32 workspace of attn_ffn_pair_split_ws_floats(...) elements."""
+    aff = (C.c_int32 * 4)(*tok_affine) if tok_affine is not None else None
+    _check(lib().pd_attn_ffn_pair_split(ptr(x), ptr(out), ptr(wstream), ptr(wffn_split), ptr(vecs), ptr(tok_index),
+                                        C.cast(aff, C.c_void_p) if aff is not None else None, B, ntok, nc, vol, units, scale, eps_attn, eps_ffn,
+                                        ptr(ws), ws.numel(), _opts_ref(opts), stream_ptr()), "pd_attn_ffn_pair_split")

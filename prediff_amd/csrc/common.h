@@ -58,6 +58,18 @@ static inline int pd_cur_device() {
   return d;
 }
 
+// compute units of the current device (MI355X: 256), asked once per device: grid sizes and form heuristics derive from it
+static inline int pd_num_cus() {
+  static int n_dev[PD_MAX_DEVICES];
+  int& n = n_dev[pd_cur_device()];
+  if (n <= 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, pd_cur_device()) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+
 #define PD_CHECK_LAUNCH()                                                 \
   do {                                                                    \
     hipError_t e__ = hipGetLastError();                                   \
@@ -77,16 +89,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 namespace PD_NS {
-// four / two fp32 -> operand type (RNE).  fp16: v_cvt_pk_f16_f32 + saturation at +-65504 (v_pk_min/max_f16; a NaN saturates too).
-__device__ __forceinline__ op4v cvt_op4(const f32x4& a) {
-#if PD_IS_F16
-  op4v h = __builtin_convertvector(a, op4v);
-  h = __builtin_elementwise_min(h, (op4v)(_Float16)65504.f);
-  return __builtin_elementwise_max(h, (op4v)(_Float16)(-65504.f));
-#else
-  return __builtin_convertvector(a, op4v);     // v_cvt_pk_bf16_f32 with the MFMA hazards handled by the compiler
-#endif
-}
+// four fp32 -> operand type (RNE): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 through the compiler (MFMA hazards handled).  NOT saturating: this
+// is the register-to-register packer of pd_attn_ffn_pair, whose every input sits behind a LayerNorm (|y| <= sqrt(C) |gamma| + |beta|), a
+// softmax ([0, 1]), a GELU of such a product or a product of two such values -- nowhere near 65504 for any weights that are not already
+// broken, and its chunk loops are VALU-issue bound (two v_pk_min/max_f16 per pair of values measured 5.5 % of the fp16 step).  An overflow
+// would come out as inf / NaN in the result, not silently: tests assert finiteness.  Everything that converts UNnormalised values (the
+// GEMM epilogues, pd_cast_rows on the residual stream) goes through pack_op2 / f2op below, which saturate.
+__device__ __forceinline__ op4v cvt_op4(const f32x4& a) { return __builtin_convertvector(a, op4v); }
 // two fp32 -> packed operand pair (lo | hi << 16), round to nearest even
 __device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {
 #if PD_IS_F16
@@ -173,6 +182,13 @@ __device__ __forceinline__ float gelu_sigmoid_arg(float x) {   // the argument o
 __device__ __forceinline__ float gelu_sigmoid(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gelu_sigmoid_arg(x)));
 }
+
+// The activation of a producer whose result is rounded to 16 bits right away (every single-pass 16-bit-operand producer: pd_igemm's
+// 16-bit-only epilogues, the split-K reduce, pd_ffn_fused, pd_attn_ffn_pair): GELU in the sigmoid form -- ONE form in every such producer,
+// whatever instantiation or launch path a shape / batch size selects (a layer's bits must not depend on the path: ADVICE r4).  The hi/lo
+// (fp32-class) engine and fp32 outputs keep act_apply's erf form.
+__device__ __forceinline__ float act_apply(float v, int act);
+__device__ __forceinline__ float act_apply16(float v, int act) { return act == PD_ACT_GELU ? gelu_sigmoid(v) : act_apply(v, act); }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {

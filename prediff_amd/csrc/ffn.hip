@@ -209,8 +209,8 @@ __global__ void __launch_bounds__(512, 2) ffn_fused_kernel(const pd_ffn_args_k p
       for (int g = 0; g < 4; ++g) {
         const int nl = tn * 32 + 8 * g + 4 * lhalf;          // hidden unit inside the chunk (multiple of 4)
         // (the bias is already in the accumulator: GEMM-1 started from it)
-        const float h0 = act_apply(acc1[4 * g] + acc1b[4 * g], ACT), h1 = act_apply(acc1[4 * g + 1] + acc1b[4 * g + 1], ACT);
-        const float h2 = act_apply(acc1[4 * g + 2] + acc1b[4 * g + 2], ACT), h3 = act_apply(acc1[4 * g + 3] + acc1b[4 * g + 3], ACT);
+        const float h0 = act_apply16(acc1[4 * g] + acc1b[4 * g], ACT), h1 = act_apply16(acc1[4 * g + 1] + acc1b[4 * g + 1], ACT);
+        const float h2 = act_apply16(acc1[4 * g + 2] + acc1b[4 * g + 2], ACT), h3 = act_apply16(acc1[4 * g + 3] + acc1b[4 * g + 3], ACT);
         const int off = hrow * 128 + (((nl >> 3) ^ hswz) << 4) + ((nl & 7) << 1);
         // Written with an opaque ds_write: for a visible LDS store hipcc first drains the in-flight weight DMA (it cannot tell
         // that H and the DMA destinations are disjoint LDS regions), which would serialise the prefetch every chunk.
@@ -404,8 +404,8 @@ __global__ void __launch_bounds__(512, NS == 2 ? 4 : 2) ffn64_kernel(const pd_ff
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int d = tn * 32 + dt * 16 + 4 * lg;
-          const float h0 = act_apply(acc1[dt][0], ACT), h1 = act_apply(acc1[dt][1], ACT);
-          const float h2 = act_apply(acc1[dt][2], ACT), h3 = act_apply(acc1[dt][3], ACT);
+          const float h0 = act_apply16(acc1[dt][0], ACT), h1 = act_apply16(acc1[dt][1], ACT);
+          const float h2 = act_apply16(acc1[dt][2], ACT), h3 = act_apply16(acc1[dt][3], ACT);
           const uint64_t pk = (uint64_t)(pack_op2(h0, h1)) | ((uint64_t)(pack_op2(h2, h3)) << 32);
           const int off = trow * 128 + (((d >> 3) ^ ((trow >> 1) & 7)) << 4) + ((d & 7) << 1);
           // opaque ds_write: a visible LDS store would make hipcc drain the in-flight weight DMA first

@@ -366,7 +366,8 @@ extern "C" int PD_ENTRY(igemm)(const pd_igemm_args* pa, pd_stream_t stream) {
     // rounds are the cheaper ones (Conv3d at 32 trajectories: 317 us in 2 rounds against 385 us in 4)
     if (tile == PD_BIG_TILE_DEFAULT && !a.disable_256 && !a.split && (int64_t)a.taps * a.Cin >= min_k_256 && pd_igemm256_supported(a, kind)) {
       const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.nbatch > 0 ? a.nbatch : 1);
-      const int64_t r128 = (t128 + 511) / 512, r256 = (t256 + 255) / 256;
+      const int64_t ncu = pd_num_cus();
+      const int64_t r128 = (t128 + 2 * ncu - 1) / (2 * ncu), r256 = (t256 + ncu - 1) / ncu;
       if (r256 * 33 <= r128 * 20) tile = 7;
     }
   }

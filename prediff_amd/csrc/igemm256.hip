@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const pd_igemm
     }
     if (p.act != 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+      for (int e = 0; e < 4; ++e) v[e] = (p.out_bf16 && !p.out_bf16_lo && !p.out_f32) ? act_apply16(v[e], p.act) : act_apply(v[e], p.act);
     }
     if (p.mul) {
       const float* mu = p.mul + (int64_t)m * p.ld_mul + n;
@@ -440,7 +440,7 @@ static int launch256_splitk(const pd_igemm_args& a, hipStream_t s) {
 
 bool pd_igemm256_supported(const pd_igemm_args& a, int kind);
 
-// K-slices for a launch of `tiles` 256 x 256 tiles and nk K-tiles on the 256 CUs of the MI355X (0 = do not split): split when the
+// K-slices for a launch of `tiles` 256 x 256 tiles and nk K-tiles on the device's CUs (256 on the MI355X; 0 = do not split): split when the
 // tiles cover at most half of the CUs, into as many slices as fit one round, each at least 8 K-tiles long, within the workspace.
 int pd_igemm256_ksplit(const pd_igemm_args& a, int kind) {
   const int max_tiles = a.splitk_max_tiles > 0 ? a.splitk_max_tiles : a.splitk_max_tiles < 0 ? 0 : 128;   // (A/B switch of the caller)
@@ -448,7 +448,7 @@ int pd_igemm256_ksplit(const pd_igemm_args& a, int kind) {
   const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int nk = a.taps * (a.Cin >> (a.fp8 ? 7 : 6));       // K-tiles of 128 B per row
   if (tiles > max_tiles || nk < 32) return 0;
-  int64_t ks = std::min<int64_t>(256 / tiles, nk / 8);
+  int64_t ks = std::min<int64_t>(pd_num_cus() / tiles, nk / 8);
   ks = std::min<int64_t>(ks, a.splitk_ws_elems / ((int64_t)a.M * a.N));
   return ks >= 2 ? (int)ks : 0;
 }

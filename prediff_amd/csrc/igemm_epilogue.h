@@ -46,10 +46,12 @@ __device__ __forceinline__ void igemm_epilogue_rows(const pd_igemm_args& p, cons
         for (int q = 0; q < CW / 4; ++q) { const float4 t4 = *(const float4*)(rv + 4 * q); v[4 * q] += t4.x; v[4 * q + 1] += t4.y; v[4 * q + 2] += t4.z; v[4 * q + 3] += t4.w; }
       }
       if (act != 0) {
-        // bf16-only GELU producer (FFN-1 of the bf16 engine: ACT and OL are compile-time here): the 9-instruction sigmoid form, 2.5e-5 from
-        // the erf form and rounded to bf16 right below; every other call site (hi/lo engine included) keeps act_apply
+        // a 16-bit-only producer (FFN-1 of the single-pass engines; compile-time in the hot instantiation, the same rule at run time in
+        // the generic ones): the 9-instruction sigmoid-form GELU, 2.5e-5 from the erf form and rounded to 16 bits right below; an fp32
+        // or hi/lo output (the fp32-class engine) keeps act_apply's erf form
+        const bool only16 = (ACT == PD_ACT_GELU && OL == 0 && OF == 0) || (has_ob && !has_ol && !has_of);
 #pragma unroll
-        for (int e = 0; e < CW; ++e) v[e] = (ACT == PD_ACT_GELU && OL == 0 && OF == 0) ? gelu_sigmoid(v[e]) : act_apply(v[e], act);
+        for (int e = 0; e < CW; ++e) v[e] = only16 ? act_apply16(v[e], act) : act_apply(v[e], act);
       }
       if (has_mu) {
 #pragma unroll
@@ -104,7 +106,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const pd_igemm_args& p, cons
         if (n + e >= p.N) break;
         float x = v[e] * p.alpha + bias_v[e];
         if (rv) x += rv[e];
-        x = act_apply(x, act);
+        x = (has_ob && !has_ol && !has_of) ? act_apply16(x, act) : act_apply(x, act);
         if (mu) x *= mu[e];
         if (rs) x += rs[e];
         if (has_of) outf[(int64_t)m * p.ld_out + n + e] = x;

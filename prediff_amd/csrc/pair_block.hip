@@ -105,6 +105,11 @@ struct pd_pair_args_k {
   unsigned long long* trace;
   float* dbg_buf;             // PD_PAIR_DEBUG builds only: [rows][256] dump of one intermediate of head 0 (dbg_stage)
   int dbg_stage;
+  // split forms (MODE 1 / 2, small grids): blockIdx.y = slice (head / quarter of the hidden units)
+  const float* slab_in;       // MODE 2: the NSPL attention partials [slice][B * ntok][C] of MODE 1, summed in slice order onto x + b_proj
+  float* slab_out;            // MODE 1 / 2: this slice's partial result, [slice][B * ntok][C]
+  const void* wstream2;       // MODE 2: the FFN chunks in quarter-major order (packing.pack_pair_ffn_split)
+  uint32_t w2bytes;
 };
 
 __device__ __forceinline__ float pk_rows4_max(float v) {
@@ -166,7 +171,18 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
                                       // property of the chunk pair, the four waves meet at every chunk's barrier)
 #endif
 
-template <int NC, int CW, int NWV = 4>
+// MODE (small grids: a 64-row tile per CU leaves most of the chip idle and every tile streams ALL the weights -- 6.3 MB at units 512):
+//   0  the whole pair in one workgroup per tile (everything above);
+//   1  grid (tiles, 4): workgroup (tile, h) runs LayerNorm-1 and head h only (a quarter of the attention chunks) and stores its proj
+//      partial  Wp[:, head h] O_h  (no bias, no residual) to slab_out[h];
+//   2  grid (tiles, 4): workgroup (tile, s) forms  x' = ((((x + b_proj) + slab_in[0]) + slab_in[1]) + slab_in[2]) + slab_in[3]  (fixed order:
+//      deterministic), LayerNorm-2, and the FFN over hidden units [s HID / 4, (s + 1) HID / 4) from the quarter-major stream wstream2;
+//      slice 0's partial starts from x' + b_2, the others from zero; -> slab_out[s].  pair_split_sum_kernel adds the four.
+// Four times the workgroups, a quarter of the weight stream each.  The split forms keep no cross-tile pipelining of the rows (plain
+// bursts at the tile boundaries); their fp32 summation order differs from MODE 0's (partials added instead of one running accumulator),
+// so the engine uses them only where it may choose kernels by launch size (split_k: the small-batch mode).
+constexpr int PAIR_NSPL = 4;
+template <int NC, int CW, int NWV = 4, int MODE = 0>
 __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace pairk;
@@ -176,6 +192,12 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
                 T_B1 = GG::T_B1, T_RB = GG::T_RB, T_FLOATS = GG::T_FLOATS, RING_OFF = GG::RING_OFF, CH_ALL = GG::CH_ALL;
   static_assert(NC * CW <= 2, "a wave holds 32 x 256 or 16 x 512 fp32 row values");
   static_assert(NWV == 4 || (NWV == 8 && NC == 1 && CW == 1), "eight waves (two per SIMD, 256 registers each): 16 x 256 rows per wave only");
+  static_assert(MODE == 0 || (NC == 1 && NWV == 4 && NJ % PAIR_NSPL == 0 && HEADS == PAIR_NSPL), "split forms: one group per wave, four waves");
+  // the slice of a split form and its window of the weight stream
+  constexpr int CH_HEAD = 4 * NQ, CH_FQ = 2 * (NJ / PAIR_NSPL) * NW, NJL = MODE == 2 ? NJ / PAIR_NSPL : NJ;
+  const int slice = MODE ? (int)blockIdx.y : 0;
+  const int kid_base = MODE == 1 ? slice * CH_HEAD : MODE == 2 ? slice * CH_FQ : 0;
+  const int kid_end = MODE == 1 ? kid_base + CH_HEAD : MODE == 2 ? kid_base + CH_FQ : CH_ALL;
   constexpr int DPW = NFRAG / NWV;                  // 1 KB DMA pieces per wave per chunk: 8 / 4
   constexpr int PF = FragPipe<NC, NWV>::PF, PFN = FragPipe<NC, NWV>::PFN;
   static_assert(NFRAG % PFN == 0 && PF + 2 <= PFN && PF % 2 == 0 && PF + 4 <= 15, "fragment pipeline geometry");
@@ -190,14 +212,15 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
   __syncthreads();
 
   // ---- weight stream: chunk ids 0 .. CH_ALL-1 cyclically, chunk number n -> ring slot n & 3 ----
-  const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, p.wbytes, 0x00020000);
+  const auto rW = MODE == 2 ? __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream2, 0, p.w2bytes, 0x00020000)
+                            : __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, p.wbytes, 0x00020000);
   // Every wave copies a quarter of every chunk, as 8 pieces of 1 KB (one DMA instruction each); piece k of a wave belongs to chunk
   // k / 8.  The prologue issues chunks 0..2, then the 8 pieces of chunk c + 3 go out in one burst behind the mid-chunk barrier of
   // chunk c (everybody is past chunk c - 1, whose slot this is).
   // The instruction's immediate offset advances BOTH the global and the LDS address, so a burst needs two scalar address pairs (pieces
   // 0..3 and 4..7 with immediates 0 / 1024 / 2048 / 3072), not eight: ~10 scalar instructions per chunk instead of ~110 (they were a
   // fifth of all instructions the level-1 instantiation issued in its FFN loop).
-  int n_chunk = 0, kid = 0;                        // chunks requested by this wave; stream id of the next one
+  int n_chunk = 0, kid = kid_base;                 // chunks requested by this wave; stream id of the next one
   const uint32_t dma_voff = (uint32_t)lane * 16u;
   auto issue_chunk = [&]() {
 #if PD_PAIR_ABLATE & 1
@@ -216,7 +239,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
       BLDS16I(rW, d + 4096, dma_voff, so + 4096u, 3072);
     }
     ++n_chunk;
-    kid = (kid + 1 == CH_ALL) ? 0 : kid + 1;
+    kid = (kid + 1 == kid_end) ? kid_base : kid + 1;
   };
   static_assert(DPW == 8 || DPW == 4, "issue_chunk is written out for 8 or 4 pieces per wave");
   issue_chunk();
@@ -316,7 +339,9 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
   // invalid slot gets an offset beyond the buffers: its loads return 0 and its stores are dropped by the descriptor's bounds check --
   // ALWAYS exactly NC * CT load and store instructions per tile, no lane ever branches.
   const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
-  const auto rO = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.xbytes, 0x00020000);
+  // MODE 1 / 2: the rows leave to this slice's slab (same row layout as x: the same lane offsets address it)
+  const auto rO = MODE ? __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.slab_out + (size_t)slice * p.xbytes), 0, p.xbytes, 0x00020000)
+                       : __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.xbytes, 0x00020000);
   constexpr uint32_t OOB = 0xFFFFF000u;
   auto tile_rows = [&](int tile, uint32_t (&off)[NC]) {
     // (the lane id is re-derived here, opaquely: q and g kept alive across the whole tile loop were the two registers this kernel
@@ -348,7 +373,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #endif
 #define PK_ROW_LD(OFF, NT) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (OFF) + (uint32_t)((NT) * 64), 0, PD_PAIR_AUX_LD))
 #define PK_ROW_ST(V, OFF, NT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), rO, (OFF) + (uint32_t)((NT) * 64), 0, PD_PAIR_AUX_ST)
-#define PK_HOOK_IO (!(PD_PAIR_ABLATE & 16))
+#define PK_HOOK_IO (!(PD_PAIR_ABLATE & 16) && MODE == 0)      /* (the split forms move their rows in plain bursts) */
   // hook of fragment group gi in the TP-th chunk of a tile: row instruction 16 TP + gi of the NC * CT stores of the previous tile's rows
 #define PK_ST_HOOK(TP)                                                                                                     \
   { const int fi_ = 16 * (TP) + gi; if (PK_HOOK_IO && fi_ < NC * CT) PK_ROW_ST(acc[fi_ / CT][fi_ % CT], ooff[fi_ / CT], fi_ % CT); }
@@ -364,14 +389,48 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
   uint32_t roff[NC], noff[NC], ooff[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) roff[c] = ooff[c] = OOB;
-  tile_rows(blockIdx.x, noff);
+  if constexpr (MODE == 0) {
+    tile_rows(blockIdx.x, noff);
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int nt = 0; nt < CT; ++nt) {
-      xn[c][nt] = PK_ROW_LD(noff[c], nt);
-      acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};       // (the first tile has no predecessor: its hook stores go to OOB offsets)
+      for (int nt = 0; nt < CT; ++nt) {
+        xn[c][nt] = PK_ROW_LD(noff[c], nt);
+        acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};     // (the first tile has no predecessor: its hook stores go to OOB offsets)
+      }
+  }
+  // MODE 2: x' = ((((x + b_proj) + P_0) + P_1) + P_2) + P_3 from the attention partials of MODE 1 -- always in this order.  One slab per
+  // round trip into acc (nothing else is alive yet; two slabs at a time -- a third 128-register array -- spilled).
+  auto sum_partials = [&](const uint32_t (&off)[NC], f32x4 (&dst)[NC][CT], f32x4 (&tmp)[NC][CT]) {
+    const auto rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.slab_in, 0, p.xbytes * (uint32_t)PAIR_NSPL, 0x00020000);
+#pragma unroll 1
+    for (int k = 0; k < PAIR_NSPL; ++k) {
+      const uint32_t so = (uint32_t)k * p.xbytes;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt)     // (an invalid row keeps its out-of-range LANE offset: zeros, whatever the scalar offset adds)
+          tmp[c][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rS, off[c] + (uint32_t)(nt * 64), so, 0));
+      if (k == 0) {                          // x + b_proj while the first slab is in flight
+#pragma unroll
+        for (int blk = 0; blk < CT / 8; ++blk) {
+          f32x4 bv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) PK_LDS_F4(bv[i], vtab, (T_BP + 16 * (blk * 8 + i)) * 4);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]));
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dst[c][blk * 8 + i] = dst[c][blk * 8 + i] + bv[i];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) dst[c][nt] = dst[c][nt] + tmp[c][nt];
     }
+  };
   // chunks 0..2 landed (the row loads above are younger: this wait covers both), visible to every wave; fragment prologue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -387,7 +446,26 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
       roff[c] = noff[c];
       noff[c] = OOB;
     }
-    if (tile + (int)gridDim.x < p.ntiles) tile_rows(tile + gridDim.x, noff);
+    if (MODE == 0 && tile + (int)gridDim.x < p.ntiles) tile_rows(tile + gridDim.x, noff);
+    if constexpr (MODE != 0) {
+      // split forms: a tile's rows arrive in one burst at its start (nothing is carried from tile to tile: no row registers live
+      // across the chunk loops beyond the one array in use)
+      tile_rows(tile, roff);
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int nt = 0; nt < CT; ++nt) xn[c][nt] = PK_ROW_LD(roff[c], nt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {                                       // MODE 2: x' is built in acc (where MODE 0 has it at this point), xn is the scratch array
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int nt = 0; nt < CT; ++nt) acc[c][nt] = PK_ROW_LD(roff[c], nt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sum_partials(roff, acc, xn);
+      }
+    }
 #if PD_PAIR_DEBUG
     auto dump4 = [&](int stage, int c, const f32x4& a, const f32x4& b, const f32x4& cc4, const f32x4& d) {
       if (p.dbg_buf && p.dbg_stage == stage && roff[c] != OOB) {
@@ -465,8 +543,15 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
       for (int nt = 0; nt < CT; ++nt)
         if (PK_HOOK_IO) PK_ROW_ST(acc[0][nt], ooff[0], nt);
     }
-    layer_norm(xn, T_LN1G, T_LN1B, p.eps1);
-    if constexpr (CW == 2) add_vec(xn, T_BP);
+    if constexpr (MODE != 2) layer_norm(xn, T_LN1G, T_LN1B, p.eps1);
+    if constexpr (MODE == 1) {                       // a head's proj partial alone: the accumulator starts from zero
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (CW == 2 && MODE == 0) {
+      add_vec(xn, T_BP);
+    }
     PK_TRACE();   // LN1 done
     // VMEM schedule around a tile boundary (hooks issue one row instruction per fragment group).  With 32 row instructions per tile
     // (NC * CW == 2): the two LAST chunks of a tile carry 16 loads each, the two FIRST chunks of the next one 16 stores each, nothing
@@ -484,9 +569,10 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
     //     first chunk: 8 + 8 + 16 + 32 = 64 (-> 63, the field's maximum: a stronger wait);  second: 8 + 8 + 32 = 48;  from the third on: 8.
     constexpr bool IO32 = NC * CW == 2;
     // (all of the above with 8 DMA pieces per wave and chunk; in general DPW + the hook instructions of the window)
-    constexpr int VMC_E1 = DPW + 8, VMC_E0 = DPW + (IO32 ? 24 : 16);
-    constexpr int VMC_T0 = CW == 2 ? 63 : DPW + (IO32 ? 32 : 16), VMC_T1 = CW == 2 ? 48 : DPW + (IO32 ? 32 : 16),
-                  VMC_T2 = CW == 2 ? DPW : DPW + (IO32 ? 24 : 8), VMC_T3 = CW == 2 ? DPW : DPW + (IO32 ? 8 : 0);
+    // (the split forms issue no row instruction inside the chunk loops: DPW everywhere)
+    constexpr int VMC_E1 = MODE ? DPW : DPW + 8, VMC_E0 = MODE ? DPW : DPW + (IO32 ? 24 : 16);
+    constexpr int VMC_T0 = MODE ? DPW : CW == 2 ? 63 : DPW + (IO32 ? 32 : 16), VMC_T1 = MODE ? DPW : CW == 2 ? 48 : DPW + (IO32 ? 32 : 16),
+                  VMC_T2 = MODE ? DPW : CW == 2 ? DPW : DPW + (IO32 ? 24 : 8), VMC_T3 = MODE ? DPW : CW == 2 ? DPW : DPW + (IO32 ? 8 : 0);
     // FM: 1 = the tile's first head at compile time (level 0: head 0 is its own instantiation, with the row stores in its hooks),
     // 0 = not the first, 2 = level 1: the wait counts of head 0 chosen at run time (h is uniform: a scalar branch)
 #define PK_SYNC_T(TP)                                                                                                       \
@@ -593,26 +679,45 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #define PK_P_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(3 * NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_OUT(of, SUB), (void)0)
       PK_P_CHUNK(0) PK_P_CHUNK(1) PK_P_CHUNK(2) PK_P_CHUNK(3)
     };
-    if constexpr (CW == 1) {
+    if constexpr (MODE == 1) {
+      head(std::integral_constant<int, 0>{}, slice);        // this workgroup's head; FM = 0: no row traffic in its hooks, plain wait counts
+    } else if constexpr (MODE == 0 && CW == 1) {
       head(std::integral_constant<int, 1>{}, 0);
 #pragma unroll 1
       for (int h = 1; h < HEADS; ++h) head(std::integral_constant<int, 0>{}, h);
-    } else {
+    } else if constexpr (MODE == 0) {
 #pragma unroll 1
       for (int h = 0; h < HEADS; ++h) head(std::integral_constant<int, 2>{}, h);
     }
     PK_DRAIN();                                     // (a LayerNorm follows)
     PK_TRACE();   // attention done
+    if constexpr (MODE == 1) {                       // the partial leaves to this head's slab; nothing else to do for the tile
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) PK_ROW_ST(acc[c][nt], roff[c], nt);
+      continue;
+    }
 
     // ================= FFN: x += W2 gelu(W1 LN2(x) + b1) + b2 =================
+    // (MODE 2: x' -- the partials summed onto x + b_proj at the tile boundary -- sits in acc, as it does here in MODE 0)
     layer_norm(acc, T_LN2G, T_LN2B, p.eps2);
     add_vec(acc, T_B2);
+    if constexpr (MODE == 2) {
+      // only slice 0's partial carries x' + b_2: a multiplication by 1 or 0 (a conditional assignment of the 128 accumulator registers
+      // -- the rows sit in AGPRs here -- cost the kernel 188 spilled registers; a non-finite x' becomes NaN in every slice, as it should)
+      const float keep = slice == 0 ? 1.0f : 0.0f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) acc[c][nt] = acc[c][nt] * keep;
+    }
     PK_TRACE();   // LN2 done
     // Order of the 64-wide hidden slices: W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0..NJ-3, W2_{NJ-2}, W2_{NJ-1} (NW chunks each).  gelu(h_j)
     // has the chunks between W1_j and W2_j to itself, as three software-pipelined stages (polynomial | exp, +1 | rcp, mul) of one value
     // per fragment group: independent short chains beside the MFMAs instead of one 9-deep dependent chain per value (a lone wave hides
     // no VALU latency).
-    const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4);
+    const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4) + (MODE == 2 ? (uint32_t)slice * (uint32_t)(GG::HID / PAIR_NSPL * 4) : 0u);   // (b1 of this slice's hidden units)
     f32x4 hc[NC][4], hn[NC][4], b1n[4];
     float ga[16 * NC], gd[16 * NC];
 #define PK_HV(H, v) H[(v) >> 4][((v) >> 2) & 3][(v) & 3]
@@ -681,12 +786,12 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
     PK_TRACE();   // W1_1 done
     // invariant: hfr = gelu(h_j) as fragments, hn = h_{j+1} (pre-activation), b1n = b1 of slice j + 2
 #pragma unroll 1
-    for (int j = 0; j < NJ - 2; ++j) {
+    for (int j = 0; j < NJL - 2; ++j) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) hc[c][ht] = b1n[ht];
-      const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < NJ ? j + 3 : 0) * 256u;
+      const uint32_t vb1n = vb1 + (uint32_t)(j + 3 < NJL ? j + 3 : 0) * 256u;
       if constexpr (NC == 2 && PD_PAIR_GELU_BOTH) {
         // x^T += W2[:, slice j] gelu(h_j)^T   beside the first half of gelu(h_{j+1}) (group 0)
         PK_W2_SLICE(PK_GELU_GROUP(hn, 0, 1, gi), PK_GELU_TAIL(hn, 0, 1), (void)0, (void)0)
@@ -733,25 +838,33 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
     }
     PK_DRAIN();                                     // (the next tile's LayerNorm follows)
     PK_TRACE();   // FFN done
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) PK_ROW_ST(acc[c][nt], roff[c], nt);
+    }
   }
   // ---- the last tile's rows ----
+  if constexpr (MODE == 0) {
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int nt = 0; nt < CT; ++nt) PK_ROW_ST(acc[c][nt], roff[c], nt);
+      for (int nt = 0; nt < CT; ++nt) PK_ROW_ST(acc[c][nt], roff[c], nt);
+  }
   // nothing of this workgroup may still be writing LDS when its allocation is handed to the next one
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
 
-template <int NC, int CW, int NWV = 4>
+template <int NC, int CW, int NWV = 4, int MODE = 0>
 static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   using namespace pairk;
   constexpr int LDS_BYTES = G<CW>::LDS_BYTES;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW, NWV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_ffn_pair: hipFuncSetAttribute(%d) failed: %s", LDS_BYTES, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -759,11 +872,22 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
     attr_set = true;
   }
   // persistent: every workgroup takes the same number of tiles (the last few one less), one workgroup per CU
-  const int per_wg = (a.ntiles + 255) / 256;
+  // (split forms: PAIR_NSPL workgroups per tile -- blockIdx.y = the slice)
+  const int ncu = pd_num_cus();
+  constexpr int WPT = MODE ? PAIR_NSPL : 1;
+  const int per_wg = (a.ntiles * WPT + ncu - 1) / ncu;
   const int grid = (a.ntiles + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL((pair_kernel<NC, CW, NWV>), dim3((unsigned)grid), dim3(NWV * 64), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((pair_kernel<NC, CW, NWV, MODE>), dim3((unsigned)grid, (unsigned)WPT), dim3(NWV * 64), LDS_BYTES, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
+}
+
+// out = ((P_0 + P_1) + P_2) + P_3 over the four FFN partials of the split form (P_0 carries x' + b_2): 16 B per thread, fixed order
+__global__ void __launch_bounds__(256) pair_split_sum_kernel(const float4* __restrict__ slabs, float4* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 a = slabs[i], b = slabs[i + n4], c = slabs[i + 2 * n4], d = slabs[i + 3 * n4];
+    out[i] = make_float4(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y, ((a.z + b.z) + c.z) + d.z, ((a.w + b.w) + c.w) + d.w);
+  }
 }
 
 #ifndef PD_PAIR_BIG_FORM
@@ -790,20 +914,19 @@ extern "C" int pd_f16_attn_ffn_pair(const float*, float*, const void*, const flo
 extern "C" int pd_attn_ffn_pair_cuboids_per_group(int vol);
 #endif
 
-extern "C" int PD_ENTRY(attn_ffn_pair)(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
-                                       const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn,
-                                       float eps_ffn, const pd_call_opts* opts, pd_stream_t stream) {
+// argument checks + the kernel's argument struct, shared by the one-launch and the split form
+static int pair_fill_args(pd_pair_args_k& a, const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
+                          const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn, float eps_ffn,
+                          const pd_call_opts* opts) {
   using namespace pairk;
-  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_attn_ffn_pair(x, out, wstream, vecs, tok_index, tok_affine, B, ntok, nc, vol, units, scale, eps_attn,
-                                                         eps_ffn, opts, stream));
   PD_CHECK_ARG(x && out && wstream && vecs, "pd_attn_ffn_pair: null pointer");
   PD_CHECK_ARG(units == 256 || units == 512, "pd_attn_ffn_pair: units %d (256 or 512)", units);
   PD_CHECK_ARG(B > 0 && ntok > 0 && (int64_t)B * ntok < (1ll << 31), "pd_attn_ffn_pair: bad sizes");
   PD_CHECK_ARG(nc > 0 && vol >= 1 && vol <= 16, "pd_attn_ffn_pair: cuboid volume %d not in 1..16", vol);
   PD_CHECK_ARG(tok_index || (tok_affine && tok_affine[0] > 0), "pd_attn_ffn_pair: neither a token table nor its affine form");
   PD_CHECK_ARG((int64_t)B * ntok * (units * 4) < 0xFFFFF000ll, "pd_attn_ffn_pair: x larger than a 4 GiB buffer descriptor");
-  pd_pair_args_k a;
   a.x = x; a.out = out; a.wstream = wstream; a.vecs = vecs; a.tok_index = tok_index;
+  a.slab_in = nullptr; a.slab_out = nullptr; a.wstream2 = nullptr; a.w2bytes = 0;
   a.scale = scale; a.eps1 = eps_attn; a.eps2 = eps_ffn;
   a.wbytes = (uint32_t)((units == 256 ? G<1>::CH_ALL : G<2>::CH_ALL) * CHUNK);
   a.xbytes = (uint32_t)((int64_t)B * ntok * (units * 4));
@@ -823,6 +946,18 @@ extern "C" int PD_ENTRY(attn_ffn_pair)(const float* x, float* out, const void* w
   a.aff_inner = a.aff_on ? tok_affine[2] : 0;
   a.aff_slot = a.aff_on ? tok_affine[3] : 0;
   a.gps = (nc + a.pack - 1) / a.pack;
+  return PD_OK;
+}
+
+extern "C" int PD_ENTRY(attn_ffn_pair)(const float* x, float* out, const void* wstream, const float* vecs, const int32_t* tok_index,
+                                       const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn,
+                                       float eps_ffn, const pd_call_opts* opts, pd_stream_t stream) {
+  using namespace pairk;
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_attn_ffn_pair(x, out, wstream, vecs, tok_index, tok_affine, B, ntok, nc, vol, units, scale, eps_attn,
+                                                         eps_ffn, opts, stream));
+  pd_pair_args_k a;
+  const int rc = pair_fill_args(a, x, out, wstream, vecs, tok_index, tok_affine, B, ntok, nc, vol, units, scale, eps_attn, eps_ffn, opts);
+  if (rc != PD_OK) return rc;
   const int64_t groups = (int64_t)B * a.gps;
   if (units == 512) {                               // one group per wave: 64-row tiles
     a.ntiles = (int)((groups + 3) / 4);
@@ -833,13 +968,62 @@ extern "C" int PD_ENTRY(attn_ffn_pair)(const float* x, float* out, const void* w
   // the other's MFMAs; opts->pair_form = 8); below that ONE group per wave and four waves (64-row tiles): twice the workgroups,
   // half the MFMAs per streamed chunk -- the small-batch form
   const int force = opts ? opts->pair_form : 0;      // A/B: 1 / 2 = 16-slot groups per wave (four waves), 8 = eight waves of one group
-  const int nc_wave = force ? force : ((groups + 7) / 8 > 128 ? PD_PAIR_BIG_FORM : 1);
+  const int nc_wave = force ? force : ((groups + 7) / 8 > pd_num_cus() / 2 ? PD_PAIR_BIG_FORM : 1);
   if (nc_wave == 8) {
     a.ntiles = (int)((groups + 7) / 8);
     return launch_pair<1, 1, 8>(a, (hipStream_t)stream);
   }
   a.ntiles = (int)((groups + 4 * nc_wave - 1) / (4 * nc_wave));
   return nc_wave == 2 ? launch_pair<2, 1>(a, (hipStream_t)stream) : launch_pair<1, 1>(a, (hipStream_t)stream);
+}
+
+// ---- the pair as three launches for small grids (few trajectories per launch): four workgroups per 64-row tile -----------------------
+#if !PD_IS_F16
+extern "C" int64_t pd_attn_ffn_pair_split_ws_floats(int B, int ntok, int units) { return (int64_t)2 * PAIR_NSPL * B * ntok * units; }
+extern "C" int pd_f16_attn_ffn_pair_split(const float*, float*, const void*, const void*, const float*, const int32_t*, const int32_t*, int, int, int, int,
+                                          int, float, float, float, float*, int64_t, const pd_call_opts*, pd_stream_t);
+#else
+extern "C" int64_t pd_attn_ffn_pair_split_ws_floats(int B, int ntok, int units);
+#endif
+
+extern "C" int PD_ENTRY(attn_ffn_pair_split)(const float* x, float* out, const void* wstream, const void* wffn_split, const float* vecs,
+                                             const int32_t* tok_index, const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units,
+                                             float scale, float eps_attn, float eps_ffn, float* ws, int64_t ws_floats, const pd_call_opts* opts,
+                                             pd_stream_t stream) {
+  using namespace pairk;
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_attn_ffn_pair_split(x, out, wstream, wffn_split, vecs, tok_index, tok_affine, B, ntok, nc, vol, units,
+                                                               scale, eps_attn, eps_ffn, ws, ws_floats, opts, stream));
+  pd_pair_args_k a;
+  const int rc = pair_fill_args(a, x, out, wstream, vecs, tok_index, tok_affine, B, ntok, nc, vol, units, scale, eps_attn, eps_ffn, opts);
+  if (rc != PD_OK) return rc;
+  PD_CHECK_ARG(wffn_split && ws, "pd_attn_ffn_pair_split: null pointer");
+  // (built for the level-1 blocks: at units 256 a 64-row tile streams 1.5 MB and small grids already have a tile per CU from 4 trajectories on)
+  PD_CHECK_ARG(units == 512, "pd_attn_ffn_pair_split: units %d (the split form is built for units 512)", units);
+  PD_CHECK_ARG(ws_floats >= pd_attn_ffn_pair_split_ws_floats(B, ntok, units), "pd_attn_ffn_pair_split: workspace of %lld floats, %lld needed",
+               (long long)ws_floats, (long long)pd_attn_ffn_pair_split_ws_floats(B, ntok, units));
+  PD_CHECK_ARG((int64_t)PAIR_NSPL * a.xbytes < 0xFFFFF000ll, "pd_attn_ffn_pair_split: the four slabs exceed a 4 GiB buffer descriptor");
+  PD_CHECK_ARG((((uintptr_t)ws | (uintptr_t)out) & 15) == 0, "pd_attn_ffn_pair_split: ws / out must be 16 B aligned");
+  const int64_t groups = (int64_t)B * a.gps, n = (int64_t)B * ntok * units;
+  a.ntiles = (int)((groups + 3) / 4);                // one group per wave, four waves: 64-row tiles
+  float* slab_a = ws;                                // the four attention partials
+  float* slab_f = ws + PAIR_NSPL * n;                // the four FFN partials
+  hipStream_t s = (hipStream_t)stream;
+  // 1: (tile, head) -> proj partial of that head
+  a.slab_out = slab_a;
+  int r = launch_pair<1, 2, 4, 1>(a, s);
+  if (r != PD_OK) return r;
+  // 2: (tile, quarter) -> x' = x + b_proj + sum of the partials, LayerNorm, the quarter's FFN partial
+  a.slab_in = slab_a;
+  a.slab_out = slab_f;
+  a.wstream2 = wffn_split;
+  a.w2bytes = (uint32_t)(2 * G<2>::NJ * G<2>::NW * CHUNK);
+  r = launch_pair<1, 2, 4, 2>(a, s);
+  if (r != PD_OK) return r;
+  // 3: out = the four FFN partials in order
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(pair_split_sum_kernel, dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s, (const float4*)slab_f, (float4*)out, n4);
+  PD_CHECK_LAUNCH();
+  return PD_OK;
 }
 
 }  // namespace PD_NS

@@ -27,7 +27,7 @@ from torch import nn
 
 from . import _lib as L
 from .cuboid_geometry import attention_tables, relative_position_bias, relative_position_index
-from .packing import pack_conv, pack_conv_fp8, pack_linear, pack_linear_fp8, pack_pair_block, pack_pair_vecs, pad64
+from .packing import pack_conv, pack_conv_fp8, pack_linear, pack_linear_fp8, pack_pair_block, pack_pair_ffn_split, pack_pair_vecs, pad64
 from .patterns import CuboidSelfAttentionPatterns
 
 
@@ -362,6 +362,9 @@ class CuboidTransformerUNet(nn.Module):
         # units 512 (level 1): 64-row tiles that stream 6 MB of weights each -- below this many tiles (one per CU) the separate launches,
         # which spread the same rows over all CUs, are faster (scripts/sweep_pair_units.sh)
         self.pair_l1_min_tiles = int(os.environ.get("PD_PAIR_L1_MIN_TILES", "100"))
+        # ... and below that the split form of the same kernel: (tile, head) and (tile, hidden quarter) workgroups + an ordered sum
+        # (pd_attn_ffn_pair_split; only with split_k: its fp32 summation order is not the one-launch kernel's)
+        self.pair_split = os.environ.get("PD_PAIR_SPLIT", "1") != "0"
         self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)
@@ -590,7 +593,9 @@ class CuboidTransformerUNet(nn.Module):
                                             dtype=self.op_dtype),
                             pack_pair_vecs(P[na + ".ln.g"], P[na + ".ln.beta"], P[na + ".proj.b"], P[nf + ".ln.g"], P[nf + ".ln.beta"],
                                            P[nf + ".fc2.b"], P[nf + ".fc1.b"], P[na + ".bias"]),
-                            float(at.norm.eps), float(ff.layer_norm.eps))
+                            float(at.norm.eps), float(ff.layer_norm.eps),
+                            # units 512: the FFN chunks once more in quarter-major order, for the small-grid (split) form of the pair
+                            pack_pair_ffn_split(ff.ffn_1.weight.to(device), ff.ffn_2.weight.to(device), dtype=self.op_dtype) if at.dim == 512 else None)
 
         return dict(f32=f32, lin=lin, conv=conv, norm=norm, resblock=resblock, stack=stack)
 
@@ -879,6 +884,13 @@ class CuboidTransformerUNet(nn.Module):
                 # x += attn(x); x = ffn(x) in one launch, rows register resident (csrc/pair_block.hip)
                 L.attn_ffn_pair(x, x, pair[0], pair[1], tabs[a]["tok"], B, S, geo["nc"], geo["vol"], float(at.scale), eps_attn=pair[2],
                                 eps_ffn=pair[3], tok_affine=geo.get("affine"), units=C, opts=self.opts)
+                continue
+            if pair is not None and C == 512 and C in self.pair_units and self.pair_split and pair[4] is not None:
+                # small grids at units 512: the same pair as three launches, four workgroups per 64-row tile, each streaming a quarter of
+                # the 6.3 MB of weights (instead of the seven launches below)
+                ws = self._buf("pair.split.ws", (L.attn_ffn_pair_split_ws_floats(B, S, C),), torch.float32, dev)
+                L.attn_ffn_pair_split(x, x, pair[0], pair[4], pair[1], tabs[a]["tok"], B, S, geo["nc"], geo["vol"], float(at.scale), ws,
+                                      eps_attn=pair[2], eps_ffn=pair[3], tok_affine=geo.get("affine"), units=C, opts=self.opts)
                 continue
             self._attention(P, f"{name}.attn{a}", at, x, B, S, C, tabs[a], self._geom[level][a], dev)
             if blk.use_inter_ffn:

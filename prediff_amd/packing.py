@@ -159,6 +159,37 @@ def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w
     return out
 
 
+def pack_pair_ffn_split(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16, nsplit: int = 4) -> torch.Tensor:
+    """The FFN part of pack_pair_block's stream re-ordered for pd_attn_ffn_pair_split (units 512): `nsplit` independent sub-streams, one
+    per quarter q of the hidden units (64-wide slices j = q n .. q n + n - 1, n = hidden / 64 / nsplit), each in the software-pipelined
+    order of the kernel's FFN loop: W1_0', W1_1', (W2_j', W1_{j+2}') for j' = 0 .. n - 3, W2_{n-2}', W2_{n-1}' (primes = local slices)."""
+    Cn, hid = w2.shape
+    assert Cn in (256, 512) and tuple(w1.shape) == (hid, Cn) and hid == 4 * Cn
+    CT = Cn // 16
+    f1, f2 = _mfma_frags(to_operand(w1.detach(), dtype)), _mfma_frags(to_operand(w2.detach(), dtype))
+
+    def tile_chunks(fr, F0, nF, K0, nK):
+        v = fr[F0:F0 + nF, K0:K0 + nK].permute(1, 0, 2, 3).reshape(nF * nK, 64, 8)
+        return list(v.reshape(nF * nK // 32, 32, 64, 8))
+
+    nj = hid // 64
+    n = nj // nsplit
+    assert nj % nsplit == 0 and n >= 3
+    w1s = lambda j: tile_chunks(f1, 4 * j, 4, 0, Cn // 32)
+    w2s = lambda j: tile_chunks(f2, 0, CT, 2 * j, 2)
+    chunks = []
+    for q in range(nsplit):
+        j0 = q * n
+        chunks += w1s(j0) + w1s(j0 + 1)
+        for j in range(n):
+            chunks += w2s(j0 + j)
+            if j + 2 < n:
+                chunks += w1s(j0 + j + 2)
+    out = torch.stack(chunks).contiguous()
+    assert out.shape[0] == 2 * nj * (Cn // 256) and out.numel() * 2 == out.shape[0] * PAIR_CHUNK_BYTES
+    return out
+
+
 def pack_pair_vecs(ln1_g, ln1_b, bproj, ln2_g, ln2_b, b2, b1, rel_bias) -> torch.Tensor:
     """fp32 tables of pd_attn_ffn_pair: LN1 gamma, beta, proj bias, LN2 gamma, beta, FFN-2 bias (units each), FFN-1 bias (hidden), and the
     (4 heads, 16, 16) score table of a 16-slot group: the relative-position bias (4, vol, vol) on the diagonal block of every cuboid the

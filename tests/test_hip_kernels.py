@@ -1054,6 +1054,64 @@ def test_attn_ffn_pair_batch_independent(Cn, shape, cuboid):
             assert torch.equal(run(x, L.CallOpts(pair_form=form)), o8), f"form {form} differs"
 
 
+@pytest.mark.parametrize("operand", ["bf16", "fp16"])
+@pytest.mark.parametrize("name,B", [("L1t13", 2), ("L1h8", 1), ("L1w8", 4), ("L1odd", 3), ("L1h8", 9)])
+def test_attn_ffn_pair_split_vs_oracle(name, B, operand):
+    """pd_attn_ffn_pair_split -- the units-512 pair for small grids as (tile, head) + (tile, hidden quarter) workgroups and an ordered sum
+    of partial slabs (csrc/pair_block.hip MODE 1 / 2) -- against the oracle's statement of the pair (reference cuboid_transformer.py:
+    1147-1156), against the one-launch kernel (same operands; partial sums instead of one running accumulator: fp32 round-off amplified
+    by the 16-bit roundings downstream), in place, twice (bit-equal: the slab sums have a fixed order), and with more tiles than the
+    chip has room for four workgroups each (B = 9 at 104 groups per sample: the persistent path)."""
+    from oracle import unet as OU
+    from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
+    from prediff_amd.packing import pack_pair_block, pack_pair_ffn_split, pack_pair_vecs
+    opts = L.CallOpts(operand)
+    odt, tol = opts.dtype, {"bf16": 6e-3, "fp16": 1e-3}[operand]
+    shape, cuboid, _, Cn, heads, Hd, sd_a, sd_f, _ = _pair_case(name)
+    x = seeded_input("pairsplit" + name, (B,) + shape + (Cn,), 1)
+    y1 = x + OU.cuboid_self_attention(sd_a, "", x, heads, cuboid, (0, 0, 0), LLL, "zeros")
+    y_ref = OU.positionwise_ffn(sd_f, "", y1, "gelu")
+    tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+    vol, nc = tabs["vol"], tabs["nc"]
+    d = lambda t: t.to(DEV)
+    bias = relative_position_bias(sd_a["relative_position_bias_table"], sd_a["relative_position_index"], vol).to(DEV)
+    ws_full = pack_pair_block(d(sd_a["qkv.weight"]), d(sd_a["proj.weight"]), d(sd_f["ffn_1.weight"]), d(sd_f["ffn_2.weight"]), dtype=odt)
+    ws_ffn = pack_pair_ffn_split(d(sd_f["ffn_1.weight"]), d(sd_f["ffn_2.weight"]), dtype=odt)
+    vecs = pack_pair_vecs(d(sd_a["norm.weight"]), d(sd_a["norm.bias"]), d(sd_a["proj.bias"]), d(sd_f["layer_norm.weight"]),
+                          d(sd_f["layer_norm.bias"]), d(sd_f["ffn_2.bias"]), d(sd_f["ffn_1.bias"]), bias)
+    ntok = shape[0] * shape[1] * shape[2]
+    xd = x.reshape(B, ntok, Cn).to(DEV).contiguous()
+    tok = tabs["tok_index"].to(DEV)
+    scale = (Cn // heads) ** -0.5
+    wsp = torch.full((L.attn_ffn_pair_split_ws_floats(B, ntok, Cn),), float("nan"), device=DEV)
+    assert wsp.numel() == L.lib().pd_attn_ffn_pair_split_ws_floats(B, ntok, Cn)
+    out = torch.full_like(xd, float("nan"))
+    L.attn_ffn_pair_split(xd, out, ws_full, ws_ffn, vecs, tok, B, ntok, nc, vol, scale, wsp, tok_affine=tabs["affine"], units=Cn, opts=opts)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()), "a row was not written (or written with garbage)"
+    e = rel_l2((out - xd).reshape(x.shape).cpu(), y_ref - x)
+    full = torch.full_like(xd, float("nan"))
+    L.attn_ffn_pair(xd, full, ws_full, vecs, tok, B, ntok, nc, vol, scale, tok_affine=tabs["affine"], units=Cn, opts=opts)
+    torch.cuda.synchronize()
+    e_full = rel_l2(out - xd, full - xd)
+    print(f"[attn_ffn_pair_split {name} B={B} {operand}] update rel-L2 vs oracle {e:.3e}, vs the one-launch kernel {e_full:.3e}")
+    assert e < tol and e_full < tol / 4
+    # in place, token ids from the table instead of the affine form, and a repeat: bit-identical
+    for aff in (None, tabs["affine"], tabs["affine"]):
+        t = xd.clone()
+        wsp.fill_(float("nan"))
+        L.attn_ffn_pair_split(t, t, ws_full, ws_ffn, vecs, tok, B, ntok, nc, vol, scale, wsp, tok_affine=aff, units=Cn, opts=opts)
+        torch.cuda.synchronize()
+        assert torch.equal(t, out)
+    # a trajectory's rows do not depend on the launch they ride in (groups never straddle samples, the slab order is fixed)
+    if B > 1:
+        t = torch.full_like(xd[:1], float("nan"))
+        L.attn_ffn_pair_split(xd[B - 1:].contiguous(), t, ws_full, ws_ffn, vecs, tok, 1, ntok, nc, vol, scale, wsp, tok_affine=tabs["affine"], units=Cn,
+                              opts=opts)
+        torch.cuda.synchronize()
+        assert torch.equal(t[0], out[B - 1])
+
+
 def test_attn_ffn_pair_rejects_what_it_does_not_run():
     assert not L.attn_ffn_pair_supported(128, 2, 512, 16)
     assert not L.attn_ffn_pair_supported(256, 4, 1024, 25)

@@ -133,7 +133,7 @@ def test_c_abi_exports_every_declared_symbol():
     """libprediff_hip.so loads and exports every function include/prediff_hip.h declares (no GPU needed)."""
     from prediff_amd import _lib as L
     hdr = open(os.path.join(ROOT, "include", "prediff_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(pd_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(pd_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     assert os.path.exists(L.LIB_PATH), "libprediff_hip.so missing: run __graft_entry__.build()"
     so = ctypes.CDLL(L.LIB_PATH)
@@ -267,6 +267,7 @@ def test_pair_packing_layout(Cn):
     assert float(ws[base + 2 * CW, 20, 7, 1]) == elem(w2, 20 % CT, 0 + 20 // CT, 7, 1)                         # W2_0, chunk 0
     assert float(ws[base + 3 * CW, 3, 50, 4]) == elem(w1, 8 + 3, 0, 50, 4)                                     # W1_2, chunk 0
     assert float(ws[nchunks - 1, 31, 63, 7]) == elem(w2, 31 % CT, 2 * (hid // 64 - 1) + (CW - 1) * (32 // CT) + 31 // CT, 63, 7)   # last chunk of W2_{n-1}
+    assert L.attn_ffn_pair_split_ws_floats(3, 832, 512) == L.lib().pd_attn_ffn_pair_split_ws_floats(3, 832, 512)
     for vol in (1, 5, 8, 9, 13, 16):
         assert pair_cuboids_per_group(vol) == L.attn_ffn_pair_cuboids_per_group(vol) == L.lib().pd_attn_ffn_pair_cuboids_per_group(vol)
         bias = torch.randn(4, vol, vol)
