@@ -44,7 +44,7 @@ typedef struct pd_call_opts {
   int32_t attn_block_debug_flags;   /* profiling ablations of the fused attention block (scripts/bench_attn_block.py) */
   int32_t small_grid;               /* != 0: the caller allows kernel choices that depend on the launch size (the engine's small-batch mode; results
                                        then are not bit-identical across batch sizes).  pd_groupnorm_silu: finer channel chunks (twice the workgroups)
-                                       when the default chunks would leave more than half of the CUs idle */
+                                       at <= 1024 rows per sample when the default chunks would leave more than half of the CUs idle */
   unsigned long long* trace;        /* device buffer for per-phase clock stamps of the fused kernels (pd_ffn_fused, pd_attn_block_fused_ex,
                                        pd_attn_ffn_pair in a -DPD_PAIR_DEBUG=1 build), or NULL (production) */
 } pd_call_opts;
@@ -139,15 +139,6 @@ int pd_groupnorm_nchunk(int S, int C);
 int pd_groupnorm_silu(const float* x, const float* gamma, const float* beta, const float* ss_scale,
                       const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, pd_bf16* out_lo,
                       int B, int S, int C, int G, int ld_out, float eps, int silu, const pd_call_opts* opts, pd_stream_t stream);
-
-/* TimeEmbedResBlock's  conv1 -> + bias + timestep-embedding row -> GroupNorm [-> (1 + scale) y + shift] -> SiLU -> 16-bit rows
- * (models/time_embed.py:147-166) as ONE call.  `conv`: the pd_igemm launch of the convolution -- epilogue alpha / bias / rowvec only, out_f32 = its
- * fp32 output h (B samples of M / B rows, ld_out == N == C); the other arguments: pd_groupnorm_silu's over h (ld_out of the rows = C).  When the
- * launch is K-split (a `splitk_ws` in conv, small batches) and h's rows fit the one-pass GroupNorm kernel, that kernel sums the slabs while it
- * loads its rows: no reduce launch, h is neither written nor read -- conv->out_f32 is then left UNTOUCHED and must not be read by the caller.
- * Otherwise the call is pd_igemm followed by pd_groupnorm_silu on out_f32. */
-int pd_conv3d_groupnorm_silu(const pd_igemm_args* conv, const float* gamma, const float* beta, const float* ss_scale, const float* ss_shift,
-                             int ld_ss, double* partials, pd_bf16* out, int G, float eps, int silu, const pd_call_opts* opts, pd_stream_t stream);
 
 /* The statistics pass of pd_groupnorm_silu alone: stats[b][g] = {mean, rstd} (fp32) of nn.GroupNorm(G, C, eps) over channels-last
  * x (B, S, C); partials as for pd_groupnorm_silu.  For consumers that normalise on the fly (pd_conv2d_gn_silu). */

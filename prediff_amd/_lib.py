@@ -90,8 +90,6 @@ _PROTOS = {
     "pd_groupnorm_nchunk": (C.c_int, [C.c_int, C.c_int]),
     "pd_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 +
                           [C.c_float, C.c_int, C.POINTER(CallOpts), C.c_void_p]),
-    "pd_conv3d_groupnorm_silu": (C.c_int, [C.POINTER(IgemmArgs)] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int, C.c_float, C.c_int,
-                                           C.POINTER(CallOpts), C.c_void_p]),
     "pd_groupnorm_stats": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "pd_conv2d_gn_silu_supported": (C.c_int, [C.c_int] * 5),
     "pd_conv2d_gn_silu": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.POINTER(CallOpts), C.c_void_p]),
@@ -190,11 +188,9 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
           A_lo=None, W_lo=None, bias=None, rowvec=None, rows_per_sample=0, residual=None, res_period=0,
           ld_res=None, mul=None, act="none", alpha=1.0, out_f32=None, out_bf16=None, out_bf16_lo=None,
           ld_out=None, ld_outb=None, nbatch=1, a_batch_stride=0, w_batch_stride=0, out_batch_stride=0,
-          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None, fp8=False, out_fp8_log2=0, opts=None,
-          args_only=False):
+          outb_batch_stride=0, res_batch_stride=0, tile=0, debug_flags=0, splitk_ws=None, fp8=False, out_fp8_log2=0, opts=None):
     """Thin wrapper around pd_igemm.  `geom` = dict(B,Ti,Hi,Wi,To,Ho,Wo,KT,KH,KW,st,sh,sw,pt,ph,pw,ut,uh,uw) or None
-    for a plain linear layer.  `opts` (CallOpts): the operand type of A / W / out_bf16 and the caller's A/B presets for this launch.
-    args_only: return the filled pd_igemm_args without launching (conv3d_groupnorm_silu)."""
+    for a plain linear layer.  `opts` (CallOpts): the operand type of A / W / out_bf16 and the caller's A/B presets for this launch."""
     a = IgemmArgs()
     if opts is not None:
         a.operand = 0 if fp8 else opts.operand          # (e4m3 operands: the 16-bit OUTPUT of such a launch is bfloat16)
@@ -231,16 +227,7 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
     a.out_fp8_log2 = out_fp8_log2     # k > 0: out_bf16 is an e4m3 byte tensor receiving e4m3(v * 2^k)
     if splitk_ws is not None:       # fp32 workspace: lets the library split the K loop of small-grid, long-K launches
         a.splitk_ws, a.splitk_ws_elems = ptr(splitk_ws), splitk_ws.numel()
-    if args_only:
-        return a
     _check(lib().pd_igemm(C.byref(a), stream_ptr()), "pd_igemm")
-
-
-def conv3d_groupnorm_silu(conv_args, gamma, beta, partials, out, G, eps, silu=True, ss_scale=None, ss_shift=None, ld_ss=0, opts=None):
-    """conv (an igemm(..., args_only=True) launch with out_f32 = h, epilogue alpha / bias / rowvec) -> GroupNorm [-> scale/shift] -> SiLU -> 16-bit
-    rows in one call; a K-split launch is reduced by the GroupNorm kernel itself and h is then NOT written (pd_conv3d_groupnorm_silu)."""
-    _check(lib().pd_conv3d_groupnorm_silu(C.byref(conv_args), ptr(gamma), ptr(beta), ptr(ss_scale), ptr(ss_shift), ld_ss, ptr(partials), ptr(out),
-                                          G, eps, 1 if silu else 0, _opts_ref(opts), stream_ptr()), "pd_conv3d_groupnorm_silu")
 
 
 def conv_geom(B, in_thw, kernel, stride=(1, 1, 1), pad=(1, 1, 1), up=(1, 1, 1), out_thw=None, virt_thw=None):

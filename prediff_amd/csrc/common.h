@@ -146,15 +146,6 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(const op8& a, const op8& b, cons
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 #endif
 }
-// source of pd_conv3d_groupnorm_silu's GroupNorm kernel when the convolution was K-split (norm.hip, igemm.hip)
-struct gn_sk_src {
-  int ksplit;
-  uint32_t slab_bytes;     // B * S * C * 4
-  float alpha;
-  const float* bias;       // [C] or null
-  const float* rowvec;     // [B][ld_rowvec] or null
-  int ld_rowvec;
-};
 }  // namespace PD_NS
 using namespace PD_NS;
 

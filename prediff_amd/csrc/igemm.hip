@@ -283,9 +283,10 @@ int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s);
 extern "C" int pd_f16_igemm(const pd_igemm_args*, pd_stream_t);
 #endif
 
-// pd_igemm on the library's own copy of the arguments (the fields "set by the library" are filled in: a.ksplit tells the caller how the
-// launch was cut).  debug_flags bit 16 (internal: pd_conv3d_groupnorm_silu): a split-K launch leaves its slabs un-reduced in a.splitk_ws.
-static int igemm_run(pd_igemm_args& a, hipStream_t s) {
+extern "C" int PD_ENTRY(igemm)(const pd_igemm_args* pa, pd_stream_t stream) {
+  PD_CHECK_ARG(pa != nullptr, "pd_igemm: null args");
+  PD_FORWARD_F16(pa->operand == PD_OPERAND_F16, pd_f16_igemm(pa, stream));
+  pd_igemm_args a = *pa;
   PD_CHECK_ARG(!PD_IS_F16 || (!a.split && !a.fp8 && !a.out_bf16_lo), "pd_igemm: IEEE-half operands: no hi/lo split, no e4m3 operands");
   // A/B switches of the caller (0 = the defaults)
   const int min_k_256 = a.min_k_256 > 0 ? a.min_k_256 : 1024;   // shortest K (taps * Cin) the automatic choice gives to the 256 x 256 kernel (512 wins
@@ -312,6 +313,7 @@ static int igemm_run(pd_igemm_args& a, hipStream_t s) {
   PD_CHECK_ARG(!a.split || (a.A_lo && a.W_lo), "pd_igemm: split needs A_lo and W_lo");
   PD_CHECK_ARG(!a.rowvec || a.rows_per_sample > 0, "pd_igemm: rowvec needs rows_per_sample");
   PD_CHECK_ARG(a.out_f32 || a.out_bf16, "pd_igemm: no output");
+  hipStream_t s = (hipStream_t)stream;
   a.vec_epilogue = ((a.N & 3) == 0) && (!a.out_f32 || (a.ld_out & 3) == 0) && (!a.out_bf16 || (a.ld_outb & 3) == 0) &&
                    (!a.residual || (a.ld_res & 3) == 0) && (!a.rowvec || (a.ld_rowvec & 3) == 0) &&
                    (!a.mul || (a.ld_mul & 3) == 0) && (((uintptr_t)a.out_f32 | (uintptr_t)a.residual | (uintptr_t)a.rowvec |
@@ -384,66 +386,6 @@ static int igemm_run(pd_igemm_args& a, hipStream_t s) {
   if (kind == 0) return dispatch_igemm<false, 0>(a, tile, s);
   if (kind == 1) return dispatch_igemm<false, 1>(a, tile, s);
   return dispatch_igemm<false, 2>(a, tile, s);
-}
-
-extern "C" int PD_ENTRY(igemm)(const pd_igemm_args* pa, pd_stream_t stream) {
-  PD_CHECK_ARG(pa != nullptr, "pd_igemm: null args");
-  PD_FORWARD_F16(pa->operand == PD_OPERAND_F16, pd_f16_igemm(pa, stream));
-  pd_igemm_args a = *pa;
-  a.debug_flags &= ~16;
-  return igemm_run(a, (hipStream_t)stream);
-}
-
-// norm.hip
-bool gn_onepass_fits(int S, int C, int G);
-void gn_onepass_launch(const float* x, const float* gamma, const float* beta, const float* ss_scale, const float* ss_shift, int ld_ss,
-                       double* partials, int nchunk, pd_bf16* out, int B, int S, int C, int G, float eps, int silu, bool fine,
-                       const gn_sk_src* sk, hipStream_t s);
-#if !PD_IS_F16
-extern "C" int pd_f16_conv3d_groupnorm_silu(const pd_igemm_args*, const float*, const float*, const float*, const float*, int, double*, pd_bf16*, int,
-                                            float, int, const pd_call_opts*, pd_stream_t);
-#endif
-extern "C" int pd_groupnorm_nchunk(int S, int C);
-extern "C" int PD_ENTRY(groupnorm_silu)(const float*, const float*, const float*, const float*, const float*, int, double*, pd_bf16*, pd_bf16*, int, int,
-                                        int, int, int, float, int, const pd_call_opts*, pd_stream_t);
-
-// TimeEmbedResBlock's  conv1 -> (+ bias, + timestep-embedding row) -> GroupNorm [-> scale/shift] -> SiLU -> 16-bit rows  (models/time_embed.py:147-166)
-// as ONE call: conv = the pd_igemm launch of the convolution (epilogue: alpha, bias, rowvec only; out_f32 = its fp32 output h, B samples of
-// M / B rows, N = C channels), the rest = pd_groupnorm_silu's arguments over h.  When the launch is K-split (small batches: a `splitk_ws` in
-// conv) and the rows fit the one-pass GroupNorm kernel, the slabs are summed by that kernel while it loads its rows: no reduce launch, h is
-// neither written nor read (out_f32 is then left UNTOUCHED -- callers must not read it).  Otherwise: pd_igemm, then pd_groupnorm_silu on out_f32.
-extern "C" int PD_ENTRY(conv3d_groupnorm_silu)(const pd_igemm_args* conv, const float* gamma, const float* beta, const float* ss_scale,
-                                               const float* ss_shift, int ld_ss, double* partials, pd_bf16* out, int G, float eps, int silu,
-                                               const pd_call_opts* opts, pd_stream_t stream) {
-  PD_CHECK_ARG(conv != nullptr, "pd_conv3d_groupnorm_silu: null args");
-  PD_FORWARD_F16(conv->operand == PD_OPERAND_F16, pd_f16_conv3d_groupnorm_silu(conv, gamma, beta, ss_scale, ss_shift, ld_ss, partials, out, G, eps,
-                                                                                silu, opts, stream));
-  pd_igemm_args a = *conv;
-  const int B = a.B, C = a.N;
-  PD_CHECK_ARG(gamma && beta && partials && out && a.out_f32, "pd_conv3d_groupnorm_silu: null pointer");
-  PD_CHECK_ARG(B > 0 && a.M % B == 0 && a.ld_out == C && G > 0 && C % G == 0, "pd_conv3d_groupnorm_silu: bad B/M/ld_out/G (%d,%d,%d,%d)", B, a.M,
-               a.ld_out, G);
-  PD_CHECK_ARG((ss_scale == nullptr) == (ss_shift == nullptr), "pd_conv3d_groupnorm_silu: scale/shift must come together");
-  PD_CHECK_ARG(!a.out_bf16 && !a.residual && !a.mul && a.act == 0 && a.nbatch <= 1,
-               "pd_conv3d_groupnorm_silu: the convolution's epilogue may hold alpha, bias and rowvec only");
-  const int S = a.M / B;
-  hipStream_t s = (hipStream_t)stream;
-  const bool gn_ok = !(opts && opts->groupnorm_two_launches) && gn_onepass_fits(S, C, G) && (!a.rowvec || a.rows_per_sample == S) &&
-                     (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)a.bias | (uintptr_t)a.rowvec | (uintptr_t)a.splitk_ws) & 15) == 0 &&
-                     (a.ld_rowvec & 3) == 0 && ((uintptr_t)out & 7) == 0 &&
-                     (!ss_scale || ((ld_ss % 4 == 0) && (((uintptr_t)ss_scale | (uintptr_t)ss_shift) & 15) == 0));
-  a.debug_flags = gn_ok ? (a.debug_flags | 16) : (a.debug_flags & ~16);
-  const int rc = igemm_run(a, s);
-  if (rc != PD_OK) return rc;
-  if (gn_ok && a.ksplit >= 2) {
-    const gn_sk_src sk = {a.ksplit, (uint32_t)((int64_t)a.M * C * 4), a.alpha, a.bias, a.rowvec, a.ld_rowvec};
-    PD_CHECK_ARG((int64_t)a.ksplit * a.M * C * 4 < 0xFFFFF000ll, "pd_conv3d_groupnorm_silu: the slabs exceed a 4 GiB buffer descriptor");
-    gn_onepass_launch(a.splitk_ws, gamma, beta, ss_scale, ss_shift, ld_ss, partials, pd_groupnorm_nchunk(S, C), out, B, S, C, G, eps, silu,
-                      true, &sk, s);
-    PD_CHECK_LAUNCH();
-    return PD_OK;
-  }
-  return PD_ENTRY(groupnorm_silu)(a.out_f32, gamma, beta, ss_scale, ss_shift, ld_ss, partials, out, nullptr, B, S, C, G, C, eps, silu, opts, stream);
 }
 
 }  // namespace PD_NS

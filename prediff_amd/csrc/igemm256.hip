@@ -431,7 +431,6 @@ static int launch256_splitk(const pd_igemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   hipLaunchKernelGGL((igemm256_kernel<KIND, 8, true, F8>), dim3(tiles, a.ksplit, 1), dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
-  if (a.debug_flags & 16) return PD_OK;      // (pd_conv3d_groupnorm_silu: the GroupNorm kernel sums the slabs)
   const int64_t total = (int64_t)a.M * (a.N >> 2);
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);

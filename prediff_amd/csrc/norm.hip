@@ -445,16 +445,11 @@ __global__ void __launch_bounds__(256) gn_apply_vec_kernel(const float* __restri
 // to 3328: 104 data registers per thread want the 256-register budget of 8 waves); the groups of the chunk (C / G = 4, 8, 16 or 32
 // channels) are reduced over the row lanes of a wave by shuffles and over the waves through LDS in a fixed order.  The choice of
 // this kernel depends on the shape only, never on the batch (the engine's batch-split-reproducible mode).
-// SK (split-K Conv3d -> GroupNorm in the small-batch mode): x is the convolution's un-reduced fp32 slabs [ksplit][B * S][C]
-// (pd_igemm_args.splitk_ws); a value is  alpha * (((slab_0 + slab_1) + slab_2) + ...) + bias[c] + rowvec[b][c]  -- the sums and the
-// epilogue of igemm_splitk_reduce_kernel in its order -- formed while the rows are loaded: the reduce launch, its fp32 write of the
-// convolution's output and this kernel's read of it are gone.
-template <int RMAX, int NT, int CH, bool SK = false>
+template <int RMAX, int NT, int CH>
 __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ ss_scale,
                                                          const float* __restrict__ ss_shift, int ld_ss, double* __restrict__ partials,
-                                                         int nchunk, pd_bf16* __restrict__ out, int S, int C, int G, float eps, int silu,
-                                                         const gn_sk_src sk) {
+                                                         int nchunk, pd_bf16* __restrict__ out, int S, int C, int G, float eps, int silu) {
   constexpr int TPR = CH / 4, NWV = NT / 64, RP = NT / TPR;          // threads per row segment, waves, rows per sweep
   __shared__ float sred[2][NWV][TPR];
   // (sample, chunk) of this workgroup.  With 16-channel chunks a 128-byte line of a row is shared by TWO workgroups: they get ids 8
@@ -475,8 +470,7 @@ __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict_
   const int c = chunk * CH + slot * 4, cpg = C / G, spg = cpg >> 2;   // float4 slots per group: 1, 2, 4 (or 8 with 32-channel chunks)
   // buffer addressing: the sample's rows behind one descriptor, lane offset in a VGPR, the sweep's offset in an SGPR -- no per-load
   // address registers (35 in-flight 64-bit pointers were what spilled); rows >= S get an out-of-range lane offset: zeros / dropped stores
-  const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * S * C), 0,
-                                                    (uint32_t)((int64_t)S * C * 4) + (SK ? (uint32_t)(sk.ksplit - 1) * sk.slab_bytes : 0u), 0x00020000);
+  const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * S * C), 0, (uint32_t)((int64_t)S * C * 4), 0x00020000);
   const auto rO = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * S * C), 0, (uint32_t)((int64_t)S * C * 2), 0x00020000);
   const uint32_t voff = (uint32_t)(rl * C + c) * 4u, sstep = (uint32_t)(RP * C) * 4u;
   constexpr uint32_t GN_OOB = 0xFFFFF000u;
@@ -488,27 +482,6 @@ __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict_
     // rows >= S: an out-of-range LANE offset (whether the hardware's range check also counts the scalar offset is not relied upon)
     const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rX, rl + RP * i < S ? voff : GN_OOB, (uint32_t)i * sstep, 0);
     v[i] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
-  }
-  if constexpr (SK) {
-    for (int k = 1; k < sk.ksplit; ++k) {
-      const uint32_t ko = __builtin_amdgcn_readfirstlane((uint32_t)k * sk.slab_bytes);
-#pragma unroll
-      for (int i = 0; i < RMAX; ++i) {
-        const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rX, rl + RP * i < S ? voff : GN_OOB, (uint32_t)i * sstep + ko, 0);
-        v[i].x += __uint_as_float(w[0]); v[i].y += __uint_as_float(w[1]); v[i].z += __uint_as_float(w[2]); v[i].w += __uint_as_float(w[3]);
-      }
-    }
-    float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), rv = bi;
-    if (sk.bias) bi = *(const float4*)(sk.bias + c);
-    if (sk.rowvec) rv = *(const float4*)(sk.rowvec + (int64_t)b * sk.ld_rowvec + c);
-#pragma unroll
-    for (int i = 0; i < RMAX; ++i) {
-      const bool ok = rl + RP * i < S;       // (rows beyond S stay zero: they are summed into the mean)
-      v[i].x = ok ? (v[i].x * sk.alpha + bi.x) + rv.x : 0.f;
-      v[i].y = ok ? (v[i].y * sk.alpha + bi.y) + rv.y : 0.f;
-      v[i].z = ok ? (v[i].z * sk.alpha + bi.z) + rv.z : 0.f;
-      v[i].w = ok ? (v[i].w * sk.alpha + bi.w) + rv.w : 0.f;
-    }
   }
   // sum over the workgroup's values of this thread's group: row lanes of the wave (lane bits 3..5), the group's slots (lane bits
   // 0..log2(spg)-1), then the 8 waves in order
@@ -570,30 +543,25 @@ __global__ void __launch_bounds__(NT) gn_onepass_kernel(const float* __restrict_
 }
 
 // Shapes of the one-pass kernel: 16-channel chunks holding whole groups, at most 26 x 128 rows (everything of a (sample, chunk) in registers)
-bool gn_onepass_fits(int S, int C, int G) {
+static bool gn_onepass_fits(int S, int C, int G) {
   const int cpg = C / G;
   return C % 32 == 0 && cpg % 4 == 0 && 16 % cpg == 0 && S <= 128 * 26;
 }
-// `fine` (the caller may choose kernels by launch size -- the engine's small-batch mode -- and the coarse chunks would leave more than half
-// of the CUs without a workgroup): chunks of half the width, twice the workgroups, half the rows in flight per thread.  Its statistics are
-// summed in another order than the coarse kernel's (not bit-identical to it).  `sk`: the input is a split-K convolution's slabs (above).
-void gn_onepass_launch(const float* x, const float* gamma, const float* beta, const float* ss_scale, const float* ss_shift, int ld_ss,
+// `fine` (pd_call_opts.small_grid: the caller may choose kernels by launch size -- the engine's small-batch mode) at <= 1024 rows, when the
+// 32-channel chunks would leave more than half of the CUs without a workgroup: 16-channel chunks, twice the workgroups, half the rows in
+// flight per thread (level-1 rows of the SEVIR-LR denoiser at 4 trajectories: 7.3 vs 9.3 us).  Its statistics are summed in another order
+// than the coarse kernel's (not bit-identical to it).  Not for the longer rows: 8-channel chunks there read 32 B of every 128-B line
+// (measured 17.8 vs 16.7 us at level 0).
+static void gn_onepass_launch(const float* x, const float* gamma, const float* beta, const float* ss_scale, const float* ss_shift, int ld_ss,
                               double* partials, int nchunk, pd_bf16* out, int B, int S, int C, int G, float eps, int silu, bool fine,
-                              const gn_sk_src* sk, hipStream_t s) {
+                              hipStream_t s) {
   const int cpg = C / G;
   const bool small = S <= 64 * 16;
-  const int ch_coarse = small ? 32 : 16;
-  fine = fine && (ch_coarse / 2) % cpg == 0 && (int64_t)B * (C / ch_coarse) * 2 <= pd_num_cus();
-  const gn_sk_src none = {1, 0u, 1.f, nullptr, nullptr, 0};
-#define GN1P(RM, CHN, SKB) hipLaunchKernelGGL((gn_onepass_kernel<RM, 512, CHN, SKB>), dim3(B * (C / CHN)), dim3(512), 0, s, x, gamma, beta, \
-                                              ss_scale, ss_shift, ld_ss, partials, nchunk, out, S, C, G, eps, silu, sk ? *sk : none)
-  if (sk) {
-    if (small) { if (fine) GN1P(8, 16, true); else GN1P(16, 32, true); }
-    else { if (fine) GN1P(13, 8, true); else GN1P(26, 16, true); }
-  } else {
-    if (small) { if (fine) GN1P(8, 16, false); else GN1P(16, 32, false); }
-    else { if (fine) GN1P(13, 8, false); else GN1P(26, 16, false); }
-  }
+  fine = fine && small && 16 % cpg == 0 && (int64_t)B * (C / 32) * 2 <= pd_num_cus();
+#define GN1P(RM, CHN) hipLaunchKernelGGL((gn_onepass_kernel<RM, 512, CHN>), dim3(B * (C / CHN)), dim3(512), 0, s, x, gamma, beta, ss_scale, ss_shift, \
+                                         ld_ss, partials, nchunk, out, S, C, G, eps, silu)
+  if (small) { if (fine) GN1P(8, 16); else GN1P(16, 32); }
+  else GN1P(26, 16);
 #undef GN1P
 }
 
@@ -617,7 +585,7 @@ extern "C" int PD_ENTRY(groupnorm_silu)(const float* x, const float* gamma, cons
   // bf16 engine (no lo half), 16-channel chunks holding whole groups, at most 26 x 128 rows: everything of a (sample, chunk) in registers
   if (vec && onepass && !out_lo && gn_onepass_fits(S, C, G)) {
     gn_onepass_launch(x, gamma, beta, ss_scale, ss_shift, ld_ss, partials, nchunk, out, B, S, C, G, eps, silu,
-                      opts && opts->small_grid, nullptr, s);
+                      opts && opts->small_grid, s);
     PD_CHECK_LAUNCH();
     return PD_OK;
   }

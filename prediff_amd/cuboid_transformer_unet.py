@@ -366,7 +366,6 @@ class CuboidTransformerUNet(nn.Module):
         # (pd_attn_ffn_pair_split; only with split_k: its fp32 summation order is not the one-launch kernel's)
         self.pair_split = os.environ.get("PD_PAIR_SPLIT", "1") != "0"
         self.split_k = True           # bf16 mode, <= 16 trajectories per launch: split-K Conv3d (K-slices as extra workgroups)
-        self.fuse_conv_gn = os.environ.get("PD_FUSE_CONV_GN", "1") != "0"   # ... and conv1 -> GroupNorm-2 -> SiLU as one call there (A/B)
         self.input_shape, self.target_shape = input_shape, target_shape
         self.num_blocks = len(depth)
         self.depth = list(depth)
@@ -723,23 +722,12 @@ class CuboidTransformerUNet(nn.Module):
         else:
             a1, a1lo, ld1 = self._gn(x, P[name + ".gn1.g"], P[name + ".gn1.beta"], B, S, Cin, m.in_groups, "gn.a", dev)
             w1, w1lo = P[name + ".conv1.w"]
-            conv1 = dict(M=B * S, N=Cout, Cin=ld1, taps=27, w_tap_stride=Cout * ld1, geom=geom, bias=P[name + ".conv1.b"],
-                         rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h, splitk_ws=ws, opts=self.opts)
-            if ws is not None and self.fuse_conv_gn and (name + ".conv2.w8") not in P and pad64(Cout) == Cout:
-                # small-batch mode: conv1 (K-split) -> GroupNorm-2 -> SiLU in one call; the GroupNorm kernel sums the K-slices, h is never stored
-                a2 = self._bf("gn.a", B * S, Cout, dev)[0]
-                part = self._buf("gn.part", (B * L.groupnorm_nchunk(S, Cout) * m.out_groups * 2,), torch.float64, dev)
-                kw = dict(ss_scale=emb, ss_shift=emb[:, Cout:], ld_ss=2 * Cout) if ssn else {}
-                L.conv3d_groupnorm_silu(L.igemm(a1, w1, args_only=True, **conv1), P[name + ".gn2.g"], P[name + ".gn2.beta"], part, a2, m.out_groups,
-                                        1e-5, **kw, opts=self._opts_for(B))
-                a2lo, h = None, None
-            else:
-                L.igemm(a1, w1, A_lo=a1lo, W_lo=w1lo, **conv1)
+            L.igemm(a1, w1, A_lo=a1lo, W_lo=w1lo, M=B * S, N=Cout, Cin=ld1, taps=27, w_tap_stride=Cout * ld1, geom=geom,
+                    bias=P[name + ".conv1.b"], rowvec=(emb if (m.use_embed and not ssn) else None), rows_per_sample=S, out_f32=h,
+                    splitk_ws=ws, opts=self.opts)
         ldo = pad64(Cout)
         fp8_2 = (name + ".conv2.w8") in P
-        if h is None:
-            w2, w2lo = P[name + ".conv2.w"]
-        elif fp8_2:
+        if fp8_2:
             a28 = self._gn_fp8(h, P[name + ".gn2.g"], P[name + ".gn2.beta"], B, S, Cout, m.out_groups, "gn.a", dev,
                                ss=(emb if ssn else None))
         else:
