@@ -582,10 +582,15 @@ __global__ void __launch_bounds__(512, NS == 3 ? 4 : 2) attn_block_kernel(const 
       const char* cW = ring(s);
       if (!(p.dbg & 8)) {
         op8 fa[2], fb[2];                       // two-deep fragment pipeline
+        // (row / swizzle terms from the head's opaque lane id: derived from `lane` they are loop invariant, hipcc parks the eight
+        //  fragment addresses in registers across the whole head loop and -- at KT >= 2, where the core needs the registers -- spills
+        //  them: reloads are VMEM loads in front of which the weight DMA queue drains)
+        const int lrow_h = lane_h & 31, lhalf_h = lane_h >> 5, swz_h = (lrow_h >> 1) & 7;
+        const int a_row_h = (wm * 32 + lrow_h) * 128, b_row_h = (wn >> 1) * 8192 + ((wn & 1) * 32 + lrow_h) * 128;
         auto ldp = [&](int kk, int slot) {
-          const int pos = ((kk * 2 + lhalf) ^ swz) * 16;
-          fa[slot] = *(const op8*)(sQ + g2_a_row + pos);
-          fb[slot] = *(const op8*)(cW + g2_b_row + pos);
+          const int pos = ((kk * 2 + lhalf_h) ^ swz_h) * 16;
+          fa[slot] = *(const op8*)(sQ + a_row_h + pos);
+          fb[slot] = *(const op8*)(cW + b_row_h + pos);
         };
         ldp(0, 0);
 #pragma unroll

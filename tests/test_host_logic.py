@@ -129,6 +129,24 @@ def test_packing_layout():
     assert hi.shape == (7, 128) and lo is None
 
 
+def test_built_library_has_no_scratch_kernels():
+    """Every kernel inside the built libprediff_hip.so -- all 236 of both operand builds, not only the pair kernel -- is free of scratch
+    memory and VGPR spills (scripts/check_no_scratch.py reads the code objects bundled in the .so): a spill reload is a VMEM load in
+    front of the counted weight-DMA waits of the fused kernels (attn_block_kernel<256, 2..4> spilled 4-12 registers)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_no_scratch", os.path.join(ROOT, "scripts", "check_no_scratch.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    from prediff_amd import _lib as L
+    ks = m.kernels_of(L.LIB_PATH)
+    assert len(ks) > 100
+    bad = [(k[0], k[1], k[2]) for k in ks if k[1] > 0 or k[2] > 0]
+    assert not bad, bad
+    names = " ".join(k[0] for k in ks)
+    for must in ("attn_block_kernelILi256ELi2", "attn_block_kernelILi256ELi3", "attn_block_kernelILi256ELi4", "pair_kernel", "igemm256_kernel"):
+        assert must in names, must
+
+
 def test_c_abi_exports_every_declared_symbol():
     """libprediff_hip.so loads and exports every function include/prediff_hip.h declares (no GPU needed)."""
     from prediff_amd import _lib as L
