@@ -73,6 +73,23 @@ def v1_model(precision, device, workload="v1"):
     return ldm.to(device).eval()
 
 
+def pair_phases(B, precision):
+    """Attention / FFN phases inside the pair launches at B trajectories: scripts/bench_pair.py phases in a subprocess on the trace build of
+    the library (prediff_amd/libprediff_hip_trace.so: the same sources with the pair kernel's clock stamps compiled in -- the product library
+    carries none).  None when that build is missing or the run fails (the line then has no `phases`)."""
+    import subprocess
+    lib = os.path.join(ROOT, "prediff_amd", "libprediff_hip_trace.so")
+    if not os.path.exists(lib):
+        return None
+    env = dict(os.environ, PD_LIB_PATH=lib, PD_OPERAND=precision)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_pair.py"), str(B), "phases"], env=env, capture_output=True, text=True,
+                           timeout=240)
+        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception:
+        return None
+
+
 def kernel_times(ldm, B, device, reps=3, cond_shape=(7, 16, 16, 64)):
     """Average duration (s) of (a) the Conv3d implicit-GEMM launches, (b) the level-0 (attention, FFN) pair launches (pd_attn_ffn_pair)
     and (c) the round-3 fused attention-block launches (pd_attn_block_fused: what runs when the pair kernel does not -- measured with
@@ -661,6 +678,19 @@ def main():
                     "achieved": round(gf1 / pair512_s / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(gf1 / pair512_s / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(pair512_s * 1e6, 2),
                     "launches_per_step": pair512_launches * S, "gflop_per_launch": round(gf1, 3)}
+        if pair_s and args.config == "v1" and not args.no_extra and n_gpus == 1 and args.precision in ("bf16", "fp16"):
+            ph = pair_phases(Bl, args.precision)
+            if ph is not None:
+                for key, units in (("attention_block", 256), ("attention_block_level1", 512)):
+                    rows = [r for r in ph["layers"] if r["units"] == units]
+                    if key in line and rows:
+                        mean = lambda k: round(sum(r[k] for r in rows) / len(rows), 4)
+                        line[key]["phases"] = {
+                            "what": "the launch split by the kernel's own clock stamps (trace build of the same source, scripts/bench_pair.py phases): "
+                                    "attention = LayerNorm-1 .. proj + residual, ffn = LayerNorm-2 .. FFN-2 + residual; mean over the three axial layers",
+                            "attention_share_of_launch": mean("attention_share"), "ffn_share_of_launch": mean("ffn_share"),
+                            "attention_frac_of_peak": mean("attention_frac_of_peak"), "ffn_frac_of_peak": mean("ffn_frac_of_peak"),
+                            "standalone_launch_us": mean("launch_us"), "per_axis": rows}
         if strong is not None:
             if n_gpus == 1 and "B4" in small and strong["ensemble"] == 32:
                 # what the SAME ensemble would do on 8 GPUs (4 members each): the step loop has no collective, so 8 x the measured

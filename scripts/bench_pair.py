@@ -153,6 +153,56 @@ def trace(B=32):
     print("total", t[n - 1] - t[0])
 
 
+def phases(B=32):
+    """Attention phase and FFN phase INSIDE a pair launch (the trace build: prediff_amd/libprediff_hip_trace.so via PD_LIB_PATH; clock
+    stamps of wave 0 of workgroup 7 at tile start / attention done / FFN done, 24 stamps per tile), for the three axial layers of both
+    levels at B trajectories.  Prints ONE JSON line: per layer the launch time (HIP events, untraced repeats), the share of the
+    workgroup's tile time spent between `tile start` and `attention done` (LayerNorm-1, q/k/v, softmax, P.V, proj, residual) and between
+    `attention done` and `FFN done` (LayerNorm-2, FFN-1, GELU, FFN-2, residual), and what each phase's FLOPs over its share of the launch
+    come to against the 2.5 PFLOP/s peak.  The workgroup is one of a grid of identical ones: its shares are the launch's."""
+    import json
+    out = {"trajectories": B, "layers": []}
+    for Cn, shape in ((256, (13, 16, 16)), (512, (13, 8, 8))):
+        heads, Hd = 4, 4 * Cn
+        ntok = shape[0] * shape[1] * shape[2]
+        g = torch.Generator(device="cpu").manual_seed(Cn)
+        x = torch.randn(B, ntok, Cn, generator=g).to(DEV)
+        r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+        ws = pack_pair_block(r(3 * Cn, Cn, sc=Cn ** -0.5), r(Cn, Cn, sc=Cn ** -0.5), r(Hd, Cn, sc=Cn ** -0.5), r(Cn, Hd, sc=Hd ** -0.5), dtype=ODT)
+        for cuboid in ((shape[0], 1, 1), (1, shape[1], 1), (1, 1, shape[2])):
+            tabs = attention_tables(shape, cuboid, (0, 0, 0), LLL, "zeros")
+            vol, nc = tabs["vol"], tabs["nc"]
+            vecs = pack_pair_vecs(1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), 1 + r(Cn, sc=.1), r(Cn, sc=.1), r(Cn, sc=.1), r(Hd, sc=.1),
+                                  r(heads, vol, vol, sc=.5))
+            tok = tabs["tok_index"].to(DEV)
+            run = lambda o: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, nc, vol, (Cn // heads) ** -0.5, tok_affine=tabs["affine"], units=Cn, opts=o)
+            us = timeit(lambda: run(OPTS))
+            x.normal_()
+            tr = torch.zeros(256, dtype=torch.int64, device=DEV)
+            run(L.CallOpts(os.environ.get("PD_OPERAND", "bf16"), pair_form=OPTS.pair_form, trace=tr.data_ptr()))
+            torch.cuda.synchronize()
+            t = [v for v in tr.cpu().tolist() if v]
+            per = 24                                   # stamps per tile: start, LN1, 4 x (q, k, softmax, PV), attention done, LN2, W1_0, W1_1, FFN loop, FFN done
+            tiles = len(t) // per
+            if tiles == 0 or len(t) % per:
+                raise SystemExit(f"{len(t)} clock stamps (want a multiple of {per}): is PD_LIB_PATH the -DPD_PAIR_DEBUG=1 build (libprediff_hip_trace.so)?")
+            att = sum(t[i * per + 18] - t[i * per] for i in range(tiles))
+            ffn = sum(t[i * per + 23] - t[i * per + 18] for i in range(tiles))
+            gaps = (t[tiles * per - 1] - t[0]) - att - ffn       # between FFN done of a tile and the next tile's start (row stores / loads)
+            sh_a = att / (att + ffn + gaps)
+            sh_f = ffn / (att + ffn + gaps)
+            gf_att = B * ntok * 2.0 * (3 * Cn * Cn + Cn * Cn + 2 * vol * Cn) / 1e9
+            gf_ffn = B * ntok * 2.0 * (2 * Cn * Hd) / 1e9
+            out["layers"].append({"units": Cn, "cuboid": list(cuboid), "launch_us": round(us, 1), "tiles_traced": tiles,
+                                  "ticks_per_tile": round((att + ffn + gaps) / tiles, 1),
+                                  "attention_share": round(sh_a, 4), "ffn_share": round(sh_f, 4),
+                                  "attention_gflop": round(gf_att, 2), "ffn_gflop": round(gf_ffn, 2),
+                                  "attention_frac_of_peak": round(gf_att / (sh_a * us) * 1e3 / 2500, 4),
+                                  "ffn_frac_of_peak": round(gf_ffn / (sh_f * us) * 1e3 / 2500, 4),
+                                  "pair_frac_of_peak": round((gf_att + gf_ffn) / us * 1e3 / 2500, 4)})
+    print(json.dumps(out))
+
+
 def ablate(B=32):
     """Time of the pair launch in whatever library PD_LIB_PATH names (scripts/ablate_pair.sh builds -DPD_PAIR_ABLATE variants);
     PD_BENCH_UNITS=512: the level-1 shapes."""
@@ -181,6 +231,8 @@ if __name__ == "__main__":
         ablate(int(sys.argv[1]))
     elif len(sys.argv) > 2 and sys.argv[2] == "level1":
         level1(int(sys.argv[1]))
+    elif len(sys.argv) > 2 and sys.argv[2] == "phases":
+        phases(int(sys.argv[1]))
     elif len(sys.argv) > 2 and sys.argv[2] == "trace":
         trace(int(sys.argv[1]))
     else:

@@ -1091,6 +1091,7 @@ def test_attn_ffn_pair_split_vs_oracle(name, B, operand):
     1147-1156), against the one-launch kernel (same operands; partial sums instead of one running accumulator: fp32 round-off amplified
     by the 16-bit roundings downstream), in place, twice (bit-equal: the slab sums have a fixed order), and with more tiles than the
     chip has room for four workgroups each (B = 9 at 104 groups per sample: the persistent path)."""
+    from _weights import seeded_input
     from oracle import unet as OU
     from prediff_amd.cuboid_geometry import attention_tables, relative_position_bias
     from prediff_amd.packing import pack_pair_block, pack_pair_ffn_split, pack_pair_vecs
