@@ -684,13 +684,25 @@ def main():
                 for key, units in (("attention_block", 256), ("attention_block_level1", 512)):
                     rows = [r for r in ph["layers"] if r["units"] == units]
                     if key in line and rows:
-                        mean = lambda k: round(sum(r[k] for r in rows) / len(rows), 4)
+                        mean = lambda k: sum(r[k] for r in rows) / len(rows)
+                        sh_a, sh_f = mean("attention_share"), mean("ffn_share")
+                        # FLOPs of the two phases per launch over their share of THIS run's launch time
+                        if units == 256:
+                            gfa, gff = line[key]["gflop_attention_part"], line[key]["gflop_ffn_part"]
+                        else:
+                            gfa = Bl * 832 * (2 * 4 * 512 * 512 + 4 * 10 * 512) / 1e9
+                            gff = Bl * 832 * (2 * 2 * 512 * 2048) / 1e9
+                        us = line[key]["avg_launch_us"]
                         line[key]["phases"] = {
-                            "what": "the launch split by the kernel's own clock stamps (trace build of the same source, scripts/bench_pair.py phases): "
-                                    "attention = LayerNorm-1 .. proj + residual, ffn = LayerNorm-2 .. FFN-2 + residual; mean over the three axial layers",
-                            "attention_share_of_launch": mean("attention_share"), "ffn_share_of_launch": mean("ffn_share"),
-                            "attention_frac_of_peak": mean("attention_frac_of_peak"), "ffn_frac_of_peak": mean("ffn_frac_of_peak"),
-                            "standalone_launch_us": mean("launch_us"), "per_axis": rows}
+                            "what": "the launch split by the kernel's own clock stamps (shares of a workgroup's tile time from the trace build of the same "
+                                    "source, scripts/bench_pair.py phases, mean over the three axial layers; applied to this run's launch time): "
+                                    "attention = LayerNorm-1 .. proj + residual, ffn = LayerNorm-2 .. FFN-2 + residual",
+                            "attention_share_of_launch": round(sh_a, 4), "ffn_share_of_launch": round(sh_f, 4),
+                            "attention_us": round(sh_a * us, 2), "ffn_us": round(sh_f * us, 2),
+                            "attention_gflop": round(gfa, 3), "ffn_gflop": round(gff, 3),
+                            "attention_frac_of_peak": round(gfa / (sh_a * us) * 1e3 / PEAK_BF16_TFLOPS, 4),
+                            "ffn_frac_of_peak": round(gff / (sh_f * us) * 1e3 / PEAK_BF16_TFLOPS, 4),
+                            "trace_build_launch_us": round(mean("launch_us"), 1)}
         if strong is not None:
             if n_gpus == 1 and "B4" in small and strong["ensemble"] == 32:
                 # what the SAME ensemble would do on 8 GPUs (4 members each): the step loop has no collective, so 8 x the measured

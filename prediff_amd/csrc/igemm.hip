@@ -364,11 +364,12 @@ extern "C" int PD_ENTRY(igemm)(const pd_igemm_args* pa, pd_stream_t stream) {
     // long K: the 256 x 256 eight-wave kernel does a round of 256 tiles (one per CU of the MI355X) in ~1.65x the time the
     // 128 x 128 kernel needs for a round of 512 (two per CU) inside the sampling loop -- twice the work; take it when its whole
     // rounds are the cheaper ones (Conv3d at 32 trajectories: 317 us in 2 rounds against 385 us in 4)
-    if (tile == PD_BIG_TILE_DEFAULT && !a.disable_256 && !a.split && (int64_t)a.taps * a.Cin >= min_k_256 && pd_igemm256_supported(a, kind)) {
+    if (tile == PD_BIG_TILE_DEFAULT && !a.disable_256 && (int64_t)a.taps * a.Cin >= min_k_256 && pd_igemm256_supported(a, kind)) {
       const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.nbatch > 0 ? a.nbatch : 1);
       const int64_t ncu = pd_num_cus();
-      const int64_t r128 = (t128 + 2 * ncu - 1) / (2 * ncu), r256 = (t256 + ncu - 1) / ncu;
-      if (r256 * 33 <= r128 * 20) tile = 7;
+      // (the hi/lo form of the 128 x 128 kernel holds 128 KB of LDS: ONE workgroup per CU, a round is 256 tiles)
+      const int64_t r128 = a.split ? (t128 + ncu - 1) / ncu : (t128 + 2 * ncu - 1) / (2 * ncu), r256 = (t256 + ncu - 1) / ncu;
+      if (a.split ? r256 * 11 <= r128 * 5 : r256 * 33 <= r128 * 20) tile = 7;
     }
   }
   if (a.split && tile == 4) tile = 1;   // 3 x 64 KB stages do not fit

@@ -94,10 +94,20 @@ constexpr int KBUF = 4 * HT;    // one K-tile buffer: A half 0, A half 1, W half
 // reads per 16 x 16 tile become the 32 B operand of ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit E8M0 block scales; the tensor
 // scales ride in p.alpha) where bf16 issues two 16x16x32 MFMAs: the same MFMA cycles per K-tile for twice the K.  Both operands
 // use the same (lane, byte) -> k assignment, which is all a dot product needs.
-template <int KIND, int RT, bool SK = false, bool F8 = false>
+// SP: the hi/lo split engine (precision="fp32": x = hi + lo in bfloat16, three products per fragment pair).  A K-tile is still 128 B of every
+// row: 32 elements of the HIGH parts (16-B slots 0-3) followed by the same 32 elements of the LOW parts (slots 4-7), fetched by ONE DMA
+// instruction from the two arrays -- hi and lo behind one buffer descriptor, the lane's offset picks the array (the engine allocates the
+// two halves of an operand in one tensor; the launcher checks that they are less than 4 GB apart).  The fragment reads are unchanged: the
+// "first k-step" registers hold the high parts, the "second k-step" registers the low parts, and a K-tile is  acc += lo.hi; acc += hi.lo;
+// acc += hi.hi  per accumulator -- the products, their order and the 32-deep k-steps of igemm_kernel<.., SPLIT = true>, so the two
+// kernels give the SAME bits (the fp32-class engine stays bit-identical across batch sizes whichever kernel a launch size selects).
+// Same DMA bytes and LDS reads per K-tile as the bf16 kernel for 24 instead of 16 MFMAs per phase.
+template <int KIND, int RT, bool SK = false, bool F8 = false, bool SP = false>
 __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
+  static_assert(!SP || (!SK && !F8), "the hi/lo form: bf16 operands, no K-slices");
   constexpr uint32_t EB = F8 ? 1u : 2u;           // bytes per operand element
-  constexpr int KSH = F8 ? 7 : 6;                 // log2(elements per 128 B K-tile row)
+  constexpr int KSH = F8 ? 7 : SP ? 5 : 6;        // log2(elements per 128 B K-tile row)
+  constexpr uint32_t KB = SP ? 64u : 128u;        // bytes of ONE source array per K-tile row
   constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
   constexpr int ROW1 = BM - 16 * RT;              // first tile row of wave row 1 (128 for RT = 8, 96 for RT = 7)
   constexpr int RA0 = 4, RA1 = RT - 4;            // row tiles of the two A sub-halves
@@ -121,12 +131,24 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   const int n0 = (t % tiles_n) << 8;
   const int bz = blockIdx.z;
 
-  const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (int64_t)bz * p.a_batch_stride * EB), 0, p.a_bytes, 0x00020000);
-  const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + (int64_t)bz * p.w_batch_stride * EB), 0, p.w_bytes, 0x00020000);
+  // SP: one descriptor over [min(hi, lo), max(hi, lo) + bytes); a_sel / w_sel = this lane's array offset + 16-B slot inside the array's 64 B
+  const char* a_lo_p = SP ? (const char*)p.A_lo : (const char*)p.A;
+  const char* w_lo_p = SP ? (const char*)p.W_lo : (const char*)p.W;
+  const char* a_base = (const char*)p.A < a_lo_p ? (const char*)p.A : a_lo_p;
+  const char* w_base = (const char*)p.W < w_lo_p ? (const char*)p.W : w_lo_p;
+  const uint32_t a_span = (uint32_t)(((const char*)p.A < a_lo_p ? a_lo_p - (const char*)p.A : (const char*)p.A - a_lo_p));
+  const uint32_t w_span = (uint32_t)(((const char*)p.W < w_lo_p ? w_lo_p - (const char*)p.W : (const char*)p.W - w_lo_p));
+  const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a_base + (int64_t)bz * p.a_batch_stride * EB), 0, p.a_bytes + a_span, 0x00020000);
+  const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)(w_base + (int64_t)bz * p.w_batch_stride * EB), 0, p.w_bytes + w_span, 0x00020000);
 
   // ---- staging: one DMA instruction covers 64 rows x 128 B; thread -> (row tid/8, 16 B slot tid%8), swizzled source chunk ----
   const int srow = tid >> 3, spos = tid & 7;
   const int schunk = spos ^ ((srow >> 1) & 7);
+  // byte offset of this lane's 16-B slot inside a K-tile row of the source: plain = slot * 16; SP = the array (hi: slots 0-3, lo: 4-7) + slot % 4
+  const uint32_t a_sel = !SP ? (uint32_t)schunk * 16u
+                             : (uint32_t)(schunk & 3) * 16u + (uint32_t)(((schunk & 4) ? a_lo_p : (const char*)p.A) - a_base);
+  const uint32_t w_sel = !SP ? (uint32_t)schunk * 16u
+                             : (uint32_t)(schunk & 3) * 16u + (uint32_t)(((schunk & 4) ? w_lo_p : (const char*)p.W) - w_base);
   uint32_t aoff[2][2];    // [half][i]  byte offset of (row, current tap, chunk) or PD_OOB
   uint32_t acoord[2][2];  // KIND 2: ot | oh << 10 | ow << 20 | invalid << 31
   uint32_t abase[2][2];   // KIND 2: first input row of the row's sample
@@ -138,7 +160,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
       const int m = m0 + hh * ROW1 + rloc;
       const bool ok = m < p.M && rloc < 16 * RT && m < m0 + BM;
       if (KIND == 0) {
-        aoff[hh][i] = ok ? ((uint32_t)m * (uint32_t)p.lda) * EB + schunk * 16 : PD_OOB;
+        aoff[hh][i] = ok ? ((uint32_t)m * (uint32_t)p.lda) * EB + a_sel : PD_OOB;
       } else {
         const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
         const int mm = ok ? m : 0;
@@ -156,7 +178,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int n = n0 + hh * 128 + i * 64 + srow;
-      woff[hh][i] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldw) * EB + schunk * 16 : PD_OOB;
+      woff[hh][i] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldw) * EB + w_sel : PD_OOB;
     }
   const int kchunks = p.Cin >> KSH;
   const int khw = p.KH * p.KW;
@@ -190,7 +212,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
       const uint32_t c = acoord[hh][i];
       const int vt = (int)(c & 1023u) - p.pt + kt, vh = (int)((c >> 10) & 1023u) - p.ph + kh, vw = (int)((c >> 20) & 1023u) - p.pw + kw;
       const bool ok = !(c >> 31) && (unsigned)vt < (unsigned)p.Ti && (unsigned)vh < (unsigned)p.Hi && (unsigned)vw < (unsigned)p.Wi;
-      aoff[hh][i] = ok ? ((abase[hh][i] + (uint32_t)((vt * p.Hi + vh) * p.Wi + vw)) * (uint32_t)p.lda) * EB + schunk * 16 : PD_OOB;
+      aoff[hh][i] = ok ? ((abase[hh][i] + (uint32_t)((vt * p.Hi + vh) * p.Wi + vw)) * (uint32_t)p.lda) * EB + a_sel : PD_OOB;
     }
   };
   // K-tile counters of the DMA streams (A runs one K-tile ahead of the MFMAs, W two); all wave-uniform scalars
@@ -205,7 +227,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   }
   auto issue_a = [&](int hh, int buf) {    // A half hh of the A stream's current K-tile
     if (KIND != 0 && a_kc == 0) set_tap(hh, a_tap);
-    const int ka = __builtin_amdgcn_readfirstlane(a_kc * 128);
+    const int ka = __builtin_amdgcn_readfirstlane(a_kc * (int)KB);
     char* dst = dma_dst + buf * KBUF + hh * HT;
     BLDS16(rA, dst, aoff[hh][0], ka);
     BLDS16(rA, dst + 64 * 128, aoff[hh][1], ka);
@@ -217,7 +239,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     }
   };
   auto issue_w = [&](int buf) {            // both W halves of the W stream's current K-tile
-    const int kw = __builtin_amdgcn_readfirstlane((int)(w_tap_b + (uint32_t)w_kc * 128u));
+    const int kw = __builtin_amdgcn_readfirstlane((int)(w_tap_b + (uint32_t)w_kc * KB));
     char* dst = dma_dst + buf * KBUF + 2 * HT;
     BLDS16(rW, dst, woff[0][0], kw);
     BLDS16(rW, dst + 64 * 128, woff[0][1], kw);
@@ -271,6 +293,13 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     /* calls of phases 0-2 past the barriers into phase 3 and the wave rows stop alternating (measured: 1.4x -> see DESIGN) */ \
     _Pragma("unroll") for (int i = 0; i < (NR); ++i)                                                                      \
       _Pragma("unroll") for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(acc[(R0) + i][(C0) + c]));                     \
+  } else if constexpr (SP) {                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < (NR); ++i)                                                                      \
+      _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                                     \
+        acc[(R0) + i][(C0) + c] = mfma_16x16x32(a[i].v[1], bfrag[c].v[0], acc[(R0) + i][(C0) + c]);   /* lo . hi */        \
+        acc[(R0) + i][(C0) + c] = mfma_16x16x32(a[i].v[0], bfrag[c].v[1], acc[(R0) + i][(C0) + c]);   /* hi . lo */        \
+        acc[(R0) + i][(C0) + c] = mfma_16x16x32(a[i].v[0], bfrag[c].v[0], acc[(R0) + i][(C0) + c]);   /* hi . hi */        \
+      }                                                                                                                   \
   } else {                                                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                      \
       _Pragma("unroll") for (int i = 0; i < (NR); ++i)                                                                    \
@@ -460,14 +489,14 @@ int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s) {
   return kind == 0 ? launch256_splitk<0>(a, s) : launch256_splitk<2>(a, s);
 }
 
-template <int KIND, int RT, bool F8 = false>
+template <int KIND, int RT, bool F8 = false, bool SP = false>
 static int launch256(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
   constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT, false, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT, false, F8, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -476,14 +505,24 @@ static int launch256(const pd_igemm_args& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + 255) / 256);
   dim3 grid(tiles, 1, a.nbatch > 0 ? a.nbatch : 1);
-  hipLaunchKernelGGL((igemm256_kernel<KIND, RT, false, F8>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((igemm256_kernel<KIND, RT, false, F8, SP>), grid, dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
 
 // true when the 256-tile kernel can run this (already validated) launch
 bool pd_igemm256_supported(const pd_igemm_args& a, int kind) {
-  if (a.split) return false;
+  if (a.split) {
+    // the hi/lo form: both halves of an operand behind ONE buffer descriptor (bf16 build only; the engine allocates them in one tensor)
+#if PD_IS_F16
+    return false;
+#else
+    if (a.fp8 || a.nbatch > 1 || !a.A_lo || !a.W_lo) return false;
+    const int64_t da = (const char*)a.A_lo - (const char*)a.A, dw = (const char*)a.W_lo - (const char*)a.W;
+    if ((da < 0 ? -da : da) + (int64_t)a.a_bytes >= 0xfffffe00ll || (dw < 0 ? -dw : dw) + (int64_t)a.w_bytes >= 0xfffffe00ll) return false;
+    if ((da | dw) & 15) return false;
+#endif
+  }
   if (kind == 0) return true;
   return a.st == 1 && a.sh == 1 && a.sw == 1 && a.ut == 1 && a.uh == 1 && a.uw == 1 && a.vT <= 0 && a.vH <= 0 && a.vW <= 0 &&
          a.To < 1024 && a.Ho < 1024 && a.Wo < 1024;
@@ -491,6 +530,7 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind) {
 
 int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s) {
 #if !PD_IS_F16
+  if (a.split) return kind == 0 ? launch256<0, 8, false, true>(a, s) : launch256<2, 8, false, true>(a, s);
   if (a.fp8) return kind == 0 ? launch256<0, 8, true>(a, s) : launch256<2, 8, true>(a, s);
 #endif
   return kind == 0 ? launch256<0, 8>(a, s) : launch256<2, 8>(a, s);

@@ -656,9 +656,10 @@ class CuboidTransformerUNet(nn.Module):
 
     def _bf(self, name, rows, cols, device):
         """bf16 operand buffer pair (hi, lo-or-None)."""
-        hi = self._buf(name, (rows, cols), self.op_dtype, device)
-        lo = self._buf(name + ".lo", (rows, cols), torch.bfloat16, device) if self.precision == "fp32" else None
-        return hi, lo
+        if self.precision == "fp32":      # both halves in one allocation: the 256 x 256 hi/lo kernel reads them through one buffer descriptor
+            both = self._buf(name + ".hilo", (2, rows, cols), torch.bfloat16, device)
+            return both[0], both[1]
+        return self._buf(name, (rows, cols), self.op_dtype, device), None
 
     # ------------------------------------------------------------------------------------------------ building blocks
     FP8_ACT_SCALE = 16.0      # GroupNorm -> SiLU outputs are O(1): x16 keeps |y| < 28 in range and 1e-3 above the subnormals

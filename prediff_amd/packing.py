@@ -29,8 +29,13 @@ def split_bf16(x: torch.Tensor, want_lo: bool, dtype=torch.bfloat16) -> Tuple[to
     if want_lo and dtype != torch.bfloat16:
         raise ValueError("the hi/lo split exists for bfloat16 operands only")
     hi = to_operand(x, dtype)
-    lo = (x - hi.float()).to(torch.bfloat16) if want_lo else None
-    return hi.contiguous(), (lo.contiguous() if lo is not None else None)
+    if not want_lo:
+        return hi.contiguous(), None
+    # both halves in ONE allocation (hi = both[0], lo = both[1]): the 256 x 256 hi/lo kernel reads them through one buffer descriptor
+    both = torch.empty((2,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    both[0].copy_(hi)
+    both[1].copy_((x - hi.float()).to(torch.bfloat16))
+    return both[0], both[1]
 
 
 def pack_linear(weight: torch.Tensor, split: bool, k_pad: Optional[int] = None, dtype=torch.bfloat16):

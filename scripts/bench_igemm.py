@@ -17,6 +17,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--tile", type=int, default=0)
 ap.add_argument("--debug", type=int, default=0)
+ap.add_argument("--split", action="store_true", help="hi/lo split operands (the precision=\"fp32\" engine): 3 products per fragment pair")
 args = ap.parse_args()
 B = args.batch
 dev = "cuda"
@@ -31,6 +32,13 @@ def run(name, M, N, K, taps=1, geom=None, out_bf16=False, act="none", residual=F
     ob = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if out_bf16 else None
     res = torch.randn(M, N, device=dev) if residual else None
     kw = dict(M=M, N=N, Cin=Kp, taps=taps, w_tap_stride=N * Kp, geom=geom, bias=bias, act=act, residual=res, out_f32=of, out_bf16=ob, tile=args.tile, debug_flags=args.debug)
+    if args.split:        # both halves of an operand in one allocation, as the engine keeps them
+        a2, w2 = torch.empty((2,) + tuple(a.shape), dtype=torch.bfloat16, device=dev), torch.empty((2,) + tuple(w.shape), dtype=torch.bfloat16, device=dev)
+        a2[0].copy_(a); a2[1].copy_(a * 0.004); w2[0].copy_(w); w2[1].copy_(w * 0.004)
+        a, w = a2[0], w2[0]
+        kw.update(A_lo=a2[1], W_lo=w2[1])
+        if ob is not None:
+            kw.update(out_bf16_lo=torch.empty_like(ob))
     for _ in range(3):
         L.igemm(a, w, **kw)
     torch.cuda.synchronize()

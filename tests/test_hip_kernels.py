@@ -121,6 +121,63 @@ def test_igemm_conv3d(B, T, H, W, Cin, Cout, split, tile):
     assert rel_l2(out, ref) < (3e-5 if split else 3e-6)
 
 
+@pytest.mark.parametrize("kind,shape", [("conv3d", (2, 13, 16, 16, 256, 256)), ("conv3d", (3, 13, 8, 8, 512, 512)), ("conv3d", (2, 5, 7, 9, 64, 192)),
+                                        ("linear", (3328, 256, 1024)), ("linear", (1000, 300, 2048)), ("linear", (257, 512, 64))])
+def test_igemm256_hi_lo_bit_equal_to_128(kind, shape):
+    """The hi/lo (precision="fp32") form of the 256 x 256 kernel -- a K-tile of 32 high + 32 low elements per row from the two operand arrays
+    through one buffer descriptor, lo.hi + hi.lo + hi.hi per accumulator -- against the 128 x 128 SPLIT kernel: the same products in the
+    same order over the same 32-deep k-steps, so the SAME BITS (the fp32-class engine stays batch-size independent whichever kernel a
+    launch size selects); against torch fp32; with all epilogue operands (bias, per-sample row vector, residual, hi/lo 16-bit output);
+    and operands whose halves are NOT one allocation (far apart or merely separate): tile 7 falls back to the 128 x 128 kernel."""
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    if kind == "conv3d":
+        B, T, H, W, Cin, Cout = shape
+        x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).to(DEV)
+        M, N = B * T * H * W, Cout
+        a_hi, a_lo = padded_bf16(x.reshape(-1, Cin), True)
+        w_hi, w_lo = pack_conv(w, True)
+        Cp = a_hi.shape[1]
+        kw = dict(M=M, N=N, Cin=Cp, taps=27, w_tap_stride=Cout * Cp, geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), rows_per_sample=T * H * W)
+        emb = torch.randn(B, N, generator=g).to(DEV)
+        ref = F.conv3d(x.permute(0, 4, 1, 2, 3), w, None, padding=1).permute(0, 2, 3, 4, 1).reshape(M, N) + emb.repeat_interleave(T * H * W, 0)
+    else:
+        M, N, K = shape
+        x = torch.randn(M, K, generator=g).to(DEV)
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+        a_hi, a_lo = padded_bf16(x, True)
+        w_hi, w_lo = pack_linear(w, True)
+        kw = dict(M=M, N=N, Cin=a_hi.shape[1], rows_per_sample=M)
+        emb = torch.randn(1, N, generator=g).to(DEV)
+        ref = x @ w.t() + emb
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    ref = ref + bias + res
+    outs = {}
+    for tile in (1, 7):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        ob = torch.full((2, M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        L.igemm(a_hi, w_hi, A_lo=a_lo, W_lo=w_lo, bias=bias, rowvec=emb, residual=res, out_f32=out, out_bf16=ob[0], out_bf16_lo=ob[1], tile=tile, **kw)
+        torch.cuda.synchronize()
+        outs[tile] = (out, ob.clone())
+    assert rel_l2(outs[7][0], ref) < 3e-5
+    assert torch.equal(outs[1][0], outs[7][0]) and torch.equal(outs[1][1], outs[7][1])
+    assert rel_l2(outs[7][1][0].float() + outs[7][1][1].float(), ref) < 3e-5
+    # halves in separate allocations: still right (whichever kernel the library picks for them)
+    a_lo2, w_lo2 = a_lo.clone(), w_lo.clone()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    L.igemm(a_hi, w_hi, A_lo=a_lo2, W_lo=w_lo2, bias=bias, rowvec=emb, residual=res, out_f32=out, tile=7, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, outs[1][0])
+    # lo BELOW hi in memory (the descriptor starts at the lower of the two)
+    both = torch.empty((2,) + tuple(a_hi.shape), dtype=torch.bfloat16, device=DEV)
+    both[1].copy_(a_hi); both[0].copy_(a_lo)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    L.igemm(both[1], w_hi, A_lo=both[0], W_lo=w_lo, bias=bias, rowvec=emb, residual=res, out_f32=out, tile=7, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, outs[1][0])
+
+
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout,fp8", [(2, 13, 16, 16, 256, 256, False), (3, 4, 16, 16, 128, 256, False), (1, 13, 32, 16, 256, 256, False),
                                                   (2, 13, 16, 16, 256, 256, True)])
 def test_igemm_conv3d_tap_skip_equals_dense(B, T, H, W, Cin, Cout, fp8):
