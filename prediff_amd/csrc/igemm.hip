@@ -289,7 +289,9 @@ extern "C" int PD_ENTRY(igemm)(const pd_igemm_args* pa, pd_stream_t stream) {
   pd_igemm_args a = *pa;
   PD_CHECK_ARG(!PD_IS_F16 || (!a.split && !a.fp8 && !a.out_bf16_lo), "pd_igemm: IEEE-half operands: no hi/lo split, no e4m3 operands");
   // A/B switches of the caller (0 = the defaults)
-  const int min_k_256 = a.min_k_256 > 0 ? a.min_k_256 : 1024;   // shortest K (taps * Cin) the automatic choice gives to the 256 x 256 kernel (512 wins
+  // hi/lo launches carry 1.5x the MFMA work per operand byte: the 256 x 256 form wins from K = 256 on (v1, 64 trajectories, precision="fp32":
+  // 397 / 431 / 478 steps/s with 1024 / 512 / 256 -- profiles/r05_e_*)
+  const int min_k_256 = a.min_k_256 > 0 ? a.min_k_256 : a.split ? 256 : 1024;   // shortest K (taps * Cin) the automatic choice gives to the 256 x 256 kernel (512 wins
                                                                 // 25 % on stand-alone full-resolution level-1 launches and nothing end to end, two lanes running)
   PD_CHECK_ARG(a.A && a.W, "pd_igemm: A/W null");
   PD_CHECK_ARG(a.M > 0 && a.N > 0 && a.taps > 0, "pd_igemm: bad M/N/taps (%d,%d,%d)", a.M, a.N, a.taps);
