@@ -81,8 +81,10 @@ class _HipConv3d(torch.autograd.Function):
         M = B * T * H * W
         Cp = pad64(Cn)
         rows = x_ncthw.permute(0, 2, 3, 4, 1).reshape(M, Cn).float().contiguous()
-        a_hi = torch.empty((M, Cp), dtype=torch.bfloat16, device=rows.device)
-        a_lo = torch.empty_like(a_hi) if w_lo is not None else None       # the activation is split exactly when the filter is
+        # (the activation is split exactly when the filter is; both halves in one allocation: the 256 x 256 hi/lo kernel reads them
+        #  through one buffer descriptor)
+        a_both = torch.empty((2 if w_lo is not None else 1, M, Cp), dtype=torch.bfloat16, device=rows.device)
+        a_hi, a_lo = a_both[0], (a_both[1] if w_lo is not None else None)
         out = torch.empty((M, n_out), dtype=torch.float32, device=rows.device)
         with L.on_device(rows):
             L.cast_rows(rows, a_hi, a_lo, 1, M, 0, M, Cn, Cn, Cp)          # fp32 -> bf16 hi [+ lo], zero-padded columns, one pass
@@ -130,8 +132,8 @@ class _HipGnSiluConv3d(torch.autograd.Function):
         x = x.contiguous()
         dev = x.device
         part = torch.empty(B * L.groupnorm_nchunk(S, Cn) * G * 2, dtype=torch.float64, device=dev)
-        a_hi = torch.empty((M, Cn), dtype=torch.bfloat16, device=dev)
-        a_lo = torch.empty_like(a_hi) if fwd[1] is not None else None
+        a_both = torch.empty((2 if fwd[1] is not None else 1, M, Cn), dtype=torch.bfloat16, device=dev)
+        a_hi, a_lo = a_both[0], (a_both[1] if fwd[1] is not None else None)
         out = torch.empty((B, T, H, W, N), dtype=torch.float32, device=dev)
         with L.on_device(x):
             L.groupnorm_silu(x, gn.weight, gn.bias, part, a_hi, a_lo, B, S, Cn, G, Cn, gn.eps, silu=True)
@@ -150,8 +152,8 @@ class _HipGnSiluConv3d(torch.autograd.Function):
         S, M = T * H * W, B * T * H * W
         d_out = d_out.contiguous()
         dev = x.device
-        g_hi = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        g_lo = torch.empty_like(g_hi) if ctx.bwd[1] is not None else None
+        g_both = torch.empty((2 if ctx.bwd[1] is not None else 1, M, N), dtype=torch.bfloat16, device=dev)
+        g_hi, g_lo = g_both[0], (g_both[1] if ctx.bwd[1] is not None else None)
         da = torch.empty((M, Cn), dtype=torch.float32, device=dev)
         dx = torch.empty_like(x)
         part_b = torch.empty_like(part)

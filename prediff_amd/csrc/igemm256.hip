@@ -102,7 +102,12 @@ constexpr int KBUF = 4 * HT;    // one K-tile buffer: A half 0, A half 1, W half
 // acc += hi.hi  per accumulator -- the products, their order and the 32-deep k-steps of igemm_kernel<.., SPLIT = true>, so the two
 // kernels give the SAME bits (the fp32-class engine stays bit-identical across batch sizes whichever kernel a launch size selects).
 // Same DMA bytes and LDS reads per K-tile as the bf16 kernel for 24 instead of 16 MFMAs per phase.
-template <int KIND, int RT, bool SK = false, bool F8 = false, bool SP = false>
+// P2 (default since round 5; debug_flags bit 64 = the four-phase form of rounds 2-4 for A/B): a K-tile in TWO phases of 32 MFMAs (quadrants
+// (A0, W0) + (A0, W1), then (A1, W1) + (A1, W0)) instead of four of 16 -- the same fragments, registers, DMA schedule and hazards, the same
+// products in the same order per accumulator (bit-identical), half the barriers.  Measured at 32 trajectories, interleaved on one box
+// (profiles/r05_g_two_phase_ab.txt): Conv3d level 0 392 / 401 -> 385 / 377 us, level 1 320 / 325 -> 311 / 310 us, 4096^3 GEMM 108.4 -> 105.6 us,
+// headline 1532 -> 1555 steps/s.
+template <int KIND, int RT, bool SK = false, bool F8 = false, bool SP = false, bool P2 = true>
 __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   static_assert(!SP || (!SK && !F8), "the hi/lo form: bf16 operands, no K-slices");
   constexpr uint32_t EB = F8 ? 1u : 2u;           // bytes per operand element
@@ -312,6 +317,38 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     const char* sB = smem + cur * KBUF + b_rd;
     const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
 
+    if constexpr (P2) {
+      // ---------- phase A: all four W column tiles, A row tiles 0-3; quadrants (A0, W0), (A0, W1); A of kt+1 ----------
+#pragma unroll
+      for (int c = 0; c < 2; ++c) b0[c].load(sB + c * (16 * 128), lg, swz);
+#pragma unroll
+      for (int i = 0; i < RA0; ++i) a[i].load(sA + i * (16 * 128), lg, swz);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) b1[c].load(sB + (2 + c) * (16 * 128), lg, swz);
+      if (more1) { issue_a(0, cur ^ 1); issue_a(1, cur ^ 1); next_a(); }
+      PHASE_SYNC();
+      __builtin_amdgcn_s_setprio(1);
+      QUAD16(RA0, 0, 0, b0)
+      QUAD16(RA0, 0, 2, b1)
+      __builtin_amdgcn_s_setprio(0);
+      PHASE_SYNC();
+      // ---------- phase B: A row tiles 4 .. RT-1; quadrants (A1, W1), (A1, W0); W of kt+2; wait for kt+1 ----------
+#pragma unroll
+      for (int i = 0; i < RA1; ++i) a[i].load(sA + (RA0 + i) * (16 * 128), lg, swz);
+      if (more2) {
+        issue_w(cur);
+        VMCNT(4);
+      } else {
+        VMCNT(0);
+      }
+      PHASE_SYNC();
+      __builtin_amdgcn_s_setprio(1);
+      QUAD16(RA1, RA0, 2, b1)
+      QUAD16(RA1, RA0, 0, b0)
+      __builtin_amdgcn_s_setprio(0);
+      PHASE_SYNC();
+      continue;
+    }
     // ---------- phase 0: W column tiles 0-1, A row tiles 0-3; quadrant (A0, W0) ----------
 #pragma unroll
     for (int c = 0; c < 2; ++c) b0[c].load(sB + c * (16 * 128), lg, swz);
@@ -489,14 +526,14 @@ int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s) {
   return kind == 0 ? launch256_splitk<0>(a, s) : launch256_splitk<2>(a, s);
 }
 
-template <int KIND, int RT, bool F8 = false, bool SP = false>
+template <int KIND, int RT, bool F8 = false, bool SP = false, bool P2 = true>
 static int launch256(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
   constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT, false, F8, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT, false, F8, SP, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -505,7 +542,7 @@ static int launch256(const pd_igemm_args& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + 255) / 256);
   dim3 grid(tiles, 1, a.nbatch > 0 ? a.nbatch : 1);
-  hipLaunchKernelGGL((igemm256_kernel<KIND, RT, false, F8, SP>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((igemm256_kernel<KIND, RT, false, F8, SP, P2>), grid, dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -533,6 +570,7 @@ int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s) {
   if (a.split) return kind == 0 ? launch256<0, 8, false, true>(a, s) : launch256<2, 8, false, true>(a, s);
   if (a.fp8) return kind == 0 ? launch256<0, 8, true>(a, s) : launch256<2, 8, true>(a, s);
 #endif
+  if (a.debug_flags & 64) return kind == 0 ? launch256<0, 8, false, false, false>(a, s) : launch256<2, 8, false, false, false>(a, s);   // (A/B: four phases)
   return kind == 0 ? launch256<0, 8>(a, s) : launch256<2, 8>(a, s);
 }
 
