@@ -568,6 +568,7 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind) {
 int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s) {
 #if !PD_IS_F16
   if (a.split) return kind == 0 ? launch256<0, 8, false, true>(a, s) : launch256<2, 8, false, true>(a, s);
+  if (a.fp8 && (a.debug_flags & 64)) return kind == 0 ? launch256<0, 8, true, false, false>(a, s) : launch256<2, 8, true, false, false>(a, s);
   if (a.fp8) return kind == 0 ? launch256<0, 8, true>(a, s) : launch256<2, 8, true>(a, s);
 #endif
   if (a.debug_flags & 64) return kind == 0 ? launch256<0, 8, false, false, false>(a, s) : launch256<2, 8, false, false, false>(a, s);   // (A/B: four phases)

@@ -6,6 +6,7 @@ from prediff_amd import _lib as L
 from prediff_amd.packing import pack_conv, pack_conv_fp8, pack_linear, pack_linear_fp8, split_bf16, to_fp8
 
 dev = torch.device("cuda")
+DBG = int(os.environ.get("PD_IGEMM_DEBUG", "0"))      # OR-ed into debug_flags (64: the four-phase K-tile of rounds 2-4)
 
 
 def timed(fn, n=20):
@@ -27,8 +28,8 @@ def conv(B, T, H, W, Cin, Cout):
     a16, _ = split_bf16(x, False); w16, _ = pack_conv(w, False)
     a8 = to_fp8(x, 16.0); w8, sw = pack_conv_fp8(w)
     out = torch.empty(M, Cout, device=dev)
-    t16 = timed(lambda: L.igemm(a16, w16, M=M, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, out_f32=out, tile=7))
-    t8 = timed(lambda: L.igemm(a8, w8, M=M, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, out_f32=out, alpha=1 / (16 * sw), fp8=True))
+    t16 = timed(lambda: L.igemm(a16, w16, M=M, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, out_f32=out, tile=7, debug_flags=DBG))
+    t8 = timed(lambda: L.igemm(a8, w8, M=M, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=geom, out_f32=out, alpha=1 / (16 * sw), fp8=True, debug_flags=DBG))
     gf = 2.0 * M * Cout * Cin * 27 / 1e9
     print(f"conv3d B={B} ({T},{H},{W}) {Cin}->{Cout}: M={M}  bf16 {t16:8.1f} us ({gf / t16:6.3f} PF/s)   fp8 {t8:8.1f} us ({gf / t8:6.3f} PF/s)   x{t16 / t8:.2f}", flush=True)
 
@@ -38,9 +39,9 @@ def linear(M, N, K):
     a16, _ = split_bf16(x, False); w16, _ = pack_linear(w, False)
     a8 = to_fp8(x, 16.0); w8, sw = pack_linear_fp8(w)
     out = torch.empty(M, N, device=dev)
-    t16 = timed(lambda: L.igemm(a16, w16, M=M, N=N, Cin=K, out_f32=out, tile=7))
+    t16 = timed(lambda: L.igemm(a16, w16, M=M, N=N, Cin=K, out_f32=out, tile=7, debug_flags=DBG))
     tauto = timed(lambda: L.igemm(a16, w16, M=M, N=N, Cin=K, out_f32=out))
-    t8 = timed(lambda: L.igemm(a8, w8, M=M, N=N, Cin=K, out_f32=out, alpha=1 / (16 * sw), fp8=True))
+    t8 = timed(lambda: L.igemm(a8, w8, M=M, N=N, Cin=K, out_f32=out, alpha=1 / (16 * sw), fp8=True, debug_flags=DBG))
     gf = 2.0 * M * N * K / 1e9
     print(f"linear {M}x{N}x{K}: bf16 256-tile {t16:8.1f} us ({gf / t16:6.3f} PF/s), auto tile {tauto:8.1f} us   fp8 {t8:8.1f} us ({gf / t8:6.3f} PF/s)   "
           f"x{min(t16, tauto) / t8:.2f} vs the better bf16", flush=True)
