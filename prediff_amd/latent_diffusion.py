@@ -133,7 +133,12 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
             self.make_cond_schedule()
         self.cond_stage_trainable = False
         self.scale_by_std = scale_by_std
-        self.scale_factor = float(scale_factor)
+        if not scale_by_std:
+            self.scale_factor = float(scale_factor)
+        else:
+            # a persistent buffer, as in the reference (latent_diffusion.py:160-164): a checkpoint written with scale_by_std=True carries
+            # "scale_factor" and has to load with strict=True.  (The std-rescaling of the very first training batch, :301-317, is training-side.)
+            self.register_buffer("scale_factor", torch.tensor(float(scale_factor)))
         self.alignment_fn: Optional[Callable] = None
         self.instantiate_first_stage(first_stage_model)
         self.instantiate_cond_stage(cond_stage_model, cond_stage_forward)

@@ -13,6 +13,12 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 x = torch.rand(7 * T, 1, 128, 128, device=dev)
 z = torch.randn(6 * T, 64, 16, 16, device=dev)
 res = {}
+if os.environ.get("VAE_FUSED_ONLY"):          # for rocprofv3: the production path alone, three passes each
+    with torch.no_grad():
+        for _ in range(3):
+            vae.encode(x).mode(); vae.decode(z)
+    torch.cuda.synchronize()
+    sys.exit(0)
 with torch.no_grad():
     outs = {}
     for fused in (True, False):

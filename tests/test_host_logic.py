@@ -319,3 +319,26 @@ def test_product_cond_schedule_vs_reference_golden():
             g = np.load(os.path.join(ROOT, "tests", "golden", "cond_schedule.npz"))
             assert ldm.cond_ids.dtype == torch.long and np.array_equal(ldm.cond_ids.numpy(), g["cond_ids"])
             assert "cond_ids" in ldm.state_dict()           # a registered buffer, as in the reference
+
+
+def test_scale_by_std_registers_the_reference_buffer():
+    """scale_by_std=True keeps `scale_factor` as a persistent buffer (reference latent_diffusion.py:160-164), so a checkpoint written by the
+    reference with that option strict-loads; without it `scale_factor` is a plain attribute and not in the state_dict."""
+    import torch
+    from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
+    from prediff_amd.latent_diffusion import LatentDiffusion
+    from _cases import TINY_UNET_CFGS
+    cfg = TINY_UNET_CFGS["axial"]
+    net = CuboidTransformerUNet(**cfg, precision="fp32")
+    kw = dict(torch_nn_module=net, layout="NTHWC", data_shape=(2, 32, 32, 1), timesteps=1000, use_ema=False,
+              latent_shape=tuple(cfg["target_shape"]), first_stage_model=None, cond_stage_model=None)
+    a = LatentDiffusion(**kw, scale_by_std=True, scale_factor=1.0)
+    b = LatentDiffusion(**kw, scale_by_std=False, scale_factor=0.18215)
+    assert "scale_factor" in a.state_dict() and a.state_dict()["scale_factor"].shape == ()
+    assert "scale_factor" not in b.state_dict() and b.scale_factor == 0.18215
+    sd = a.state_dict()
+    sd["scale_factor"] = torch.tensor(0.25)                # what the reference stores after its first training batch
+    a.load_state_dict(sd, strict=True)
+    assert float(a.scale_factor) == 0.25
+    z = torch.ones(2, 3)
+    assert torch.equal(a.get_first_stage_encoding(z), 0.25 * z)
