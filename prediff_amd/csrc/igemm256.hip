@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   // so 2 of 13 tiles drop 9 of their 27 taps -- the zero-padding taps are left out of both DMA streams and of the MFMA loop instead of
   // being streamed as zero rows (bit `tap` of tap_skip; debug_flags bit 8 keeps the dense loop for A/B runs).
   uint32_t tap_skip = 0;
-  if (KIND == 2 && !SK && p.KT > 1 && p.taps < 32 && khw < 32 && !(p.debug_flags & 8)) {   // (< 32: `tap_skip >> taps` stays a defined shift)
+  if (KIND == 2 && !SK && p.KT > 1 && p.ut == 1 && p.vT <= 0 && p.taps < 32 && khw < 32 && !(p.debug_flags & 8)) {   // (< 32: `tap_skip >> taps` stays a defined shift)
     const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
     const int m_last = min(p.M, m0 + BM) - 1;
     const int b_first = m0 / thw_o;
@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   const int nk = (p.debug_flags & 1) ? 0 : SK ? (int)((int64_t)nk_all * (kslice + 1) / p.ksplit) - kt0 : nk_all;   // (bit 1: profiling, epilogue only)
   char* const dma_dst = smem + wave * (8 * 128);   // + half * HT + i * (64 * 128) + buffer * KBUF  (lane * 16 is implicit)
 
+  const int vT = p.vT > 0 ? p.vT : p.Ti * p.ut, vH = p.vH > 0 ? p.vH : p.Hi * p.uh, vW = p.vW > 0 ? p.vW : p.Wi * p.uw;
   auto set_tap = [&](int hh, int tap) {
     const int kt = tap / khw, r = tap - kt * khw;
     const int kh = r / p.KW, kw = r - kh * p.KW;
@@ -216,8 +217,11 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
     for (int i = 0; i < 2; ++i) {
       const uint32_t c = acoord[hh][i];
       const int vt = (int)(c & 1023u) - p.pt + kt, vh = (int)((c >> 10) & 1023u) - p.ph + kh, vw = (int)((c >> 20) & 1023u) - p.pw + kw;
-      const bool ok = !(c >> 31) && (unsigned)vt < (unsigned)p.Ti && (unsigned)vh < (unsigned)p.Hi && (unsigned)vw < (unsigned)p.Wi;
-      aoff[hh][i] = ok ? ((abase[hh][i] + (uint32_t)((vt * p.Hi + vh) * p.Wi + vw)) * (uint32_t)p.lda) * EB + a_sel : PD_OOB;
+      // (nearest x2 up-sampling fused in the gather -- Upsample3DLayer / the VAE's Upsample2D: the taps are bounds-checked against the
+      //  VIRTUAL, up-sampled size, the row read is the source pixel (v >> 1))
+      const bool ok = !(c >> 31) && (unsigned)vt < (unsigned)vT && (unsigned)vh < (unsigned)vH && (unsigned)vw < (unsigned)vW;
+      const int it = p.ut == 2 ? vt >> 1 : vt, ih = p.uh == 2 ? vh >> 1 : vh, iw = p.uw == 2 ? vw >> 1 : vw;
+      aoff[hh][i] = ok ? ((abase[hh][i] + (uint32_t)((it * p.Hi + ih) * p.Wi + iw)) * (uint32_t)p.lda) * EB + a_sel : PD_OOB;
     }
   };
   // K-tile counters of the DMA streams (A runs one K-tile ahead of the MFMAs, W two); all wave-uniform scalars
@@ -561,8 +565,7 @@ bool pd_igemm256_supported(const pd_igemm_args& a, int kind) {
 #endif
   }
   if (kind == 0) return true;
-  return a.st == 1 && a.sh == 1 && a.sw == 1 && a.ut == 1 && a.uh == 1 && a.uw == 1 && a.vT <= 0 && a.vH <= 0 && a.vW <= 0 &&
-         a.To < 1024 && a.Ho < 1024 && a.Wo < 1024;
+  return a.st == 1 && a.sh == 1 && a.sw == 1 && a.To < 1024 && a.Ho < 1024 && a.Wo < 1024;      // (nearest x2 up-sampling: in the gather)
 }
 
 int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s) {
