@@ -229,9 +229,9 @@ def test_igemm_conv2d(mode, tile):
     elif mode == "up2":      # nearest x2 then conv pad 1 (cuboid_transformer.py:373-375 / taming/resnet.py:128-141)
         geom = L.conv_geom(N_, (1, H, W), (1, 3, 3), pad=(0, 1, 1), up=(1, 2, 2))
         ref = F.conv2d(F.interpolate(xc, scale_factor=2.0, mode="nearest"), bf(w), bias, padding=1)
-    elif mode == "up2_odd":  # nearest resize to an odd target (15 x 13 from 8 x 8: Upsample3DLayer with a target size, cuboid_transformer.py:363-372)
-        geom = L.conv_geom(N_, (1, H, W), (1, 3, 3), pad=(0, 1, 1), up=(1, 2, 2), out_thw=(1, 15, 13), virt_thw=(1, 15, 13))
-        ref = F.conv2d(F.interpolate(xc, size=(15, 13), mode="nearest"), bf(w), bias, padding=1)    # (for out = 2 in - 1 torch's source index is i >> 1)
+    elif mode == "up2_odd":  # nearest resize to an odd target (15 x 15 from 8 x 8: Upsample3DLayer with a target size, cuboid_transformer.py:363-372)
+        geom = L.conv_geom(N_, (1, H, W), (1, 3, 3), pad=(0, 1, 1), up=(1, 2, 2), out_thw=(1, 15, 15), virt_thw=(1, 15, 15))
+        ref = F.conv2d(F.interpolate(xc, size=(15, 15), mode="nearest"), bf(w), bias, padding=1)    # (for out = 2 in - 1 torch's source index is i >> 1)
     else:                    # pad (0,1,0,1) then stride-2 conv, padding 0 (taming/resnet.py:183-188)
         geom = L.conv_geom(N_, (1, H, W), (1, 3, 3), stride=(1, 2, 2), pad=(0, 0, 0), out_thw=(1, H // 2, W // 2))
         ref = F.conv2d(F.pad(xc, (0, 1, 0, 1)), bf(w), bias, stride=2)
