@@ -155,6 +155,13 @@ int pd_conv2d_gn_silu(const float* x, const float* stats, const float* gamma, co
                       const float* residual, float* out, int N, int H, int W_, int Cin, int Cout, int G, const pd_call_opts* opts,
                       pd_stream_t stream);
 
+/* The VAE's Upsample2D (taming/resnet.py:128-141): nearest x2 up-sampling -> Conv2d 3x3 (stride 1, zero padding 1) [+ bias] in one launch of the
+ * same tile kernel: x (N, H / 2, Wd / 2, Cin) fp32 channels last -> out (N, H, Wd, Cout) fp32; H, Wd are the OUTPUT size.  The halo of a pixel
+ * tile is staged from the half-resolution source (no normalisation in front of this convolution): no 16-bit cast pass over the input, no gather
+ * per filter tap.  Geometry as pd_conv2d_gn_silu_supported(H, Wd, Cin, Cout, 1). */
+int pd_conv2d_up2(const float* x, const pd_bf16* W, const float* bias, float* out, int N, int H, int Wd, int Cin, int Cout,
+                  const pd_call_opts* opts, pd_stream_t stream);
+
 /* pd_groupnorm_silu with an OCP e4m3 output (the A operand of an fp8 pd_igemm launch): out[b, s, c] = e4m3(y * fp8_scale),
  * round to nearest even, saturating at +-448; rows of C bytes.  C % 4 == 0, C/4 divides 256, 4 | C/G. */
 int pd_groupnorm_silu_fp8(const float* x, const float* gamma, const float* beta, const float* ss_scale,

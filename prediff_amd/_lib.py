@@ -93,6 +93,7 @@ _PROTOS = {
     "pd_groupnorm_stats": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "pd_conv2d_gn_silu_supported": (C.c_int, [C.c_int] * 5),
     "pd_conv2d_gn_silu": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.POINTER(CallOpts), C.c_void_p]),
+    "pd_conv2d_up2": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.POINTER(CallOpts), C.c_void_p]),
     "pd_groupnorm_silu_fp8": (C.c_int, [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "pd_groupnorm_silu_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
     "pd_cast_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int] * 6 + [C.POINTER(CallOpts), C.c_void_p]),
@@ -284,6 +285,11 @@ def conv2d_gn_silu(x, stats, gamma, beta, W, bias, residual, out, N, H, Wd, Cin,
     """GroupNorm -> SiLU -> Conv2d 3x3 (+ bias, + fp32 residual) in one launch (csrc/conv2d_gn.hip): the VAE ResBlock body."""
     _check(lib().pd_conv2d_gn_silu(ptr(x), ptr(stats), ptr(gamma), ptr(beta), ptr(W), ptr(bias), ptr(residual), ptr(out), N, H, Wd, Cin,
                                    Cout, G, _opts_ref(opts), stream_ptr()), "pd_conv2d_gn_silu")
+
+
+def conv2d_up2(x, W, bias, out, N, H, Wd, Cin, Cout, opts=None):
+    """nearest x2 -> Conv2d 3x3 pad 1 (+ bias) of Upsample2D in one launch; H, Wd = OUTPUT size (pd_conv2d_up2)."""
+    _check(lib().pd_conv2d_up2(ptr(x), ptr(W), ptr(bias), ptr(out), N, H, Wd, Cin, Cout, _opts_ref(opts), stream_ptr()), "pd_conv2d_up2")
 
 
 def groupnorm_silu_fp8(x, gamma, beta, partials, out, B, S, Cn, G, eps, fp8_scale, silu=True, ss_scale=None, ss_shift=None, ld_ss=0):

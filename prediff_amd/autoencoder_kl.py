@@ -184,9 +184,10 @@ class AutoencoderKL(nn.Module):
         return t
 
     def _bf(self, name, rows, cols, device):
-        hi = self._buf(name, (rows, cols), self.op_dtype, device)
-        lo = self._buf(name + ".lo", (rows, cols), torch.bfloat16, device) if self.precision == "fp32" else None
-        return hi, lo
+        if self.precision == "fp32":      # both halves in one allocation (the 256 x 256 hi/lo kernel reads them through one buffer descriptor)
+            both = self._buf(name + ".hilo", (2, rows, cols), torch.bfloat16, device)
+            return both[0], both[1]
+        return self._buf(name, (rows, cols), self.op_dtype, device), None
 
     # ------------------------------------------------------------------------------------------------ primitives
     def _cast(self, x, rows, C, name, dev):
@@ -359,9 +360,16 @@ class AutoencoderKL(nn.Module):
                 cur = self._resnet(P, f"decoder.up_blocks.{b}.resnets.{r}", rn, cur, N, hw, dev)
                 C = rn.out_channels
             if blk.upsamplers is not None:
-                a, alo, ld = self._cast(cur, N * hw[0] * hw[1], C, "cast.a", dev)
                 nxt = self._buf(f"dec.us{b}", (N * 4 * hw[0] * hw[1], C), torch.float32, dev)
-                hw = self._conv(P, f"decoder.up_blocks.{b}.upsamplers.0.conv", a, alo, ld, N, hw, C, nxt, dev, mode="up")
+                uname = f"decoder.up_blocks.{b}.upsamplers.0.conv"
+                if (self.precision == "bf16" and self.fuse_resblock and pad64(C) == C
+                        and L.conv2d_gn_silu_supported(2 * hw[0], 2 * hw[1], C, C, 1)):
+                    # Upsample2D in one launch of the fused tile kernel: the halo comes straight from the half-resolution fp32 rows
+                    L.conv2d_up2(cur, P[uname + ".w"][0], P[uname + ".b"], nxt, N, 2 * hw[0], 2 * hw[1], C, C, opts=self.opts)
+                    hw = (2 * hw[0], 2 * hw[1])
+                else:
+                    a, alo, ld = self._cast(cur, N * hw[0] * hw[1], C, "cast.a", dev)
+                    hw = self._conv(P, uname, a, alo, ld, N, hw, C, nxt, dev, mode="up")
                 cur = nxt
         S = hw[0] * hw[1]
         a, alo, ld = self._gn(P, "decoder.conv_norm_out", cur, N, S, C, dev)

@@ -56,6 +56,10 @@ struct pd_conv2d_gn_args_k {
   uint32_t w_bytes;
 };
 
+// UP (pd_conv2d_up2: the VAE's Upsample2D, taming/resnet.py:128-141 -- nearest x2 then Conv2d 3x3 pad 1): the same tile kernel with the halo
+// staged from the HALF-resolution fp32 source (virtual pixel (gy, gx) reads source pixel (gy >> 1, gx >> 1); H, Wd are the OUTPUT size) and
+// no normalisation / nonlinearity (there is none in front of that convolution): no fp32 -> 16-bit cast pass, no gather per filter tap.
+template <bool UP>
 __global__ void __launch_bounds__(256, 2) conv2d_gn_kernel(const pd_conv2d_gn_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TH = 8, TW = 16, HC = TW + 2, NHALO = (TH + 2) * HC;     // 180 halo pixels
@@ -111,8 +115,12 @@ __global__ void __launch_bounds__(256, 2) conv2d_gn_kernel(const pd_conv2d_gn_ar
   for (int cc = 0; cc < nslice; ++cc) {
     // ---------------- halo of this channel slice: fp32 -> GroupNorm -> SiLU -> bf16 -> LDS ----------------
     const int c = cc * KC + c4 * 4;
-    const float4 g4 = *(const float4*)(p.gamma + c), b4 = *(const float4*)(p.beta + c);
-    const float2 mr = *(const float2*)(p.stats + ((int64_t)n * p.G + c / cpg) * 2);     // (mean, rstd) of this thread's group
+    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 mr = make_float2(0.f, 1.f);
+    if constexpr (!UP) {
+      g4 = *(const float4*)(p.gamma + c); b4 = *(const float4*)(p.beta + c);
+      mr = *(const float2*)(p.stats + ((int64_t)n * p.G + c / cpg) * 2);     // (mean, rstd) of this thread's group
+    }
     float4 v[NV];
     bool inb[NV];
 #pragma unroll
@@ -122,7 +130,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_gn_kernel(const pd_conv2d_gn_ar
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
       inb[i] = row < NHALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.Wd;
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (inb[i]) v[i] = *(const float4*)(p.x + (((int64_t)n * p.H + gy) * p.Wd + gx) * p.Cin + c);
+      if constexpr (UP) {
+        if (inb[i]) v[i] = *(const float4*)(p.x + (((int64_t)n * (p.H >> 1) + (gy >> 1)) * (p.Wd >> 1) + (gx >> 1)) * p.Cin + c);
+      } else {
+        if (inb[i]) v[i] = *(const float4*)(p.x + (((int64_t)n * p.H + gy) * p.Wd + gx) * p.Cin + c);
+      }
     }
     WG_BARRIER();                                    // every wave is done with the previous slice's tile
     const float mean = mr.x;
@@ -147,8 +159,13 @@ __global__ void __launch_bounds__(256, 2) conv2d_gn_kernel(const pd_conv2d_gn_ar
     for (int i = 0; i < NV; ++i) {
       const int row = (i * 256 + tid) >> 4;
       if (row >= NHALO) continue;
-      float y0v = silu(fmaf(v[i].x, sc0, sh0)), y1v = silu(fmaf(v[i].y, sc1, sh1));
-      float y2v = silu(fmaf(v[i].z, sc2, sh2)), y3v = silu(fmaf(v[i].w, sc3, sh3));
+      float y0v, y1v, y2v, y3v;
+      if constexpr (UP) {
+        y0v = v[i].x; y1v = v[i].y; y2v = v[i].z; y3v = v[i].w;
+      } else {
+        y0v = silu(fmaf(v[i].x, sc0, sh0)); y1v = silu(fmaf(v[i].y, sc1, sh1));
+        y2v = silu(fmaf(v[i].z, sc2, sh2)); y3v = silu(fmaf(v[i].w, sc3, sh3));
+      }
       if (!inb[i]) y0v = y1v = y2v = y3v = 0.f;      // zero padding of the convolution input
       *(uint2*)(sX + row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) << 4) + ((c4 & 1) << 3)) = make_uint2(pack_op2(y0v, y1v), pack_op2(y2v, y3v));
     }
@@ -220,16 +237,9 @@ extern "C" int pd_f16_conv2d_gn_silu(const float*, const float*, const float*, c
 extern "C" int pd_conv2d_gn_silu_supported(int H, int W, int Cin, int Cout, int G);
 #endif
 
-extern "C" int PD_ENTRY(conv2d_gn_silu)(const float* x, const float* stats, const float* gamma, const float* beta, const pd_bf16* W,
-                                        const float* bias, const float* residual, float* out, int N, int H, int Wd, int Cin, int Cout, int G,
-                                        const pd_call_opts* opts, pd_stream_t stream) {
-  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_conv2d_gn_silu(x, stats, gamma, beta, W, bias, residual, out, N, H, Wd, Cin, Cout, G, opts, stream));
-  PD_CHECK_ARG(x && stats && gamma && beta && W && out, "pd_conv2d_gn_silu: null pointer");
-  if (!pd_conv2d_gn_silu_supported(H, Wd, Cin, Cout, G)) {
-    pd_set_error("pd_conv2d_gn_silu: unsupported geometry H=%d W=%d Cin=%d Cout=%d G=%d (H %% 8, W %% 16, Cin %% 64, Cout %% 128, 4 | Cin/G)",
-                 H, Wd, Cin, Cout, G);
-    return PD_ERR_UNSUPPORTED;
-  }
+template <bool UP>
+static int launch_conv2d_gn(const float* x, const float* stats, const float* gamma, const float* beta, const pd_bf16* W, const float* bias,
+                            const float* residual, float* out, int N, int H, int Wd, int Cin, int Cout, int G, hipStream_t stream) {
   PD_CHECK_ARG(N > 0 && (int64_t)N * H * Wd * (int64_t)std::max(Cin, Cout) < (1ll << 40), "pd_conv2d_gn_silu: bad N");
   const int64_t wbytes = (int64_t)9 * Cout * Cin * 2;
   PD_CHECK_ARG(wbytes < 0xfffffe00ll, "pd_conv2d_gn_silu: weights larger than a 4 GiB buffer descriptor");
@@ -243,7 +253,7 @@ extern "C" int PD_ENTRY(conv2d_gn_silu)(const float* x, const float* stats, cons
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv2d_gn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_gn_kernel<UP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_conv2d_gn_silu: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -252,9 +262,37 @@ extern "C" int PD_ENTRY(conv2d_gn_silu)(const float* x, const float* stats, cons
   }
   const int64_t grid = (int64_t)N * (H / 8) * (Wd / 16) * (Cout / 128);
   PD_CHECK_ARG(grid < (1ll << 31), "pd_conv2d_gn_silu: grid too large");
-  hipLaunchKernelGGL(conv2d_gn_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv2d_gn_kernel<UP>, dim3((unsigned)grid), dim3(256), lds, stream, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
+}
+
+extern "C" int PD_ENTRY(conv2d_gn_silu)(const float* x, const float* stats, const float* gamma, const float* beta, const pd_bf16* W,
+                                        const float* bias, const float* residual, float* out, int N, int H, int Wd, int Cin, int Cout, int G,
+                                        const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_conv2d_gn_silu(x, stats, gamma, beta, W, bias, residual, out, N, H, Wd, Cin, Cout, G, opts, stream));
+  PD_CHECK_ARG(x && stats && gamma && beta && W && out, "pd_conv2d_gn_silu: null pointer");
+  if (!pd_conv2d_gn_silu_supported(H, Wd, Cin, Cout, G)) {
+    pd_set_error("pd_conv2d_gn_silu: unsupported geometry H=%d W=%d Cin=%d Cout=%d G=%d (H %% 8, W %% 16, Cin %% 64, Cout %% 128, 4 | Cin/G)",
+                 H, Wd, Cin, Cout, G);
+    return PD_ERR_UNSUPPORTED;
+  }
+  return launch_conv2d_gn<false>(x, stats, gamma, beta, W, bias, residual, out, N, H, Wd, Cin, Cout, G, (hipStream_t)stream);
+}
+
+#if !PD_IS_F16
+extern "C" int pd_f16_conv2d_up2(const float*, const pd_bf16*, const float*, float*, int, int, int, int, int, const pd_call_opts*, pd_stream_t);
+#endif
+// nearest x2 up-sampling -> Conv2d 3x3 pad 1 [+ bias] (Upsample2D): x (N, H / 2, Wd / 2, Cin) fp32 -> out (N, H, Wd, Cout) fp32; H, Wd = OUTPUT size
+extern "C" int PD_ENTRY(conv2d_up2)(const float* x, const pd_bf16* W, const float* bias, float* out, int N, int H, int Wd, int Cin, int Cout,
+                                    const pd_call_opts* opts, pd_stream_t stream) {
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_conv2d_up2(x, W, bias, out, N, H, Wd, Cin, Cout, opts, stream));
+  PD_CHECK_ARG(x && W && out, "pd_conv2d_up2: null pointer");
+  if (!pd_conv2d_gn_silu_supported(H, Wd, Cin, Cout, 1) || (Cin & 3)) {
+    pd_set_error("pd_conv2d_up2: unsupported geometry H=%d W=%d Cin=%d Cout=%d (output H %% 8, W %% 16, Cin %% 64, Cout %% 128)", H, Wd, Cin, Cout);
+    return PD_ERR_UNSUPPORTED;
+  }
+  return launch_conv2d_gn<true>(x, nullptr, nullptr, nullptr, W, bias, nullptr, out, N, H, Wd, Cin, Cout, 1, (hipStream_t)stream);
 }
 
 }  // namespace PD_NS

@@ -979,6 +979,38 @@ def test_conv2d_gn_silu(N, H, W, Cin, Cout, res):
         assert torch.equal(r2, out)
 
 
+@pytest.mark.parametrize("operand", ["bf16", "fp16"])
+@pytest.mark.parametrize("N,Hs,Ws,C", [(3, 16, 16, 512), (2, 64, 64, 256), (5, 8, 24, 128), (1, 4, 8, 64)])
+def test_conv2d_up2(N, Hs, Ws, C, operand):
+    """pd_conv2d_up2 (Upsample2D: nearest x2 -> Conv2d 3x3 pad 1, taming/resnet.py:128-141, as one launch of the fused tile kernel with the halo
+    staged from the half-resolution fp32 rows) against torch on the 16-bit-rounded operands and against the route it replaces (cast pass +
+    pd_igemm with the up-sampling gather): the same products, another summation order."""
+    opts = L.CallOpts(operand)
+    dt = opts.dtype
+    g = torch.Generator(device="cpu").manual_seed(N + Hs + C)
+    x = torch.randn(N, Hs, Ws, C, generator=g).to(DEV)
+    w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    wp, _ = pack_conv(w, False, dtype=dt)
+    H, W = 2 * Hs, 2 * Ws
+    out = torch.full((N * H * W, C), float("nan"), device=DEV)
+    L.conv2d_up2(x, wp, bias, out, N, H, W, C, C, opts=opts)
+    torch.cuda.synchronize()
+    r = lambda t: t.to(dt).float()
+    ref = F.conv2d(F.interpolate(r(x).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"), r(w), bias, padding=1).permute(0, 2, 3, 1).reshape(N * H * W, C)
+    assert rel_l2(out, ref) < 3e-6
+    a = x.reshape(-1, C).to(dt).contiguous()
+    out2 = torch.full_like(out, float("nan"))
+    L.igemm(a, wp, M=N * H * W, N=C, Cin=C, taps=9, w_tap_stride=C * C, geom=L.conv_geom(N, (1, Hs, Ws), (1, 3, 3), pad=(0, 1, 1), up=(1, 2, 2)),
+            bias=bias, out_f32=out2, opts=opts)
+    torch.cuda.synchronize()
+    assert rel_l2(out, out2) < 2e-6
+    out3 = torch.full_like(out, float("nan"))
+    L.conv2d_up2(x, wp, bias, out3, N, H, W, C, C, opts=opts)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out3)
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,res", [(7, 128, 128, 128, 128, False), (10, 128, 128, 128, 128, True), (8, 32, 32, 512, 512, True)])
 def test_conv2d_gn_silu_two_workgroups_per_cu(N, H, W, Cin, Cout, res):
     """More workgroups than CUs (896 / 1280 / 256 of ~70 KB LDS: two resident per CU): 12 launches, every one against the torch statement
