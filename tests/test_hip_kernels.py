@@ -980,7 +980,7 @@ def test_conv2d_gn_silu(N, H, W, Cin, Cout, res):
 
 
 @pytest.mark.parametrize("operand", ["bf16", "fp16"])
-@pytest.mark.parametrize("N,Hs,Ws,C", [(3, 16, 16, 512), (2, 64, 64, 256), (5, 8, 24, 128), (1, 4, 8, 64)])
+@pytest.mark.parametrize("N,Hs,Ws,C", [(3, 16, 16, 512), (2, 64, 64, 256), (5, 8, 24, 128), (1, 4, 8, 128)])
 def test_conv2d_up2(N, Hs, Ws, C, operand):
     """pd_conv2d_up2 (Upsample2D: nearest x2 -> Conv2d 3x3 pad 1, taming/resnet.py:128-141, as one launch of the fused tile kernel with the halo
     staged from the half-resolution fp32 rows) against torch on the 16-bit-rounded operands and against the route it replaces (cast pass +
