@@ -162,14 +162,21 @@ def test_v1_forward_b32_vs_oracle_with_pair_kernel():
     finally:
         L.attn_ffn_pair = real
     assert n_pair == 48, f"{n_pair} pair launches (expected the 24 level-0 + 24 level-1 pairs of depth [4, 4] x down / up x 3 axes)"
-    ref = OU.unet_forward(sd, V1_UNET_CFG, x, t, cond)
-    e, e3 = rel_l2(out, ref), rel_l2(out_r3, ref)
+    # the oracle's CPU forward on 12 of the 32 samples (first / last of the launch and one from every tile group: a sample's rows do not
+    # depend on its neighbours, so its oracle forward at B = 12 is its oracle forward at B = 32) -- 25 s instead of 70 s of CPU time
+    idx = torch.tensor([0, 1, 2, 5, 9, 13, 16, 20, 23, 27, 30, 31])
+    ref = OU.unet_forward(sd, V1_UNET_CFG, x[idx], t[idx], cond[idx])
+    o, o3 = out.cpu()[idx], out_r3.cpu()[idx]
+    e, e3 = rel_l2(o, ref), rel_l2(o3, ref)
     e_ab = rel_l2(out, out_r3.cpu())
-    print(f"[v1 bf16 B=32] rel-L2 vs oracle: pair kernel {e:.3e}, round-3 kernels {e3:.3e}; between the two {e_ab:.3e}")
+    print(f"[v1 bf16 B=32] rel-L2 vs oracle (12 of 32 samples): pair kernel {e:.3e}, round-3 kernels {e3:.3e}; between the two (all 32) {e_ab:.3e}")
     assert e < TOL["bf16"] and e3 < TOL["bf16"]
     assert e_ab < TOL["bf16"]
-    per_sample = [rel_l2(out[i], ref[i]) for i in range(B)]
+    per_sample = [rel_l2(o[i], ref[i]) for i in range(len(idx))]
     assert max(per_sample) < 2 * TOL["bf16"], per_sample
+    # every sample against the engine without the pair kernel (all 32: catches a wrong tile anywhere in the launch)
+    per_ab = [rel_l2(out[i], out_r3[i].cpu()) for i in range(B)]
+    assert max(per_ab) < 2 * TOL["bf16"], per_ab
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
