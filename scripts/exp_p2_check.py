@@ -1,3 +1,5 @@
+"""igemm256_kernel: the two-phase K-tile (default) against the four-phase form of rounds 2-4 (debug_flags bit 64) on three Conv3d shapes:
+the same products in the same order per accumulator, so the outputs are bit-equal (profiles/r05_g_two_phase_ab.txt).  Run on the GPU box."""
 import torch, math, sys
 sys.path.insert(0, "/root/repo")
 from prediff_amd import _lib as L
