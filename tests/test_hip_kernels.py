@@ -212,6 +212,33 @@ def test_igemm_conv3d_tap_skip_equals_dense(B, T, H, W, Cin, Cout, fp8):
         assert rel_l2(outs[0], ref) < 3e-6
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B,T,H,W,C", [(2, 13, 16, 16, 256), (3, 13, 8, 8, 512), (1, 5, 7, 9, 128)])
+def test_igemm256_two_phase_equals_four_phase(B, T, H, W, C, fp8):
+    """The 256 x 256 kernel runs a K-tile in two phases of 32 MFMAs (round 5) instead of four of 16 (debug_flags bit 64 keeps the old form for
+    A/B): the same products in the same order per accumulator -- bit-equal outputs, bf16 and e4m3 operands."""
+    g = torch.Generator(device="cpu").manual_seed(B + C)
+    x = torch.randn(B, T, H, W, C, generator=g).to(DEV)
+    w = (torch.randn(C, C, 3, 3, 3, generator=g) / math.sqrt(27 * C)).to(DEV)
+    M = B * T * H * W
+    if fp8:
+        from prediff_amd.packing import pack_conv_fp8, to_fp8
+        a = to_fp8(x.reshape(-1, C), 16.0)
+        w_p, sw = pack_conv_fp8(w)
+        kw = dict(alpha=1.0 / (16.0 * sw), fp8=True)
+    else:
+        a, _ = padded_bf16(x.reshape(-1, C), False)
+        w_p, _ = pack_conv(w, False)
+        kw = dict(tile=7)
+    outs = []
+    for flag in (0, 64):
+        out = torch.full((M, C), float("nan"), device=DEV)
+        L.igemm(a, w_p, M=M, N=C, Cin=C, taps=27, w_tap_stride=C * C, geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), out_f32=out, debug_flags=flag, **kw)
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("tile", [0, 7])
 @pytest.mark.parametrize("mode", ["same", "up2", "up2_odd", "down2"])
 def test_igemm_conv2d(mode, tile):
