@@ -447,6 +447,32 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const pd_igemm
       acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
     }
     float v[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (p.vec_epilogue && !p.mul && p.act == 0 && ((uintptr_t)p.bias & 15) == 0) {
+      // the Conv3d launches of the small-batch mode: every epilogue operand as ONE 16-B load issued beside the slab loads (the general path
+      // below reads them as twelve dwords behind the sums); the same operations in the same order: bit-identical
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), r4 = b4, s4 = b4;
+      if (p.bias) b4 = *(const float4*)(p.bias + n);
+      if (p.rowvec) r4 = *(const float4*)(p.rowvec + (int64_t)(m / p.rows_per_sample) * p.ld_rowvec + n);
+      if (p.residual) s4 = *(const float4*)(p.residual + (int64_t)(p.res_period ? m % p.res_period : m) * p.ld_res + n);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = v[e] * p.alpha + bb[e];
+        if (p.rowvec) v[e] += rr[e];
+        if (p.residual) v[e] += ss[e];
+      }
+      if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)m * p.ld_out + n) = make_float4(v[0], v[1], v[2], v[3]);
+      if (p.out_bf16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint16_t h, l;
+          f2bf_split(v[e], h, l);
+          p.out_bf16[(int64_t)m * p.ld_outb + n + e] = p.out_bf16_lo ? h : (uint16_t)f2op(v[e]);
+          if (p.out_bf16_lo) p.out_bf16_lo[(int64_t)m * p.ld_outb + n + e] = l;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
     if (p.rowvec) {
