@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #pragma unroll
           for (int nt = 0; nt < CT; ++nt) acc[c][nt] = PK_ROW_LD(roff[c], nt);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sum_partials(roff, acc, xn);
+        if (p.slab_in) sum_partials(roff, acc, xn);      // (null: p.x already IS x' -- pair_split_xsum_kernel formed it once for the four slices)
       }
     }
 #if PD_PAIR_DEBUG
@@ -882,6 +882,19 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   return PD_OK;
 }
 
+// x' = ((((x + b_proj) + A_0) + A_1) + A_2) + A_3 over the four attention partials of the split form, written over A_0: formed ONCE per row
+// here instead of by each of the four hidden-quarter workgroups of MODE 2 (whose tile prologue then reads 128 KB instead of 640 KB: at
+// 4 trajectories the 208 workgroups pulled 133 MB through HBM / MALL before their first chunk).  The order of the sum is MODE 2's own
+// (sum_partials): bit-identical.
+__global__ void __launch_bounds__(256) pair_split_xsum_kernel(const float4* __restrict__ x, const float4* __restrict__ bproj, float4* __restrict__ slabs,
+                                                              int64_t n4, int c4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 xv = x[i], b = bproj[i % c4], s0 = slabs[i], s1 = slabs[i + n4], s2 = slabs[i + 2 * n4], s3 = slabs[i + 3 * n4];
+    slabs[i] = make_float4(((((xv.x + b.x) + s0.x) + s1.x) + s2.x) + s3.x, ((((xv.y + b.y) + s0.y) + s1.y) + s2.y) + s3.y,
+                           ((((xv.z + b.z) + s0.z) + s1.z) + s2.z) + s3.z, ((((xv.w + b.w) + s0.w) + s1.w) + s2.w) + s3.w);
+  }
+}
+
 // out = ((P_0 + P_1) + P_2) + P_3 over the four FFN partials of the split form (P_0 carries x' + b_2): 16 B per thread, fixed order
 __global__ void __launch_bounds__(256) pair_split_sum_kernel(const float4* __restrict__ slabs, float4* __restrict__ out, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -1012,16 +1025,23 @@ extern "C" int PD_ENTRY(attn_ffn_pair_split)(const float* x, float* out, const v
   a.slab_out = slab_a;
   int r = launch_pair<1, 2, 4, 1>(a, s);
   if (r != PD_OK) return r;
-  // 2: (tile, quarter) -> x' = x + b_proj + sum of the partials, LayerNorm, the quarter's FFN partial
-  a.slab_in = slab_a;
+  // 2a: x' = x + b_proj + the four partials in order, once per row (over partial 0)
+  const int64_t n4 = n / 4;
+  const unsigned sum_blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 2048);
+  PD_CHECK_ARG((((uintptr_t)x | (uintptr_t)vecs) & 15) == 0, "pd_attn_ffn_pair_split: x / vecs must be 16 B aligned");
+  hipLaunchKernelGGL(pair_split_xsum_kernel, dim3(sum_blocks), dim3(256), 0, s, (const float4*)x, (const float4*)(vecs + G<2>::T_BP), (float4*)slab_a, n4,
+                     G<2>::C / 4);
+  PD_CHECK_LAUNCH();
+  // 2b: (tile, quarter) -> LayerNorm of x', the quarter's FFN partial (quarter 0 carries x' + b_2)
+  a.x = slab_a;
+  a.slab_in = nullptr;
   a.slab_out = slab_f;
   a.wstream2 = wffn_split;
   a.w2bytes = (uint32_t)(2 * G<2>::NJ * G<2>::NW * CHUNK);
   r = launch_pair<1, 2, 4, 2>(a, s);
   if (r != PD_OK) return r;
   // 3: out = the four FFN partials in order
-  const int64_t n4 = n / 4;
-  hipLaunchKernelGGL(pair_split_sum_kernel, dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s, (const float4*)slab_f, (float4*)out, n4);
+  hipLaunchKernelGGL(pair_split_sum_kernel, dim3(sum_blocks), dim3(256), 0, s, (const float4*)slab_f, (float4*)out, n4);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
