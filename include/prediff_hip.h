@@ -305,10 +305,10 @@ int pd_attn_ffn_pair(const float* x, float* out, const void* wstream, const floa
                      const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale, float eps_attn,
                      float eps_ffn, const pd_call_opts* opts, pd_stream_t stream);
 
-/* The same pair for SMALL GRIDS (few trajectories per launch), units 512: three launches that give every 64-row tile to FOUR workgroups,
- * each streaming a quarter of the weights -- (tile, head): LayerNorm-1 + that head's attention + its proj partial; (tile, quarter of the
- * hidden units): x' = x + b_proj + the four partials (in head order), LayerNorm-2, that quarter's FFN partial; a sum of the four FFN
- * partials (in order) into out.  Deterministic; the fp32 summation order differs from pd_attn_ffn_pair's (partials instead of one
+/* The same pair for SMALL GRIDS (few trajectories per launch), units 512: two tile launches + two row sums that give every 64-row tile to FOUR workgroups,
+ * each streaming a quarter of the weights -- (tile, head): LayerNorm-1 + that head's attention + its proj partial; a row sum
+ * x' = x + b_proj + the four partials (in head order); (tile, quarter of the hidden units): LayerNorm-2 of x', that quarter's FFN partial;
+ * a row sum of the four FFN partials (in order) into out.  x and vecs 16 B aligned.  Deterministic; the fp32 summation order differs from pd_attn_ffn_pair's (partials instead of one
  * running accumulator), so the two agree to fp32 round-off amplified by the 16-bit roundings downstream, not bit for bit.
  *   wffn_split: the FFN chunks of `wstream` in quarter-major order (prediff_amd/packing.py: pack_pair_ffn_split), 128 chunks of 32 KB;
  *   ws: caller workspace of pd_attn_ffn_pair_split_ws_floats(B, ntok, units) floats (2 x 4 partial slabs of x's size), 16 B aligned. */

@@ -430,7 +430,7 @@ def attn_ffn_pair_split_ws_floats(B, ntok, units):
 
 def attn_ffn_pair_split(x, out, wstream, wffn_split, vecs, tok_index, B, ntok, nc, vol, scale, ws, eps_attn=1e-5, eps_ffn=1e-5, tok_affine=None,
                         units=512, opts=None):
-    """The (attention, FFN) pair at units 512 for small grids: three launches, four workgroups per 64-row tile (csrc/pair_block.hip MODE 1 / 2
+    """The (attention, FFN) pair at units 512 for small grids: two tile launches + two row sums, four workgroups per 64-row tile (csrc/pair_block.hip MODE 1 / 2
     + pair_split_sum_kernel).  wffn_split: packing.pack_pair_ffn_split; ws: fp32 workspace of attn_ffn_pair_split_ws_floats(...) elements."""
     aff = (C.c_int32 * 4)(*tok_affine) if tok_affine is not None else None
     _check(lib().pd_attn_ffn_pair_split(ptr(x), ptr(out), ptr(wstream), ptr(wffn_split), ptr(vecs), ptr(tok_index),

@@ -990,7 +990,7 @@ extern "C" int PD_ENTRY(attn_ffn_pair)(const float* x, float* out, const void* w
   return nc_wave == 2 ? launch_pair<2, 1>(a, (hipStream_t)stream) : launch_pair<1, 1>(a, (hipStream_t)stream);
 }
 
-// ---- the pair as three launches for small grids (few trajectories per launch): four workgroups per 64-row tile -----------------------
+// ---- the pair as two tile launches + two row sums for small grids (few trajectories per launch): four workgroups per 64-row tile -----------------------
 #if !PD_IS_F16
 extern "C" int64_t pd_attn_ffn_pair_split_ws_floats(int B, int ntok, int units) { return (int64_t)2 * PAIR_NSPL * B * ntok * units; }
 extern "C" int pd_f16_attn_ffn_pair_split(const float*, float*, const void*, const void*, const float*, const int32_t*, const int32_t*, int, int, int, int,

@@ -896,7 +896,7 @@ class CuboidTransformerUNet(nn.Module):
                                 eps_ffn=pair[3], tok_affine=geo.get("affine"), units=C, opts=self.opts)
                 continue
             if pair is not None and C == 512 and C in self.pair_units and self.pair_split and pair[4] is not None:
-                # small grids at units 512: the same pair as three launches, four workgroups per 64-row tile, each streaming a quarter of
+                # small grids at units 512: the same pair as two tile launches + two row sums, four workgroups per 64-row tile, each streaming a quarter of
                 # the 6.3 MB of weights (instead of the seven launches below)
                 ws = self._buf("pair.split.ws", (L.attn_ffn_pair_split_ws_floats(B, S, C),), torch.float32, dev)
                 L.attn_ffn_pair_split(x, x, pair[0], pair[4], pair[1], tabs[a]["tok"], B, S, geo["nc"], geo["vol"], float(at.scale), ws,
