@@ -361,7 +361,7 @@ def lanes_for(batch, args):
     """Lanes for a small per-GPU batch: sub-batches of >= 2 trajectories on concurrent streams (measured, profiles/r02_*sweep*)."""
     if args.small_streams:
         return args.small_streams
-    return 2 if batch >= 8 else 1       # r02 sweeps: 4 x 1 / 4 x 2 = 543 / 527 steps/s, 8 x 1 / 8 x 2 = 802 / 827, 16 x 2 best
+    return 2 if batch >= 16 else 1      # round 5 (profiles/r05_r_small_batch_lanes.txt): 8 x 1 / 8 x 2 = 951 / 918 steps/s, 12: 1089 / 1021, 16: 1325 / 1345-1358
 
 
 def main():

@@ -151,7 +151,9 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
         # picks its K slicing from the per-launch batch, so another lane count / micro-batch / ensemble sharding changes the fp32
         # summation order and the latents agree to bf16 noise (5e-3 per forward), not bit for bit (DESIGN.md §4;
         # tests/test_hip_configs.py::test_v1_lane_split_tolerance).  `torch_nn_module.split_k = False` is the reproducible mode.
-        self.num_streams = 2
+        # Default: two lanes from 8 trajectories per lane on, ONE below that (MI355X, round 5: 16 trajectories 1345-1358 steps/s in two lanes vs
+        # 1293-1325 in one, but 12: 1020 vs 1089 and 8: 918 vs 951 -- profiles/r05_r_small_batch_lanes.txt).  Assigning `num_streams` pins it.
+        self._num_streams, self._lanes_pinned = 2, False
         self.aligned_lanes = 1        # knowledge-aligned loop: denoiser lanes next to the guidance stream (see p_sample_loop)
         self.guidance_high_priority = False   # knowledge-aligned loop: run the guidance on a high-priority side stream (A/B switch;
                                               # measured neutral: 32.9 vs 32.8-33.1 ms at 32 trajectories, 11.5 vs 11.6 ms at 8)
@@ -434,9 +436,21 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
         self._graphs[lane] = (key, st)   # one live graph per lane
         return st
 
+    MIN_AUTO_LANE_BATCH = 8
+
+    @property
+    def num_streams(self):
+        return self._num_streams
+
+    @num_streams.setter
+    def num_streams(self, value):
+        self._num_streams, self._lanes_pinned = int(value), True
+
     def _lanes(self, kind, B, cond, device, allow):
         """Per-lane graph states and streams for a batch of B, or None when the single-graph path has to be used."""
         S = int(self.num_streams) if allow else 1
+        if not self._lanes_pinned and S > 1 and B // S < self.MIN_AUTO_LANE_BATCH:
+            S = 1
         if S <= 1 or B % S or B // S < 1 or not isinstance(cond, torch.Tensor):
             return None
         Bl = B // S
@@ -521,14 +535,14 @@ class LatentDiffusion(LossEvaluationMixin, _module_base()):
             # one denoiser graph on one side stream: the guidance is the concurrent second stream of work, and splitting the denoiser
             # into lanes as well only makes the three compete (measured at 32 / 8 trajectories: 33.4 / 11.6 ms per step with one
             # lane, 34.8 / 13.6 with two, 37.2 / 16.0 with four -- profiles/r02_j_time_alignment*.log).  `aligned_lanes` overrides.
-            saved = self.num_streams
+            saved = (self._num_streams, self._lanes_pinned)
             try:                                 # an exception in the capture must not leave the module with another lane count
                 self.num_streams = max(1, int(self.aligned_lanes))
                 if B % max(1, self.num_streams):
                     self.num_streams = 1
                 eps_lanes = self._lanes("eps", B, cond, device, True) if self.num_streams > 1 else None
             finally:
-                self.num_streams = saved
+                self._num_streams, self._lanes_pinned = saved
             if eps_lanes is None:
                 key = str(device)
                 if len(self._lane_streams.get(key, ())) < 1:
