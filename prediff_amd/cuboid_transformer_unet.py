@@ -361,7 +361,7 @@ class CuboidTransformerUNet(nn.Module):
         self.pair_units = {int(u) for u in os.environ.get("PD_PAIR_UNITS", "256,512").split(",") if u}   # A/B: block widths handed to it
         # units 512 (level 1): 64-row tiles that stream 6 MB of weights each -- below this many tiles (one per CU) the separate launches,
         # which spread the same rows over all CUs, are faster (scripts/sweep_pair_units.sh)
-        self.pair_l1_min_tiles = int(os.environ.get("PD_PAIR_L1_MIN_TILES", "100"))
+        self.pair_l1_min_tiles = int(os.environ.get("PD_PAIR_L1_MIN_TILES", "90"))     # (round 5 sweep, profiles/r05_r_small_batch_lanes.txt: one launch from 7 trajectories on)
         # ... and below that the split form of the same kernel: (tile, head) and (tile, hidden quarter) workgroups + an ordered sum
         # (pd_attn_ffn_pair_split; only with split_k: its fp32 summation order is not the one-launch kernel's)
         self.pair_split = os.environ.get("PD_PAIR_SPLIT", "1") != "0"
