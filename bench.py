@@ -693,16 +693,23 @@ def main():
                             gfa = Bl * 832 * (2 * 4 * 512 * 512 + 4 * 10 * 512) / 1e9
                             gff = Bl * 832 * (2 * 2 * 512 * 2048) / 1e9
                         us = line[key]["avg_launch_us"]
+                        tb_us = mean("launch_us")
+                        if abs(tb_us / us - 1.0) > 0.10:
+                            # the stamps are evidence for the product kernel only if the traced build runs like it (the old 24-stamp
+                            # build of the units-512 form ran 3x slower): say so instead of printing shares of a different kernel
+                            line[key]["phases"] = {"dropped": "trace build launch differs from the product launch by more than 10 %",
+                                                   "trace_build_launch_us": round(tb_us, 1), "product_launch_us": us}
+                            continue
                         line[key]["phases"] = {
-                            "what": "the launch split by the kernel's own clock stamps (shares of a workgroup's tile time from the trace build of the same "
-                                    "source, scripts/bench_pair.py phases, mean over the three axial layers; applied to this run's launch time): "
+                            "what": "the launch split by the kernel's own clock stamps (three per tile, held in scalar registers: the -DPD_PAIR_TRACE=1 build "
+                                    "of the same source, scripts/bench_pair.py phases, mean over the three axial layers; applied to this run's launch time): "
                                     "attention = LayerNorm-1 .. proj + residual, ffn = LayerNorm-2 .. FFN-2 + residual",
                             "attention_share_of_launch": round(sh_a, 4), "ffn_share_of_launch": round(sh_f, 4),
                             "attention_us": round(sh_a * us, 2), "ffn_us": round(sh_f * us, 2),
                             "attention_gflop": round(gfa, 3), "ffn_gflop": round(gff, 3),
                             "attention_frac_of_peak": round(gfa / (sh_a * us) * 1e3 / PEAK_BF16_TFLOPS, 4),
                             "ffn_frac_of_peak": round(gff / (sh_f * us) * 1e3 / PEAK_BF16_TFLOPS, 4),
-                            "trace_build_launch_us": round(mean("launch_us"), 1)}
+                            "trace_build_launch_us": round(tb_us, 1), "trace_build_vs_product": round(tb_us / us, 3)}
         if strong is not None:
             if n_gpus == 1 and "B4" in small and strong["ensemble"] == 32:
                 # what the SAME ensemble would do on 8 GPUs (4 members each): the step loop has no collective, so 8 x the measured

@@ -69,6 +69,30 @@ class CallOpts(C.Structure):
         """torch dtype of the 16-bit operand buffers these options describe"""
         return torch.float16 if self.operand == OPERAND["fp16"] else torch.bfloat16
 
+    _HOST_FIELDS = ("igemm_tile", "igemm_debug_or", "igemm_disable_256", "igemm_min_k_256", "igemm_splitk_max_tiles")
+
+    def _state(self):
+        """every member but `trace` (a device pointer of a profiling run: meaningless in a copy or another process)"""
+        st = {n: getattr(self, n) for n, _ in self._fields_ if n != "trace"}
+        st.update({n: getattr(self, n) for n in self._HOST_FIELDS})
+        return st
+
+    def replace(self, **kw):
+        """a copy with some members changed (the options a module passes are never mutated per launch)"""
+        st = self._state()
+        st["trace"] = self.trace
+        st.update(kw)
+        return CallOpts(**st)
+
+    def __reduce__(self):
+        # ctypes refuses to pickle structures holding pointers; a module that owns a CallOpts must stay deepcopy- / pickle-able
+        # (EMA by deepcopy, DDP spawn, torch.save(module))
+        return (_callopts_from_state, (self._state(),))
+
+
+def _callopts_from_state(st):
+    return CallOpts(**st)
+
 
 def _opts_ref(opts):
     return C.byref(opts) if opts is not None else None

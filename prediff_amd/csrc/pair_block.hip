@@ -154,6 +154,9 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
 #ifndef PD_PAIR_DEBUG
 #define PD_PAIR_DEBUG 0
 #endif
+#ifndef PD_PAIR_TRACE
+#define PD_PAIR_TRACE 0
+#endif
 // compile-time ablations for profiling builds (-DPD_PAIR_ABLATE=bits, scripts/ablate_pair.sh): 1 no weight DMA after the prologue,
 // 2 no fragment reads, 4 no MFMAs in the chunk bodies, 8 no GELU work in the chunk hooks, 16 no row loads / stores in the chunk hooks,
 // 32 no mid-chunk wait + barrier (timing only: the results are garbage)
@@ -255,6 +258,28 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #define PK_TRACE() do { if (p.trace && blockIdx.x == 7 && tid == 0 && tr_n < 256) p.trace[tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
 #else
 #define PK_TRACE() do {} while (0)
+#endif
+  // PD_PAIR_TRACE (libprediff_hip_trace.so, bench.py's `phases`): THREE clock stamps per tile -- tile start, attention done, FFN done -- kept in
+  // scalar registers and written by one lane at the end of the tile: the light form of the PD_PAIR_DEBUG stamps (24 per tile + the dump
+  // hooks cost the units-512 instantiation its registers: that build ran 3x slower than the product kernel), within a few
+  // percent of the product kernel's duration (bench.py compares the two and drops the split otherwise).
+#if PD_PAIR_TRACE
+  int trl_n = 0;
+  unsigned long long trl_a = 0, trl_b = 0;
+#define PK_STAMP_START() trl_a = __builtin_amdgcn_s_memtime()
+#define PK_STAMP_ATT() trl_b = __builtin_amdgcn_s_memtime()
+#define PK_STAMP_END()                                                                       \
+  do {                                                                                       \
+    const unsigned long long e_ = __builtin_amdgcn_s_memtime();                              \
+    if (p.trace && blockIdx.x == 7 && tid == 0 && trl_n < 85) {                              \
+      p.trace[3 * trl_n] = trl_a; p.trace[3 * trl_n + 1] = trl_b; p.trace[3 * trl_n + 2] = e_; \
+    }                                                                                        \
+    ++trl_n;                                                                                 \
+  } while (0)
+#else
+#define PK_STAMP_START() do {} while (0)
+#define PK_STAMP_ATT() do {} while (0)
+#define PK_STAMP_END() do {} while (0)
 #endif
   int cc = 0;                                       // chunks consumed by this workgroup
   op8 w[PFN] = {};                               // fragment pipeline (runs on across chunks, tiles and phases)
@@ -440,6 +465,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     PK_TRACE();   // tile start
+    PK_STAMP_START();
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       ooff[c] = roff[c];
@@ -691,6 +717,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
     }
     PK_DRAIN();                                     // (a LayerNorm follows)
     PK_TRACE();   // attention done
+    PK_STAMP_ATT();
     if constexpr (MODE == 1) {                       // the partial leaves to this head's slab; nothing else to do for the tile
 #pragma unroll
       for (int c = 0; c < NC; ++c)
@@ -838,6 +865,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
     }
     PK_DRAIN();                                     // (the next tile's LayerNorm follows)
     PK_TRACE();   // FFN done
+    PK_STAMP_END();
     if constexpr (MODE == 2) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
@@ -943,7 +971,7 @@ static int pair_fill_args(pd_pair_args_k& a, const float* x, float* out, const v
   a.scale = scale; a.eps1 = eps_attn; a.eps2 = eps_ffn;
   a.wbytes = (uint32_t)((units == 256 ? G<1>::CH_ALL : G<2>::CH_ALL) * CHUNK);
   a.xbytes = (uint32_t)((int64_t)B * ntok * (units * 4));
-  a.trace = opts ? opts->trace : nullptr;          // (clock stamps: -DPD_PAIR_DEBUG=1 builds only)
+  a.trace = opts ? opts->trace : nullptr;          // (clock stamps: -DPD_PAIR_TRACE=1 / -DPD_PAIR_DEBUG=1 builds only)
 #if PD_PAIR_DEBUG
   a.dbg_buf = pd_pair_dbg_buf;
   a.dbg_stage = pd_pair_dbg_stage;

@@ -686,10 +686,16 @@ class CuboidTransformerUNet(nn.Module):
         return hi, lo, ld
 
     def _opts_for(self, B):
-        """The module's call options with `small_grid` set for launches of the small-batch mode (split_k: kernels may be chosen by launch
-        size there -- finer GroupNorm chunks; every lane of a step has the same batch, so the shared struct is safe to flip)."""
-        self.opts.small_grid = 1 if self._splitk_mode(B) else 0
-        return self.opts
+        """The module's call options, or a copy with `small_grid` set for launches of the small-batch mode (split_k: kernels may be chosen
+        by launch size there -- finer GroupNorm chunks).  `self.opts` itself is never mutated per launch (lanes may run from their own
+        host threads with different batch sizes); the copy is rebuilt when a caller changed `self.opts` (bench.py's A/B switches)."""
+        if not self._splitk_mode(B):
+            return self.opts
+        want = self.opts.replace(small_grid=1)
+        cur = getattr(self, "_opts_small", None)
+        if cur is None or cur._state() != want._state() or cur.trace != want.trace:
+            self._opts_small = cur = want
+        return cur
 
     def _splitk_mode(self, B):
         return self.precision == "bf16" and B <= self.SPLITK_MAX_BATCH and self.split_k

@@ -39,6 +39,46 @@ def seeded_state_dict(template: Mapping[str, torch.Tensor], seed: int) -> Dict[s
     return out
 
 
+def heavy_tailed_state_dict(template: Mapping[str, torch.Tensor], seed: int, nu: float = 3.0, outlier: float = 30.0,
+                            n_outlier: int = 2) -> Dict[str, torch.Tensor]:
+    """Checkpoint-like stress weights (no trained checkpoint exists offline): every matrix / filter is Student-t(nu) distributed with
+    the fan-in-scaled variance of `seeded_state_dict` (nu = 3: a few entries per tensor sit at 10-20 sigma), and `n_outlier` output
+    channels of every matrix / filter and `n_outlier` entries of every norm scale are `outlier` times larger -- the outlier-channel
+    pattern trained transformers show in their LayerNorm gains and the projections behind them.  Used by the robustness parity tests
+    of the 16-bit / 8-bit engines (overflow of the half-precision packers, the fixed e4m3 activation scale)."""
+    out = {}
+    for k in template:
+        v = template[k]
+        if not torch.is_floating_point(v):
+            out[k] = v.detach().clone().cpu()
+            continue
+        shape = tuple(v.shape)
+        g = torch.Generator(device="cpu")
+        g.manual_seed((seed * 1000003 + zlib.crc32(("ht:" + k).encode())) % (2 ** 63 - 1))
+        if len(shape) >= 2:
+            fan_in = 1
+            for s_ in shape[1:]:
+                fan_in *= s_
+            z = torch.randn(shape, generator=g, dtype=torch.float32)
+            # Student-t(nu) = z / sqrt(chi2(nu) / nu); chi2(nu) as a sum of nu squared normals (nu integer), seeded by the same generator
+            c2 = torch.zeros(shape)
+            for _ in range(int(nu)):
+                c2 += torch.randn(shape, generator=g, dtype=torch.float32) ** 2
+            t = z / torch.sqrt(c2 / nu)
+            t = t * math.sqrt((nu - 2.0) / nu) * (1.0 / math.sqrt(fan_in))        # unit-variance t, then the fan-in scale
+            rows = torch.randperm(shape[0], generator=g)[:min(n_outlier, shape[0])]
+            t[rows] *= outlier
+            out[k] = t
+        elif k.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+            idx = torch.randperm(shape[0], generator=g)[:min(n_outlier, shape[0])]
+            w[idx] *= outlier
+            out[k] = w
+        else:
+            out[k] = 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+    return out
+
+
 def seeded_input(name: str, shape, seed: int, kind: str = "normal") -> torch.Tensor:
     g = torch.Generator(device="cpu")
     g.manual_seed((seed * 7919 + zlib.crc32(name.encode())) % (2 ** 63 - 1))

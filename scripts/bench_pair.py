@@ -155,7 +155,7 @@ def trace(B=32):
 
 def phases(B=32):
     """Attention phase and FFN phase INSIDE a pair launch (the trace build: prediff_amd/libprediff_hip_trace.so via PD_LIB_PATH; clock
-    stamps of wave 0 of workgroup 7 at tile start / attention done / FFN done, 24 stamps per tile), for the three axial layers of both
+    stamps of wave 0 of workgroup 7 at tile start / attention done / FFN done, three per tile), for the three axial layers of both
     levels at B trajectories.  Prints ONE JSON line: per layer the launch time (HIP events, untraced repeats), the share of the
     workgroup's tile time spent between `tile start` and `attention done` (LayerNorm-1, q/k/v, softmax, P.V, proj, residual) and between
     `attention done` and `FFN done` (LayerNorm-2, FFN-1, GELU, FFN-2, residual), and what each phase's FLOPs over its share of the launch
@@ -182,12 +182,12 @@ def phases(B=32):
             run(L.CallOpts(os.environ.get("PD_OPERAND", "bf16"), pair_form=OPTS.pair_form, trace=tr.data_ptr()))
             torch.cuda.synchronize()
             t = [v for v in tr.cpu().tolist() if v]
-            per = 24                                   # stamps per tile: start, LN1, 4 x (q, k, softmax, PV), attention done, LN2, W1_0, W1_1, FFN loop, FFN done
+            per = 3                                    # stamps per tile (the -DPD_PAIR_TRACE=1 build): tile start, attention done, FFN done
             tiles = len(t) // per
             if tiles == 0 or len(t) % per:
-                raise SystemExit(f"{len(t)} clock stamps (want a multiple of {per}): is PD_LIB_PATH the -DPD_PAIR_DEBUG=1 build (libprediff_hip_trace.so)?")
-            att = sum(t[i * per + 18] - t[i * per] for i in range(tiles))
-            ffn = sum(t[i * per + 23] - t[i * per + 18] for i in range(tiles))
+                raise SystemExit(f"{len(t)} clock stamps (want a multiple of {per}): is PD_LIB_PATH the -DPD_PAIR_TRACE=1 build (libprediff_hip_trace.so)?")
+            att = sum(t[i * per + 1] - t[i * per] for i in range(tiles))
+            ffn = sum(t[i * per + 2] - t[i * per + 1] for i in range(tiles))
             gaps = (t[tiles * per - 1] - t[0]) - att - ffn       # between FFN done of a tile and the next tile's start (row stores / loads)
             sh_a = att / (att + ffn + gaps)
             sh_f = ffn / (att + ffn + gaps)

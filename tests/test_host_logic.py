@@ -342,3 +342,31 @@ def test_scale_by_std_registers_the_reference_buffer():
     assert float(a.scale_factor) == 0.25
     z = torch.ones(2, 3)
     assert torch.equal(a.get_first_stage_encoding(z), 0.25 * z)
+
+
+def test_modules_deepcopy_and_pickle():
+    """A module that owns a pd_call_opts struct stays deepcopy- / pickle-able (EMA by deepcopy, DDP spawn, torch.save(module)):
+    ctypes refuses structures with pointer members, so CallOpts serialises its integer members and drops the profiling pointer."""
+    import copy
+    import io
+    import pickle
+    import torch
+    from prediff_amd import _lib as L
+    from prediff_amd.autoencoder_kl import AutoencoderKL
+    from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet
+    from _cases import TINY_UNET_CFGS, TINY_VAE_CFG
+    o = L.CallOpts("fp16", pair_form=2, igemm_tile=3, trace=1234)
+    for c in (copy.deepcopy(o), pickle.loads(pickle.dumps(o))):
+        assert c._state() == o._state() and c.operand == 1 and c.igemm_tile == 3 and not c.trace
+    assert o.replace(small_grid=1).small_grid == 1 and o.small_grid == 0 and o.replace().trace == 1234
+    net = CuboidTransformerUNet(**TINY_UNET_CFGS["axial"], precision="fp16")
+    vae = AutoencoderKL(**TINY_VAE_CFG, precision="bf16")
+    for m in (net, vae):
+        m2 = copy.deepcopy(m)
+        assert m2.opts is not m.opts and m2.opts._state() == m.opts._state()
+        assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        m3 = torch.load(buf, weights_only=False)
+        assert m3.opts._state() == m.opts._state() and list(m3.state_dict()) == list(m.state_dict())
