@@ -108,6 +108,11 @@ typedef struct pd_igemm_args {
   int32_t disable_256;     /* A/B: != 0 = never hand this launch to the 256 x 256 kernel */
   int32_t min_k_256;       /* A/B: smallest K (taps * Cin) of a launch the automatic choice gives to the 256 x 256 kernel; 0 = default (1024) */
   int32_t splitk_max_tiles;/* A/B: split-K only for grids of at most this many 256 x 256 tiles; 0 = default (128), < 0 = never split */
+  int32_t w_fold;          /* ABI 4.  f > 0: TWO weight products per filter tap (precision="fp16x2": W = W_hi + W_lo in the 16-bit operand type,
+                              the activations rounded once) -- `taps` = 2 f, W holds the f taps of W_hi followed by the f taps of W_lo, and the
+                              K loop walks the activation gather of tap (t mod f) against weight slab t: D = A W_hi^T + A W_lo^T in one fp32
+                              accumulator.  f = KT * KH * KW (1 for a row-wise linear layer).  0: one product (taps = KT * KH * KW) */
+  int32_t reserved0;
 } pd_igemm_args;
 int pd_igemm(const pd_igemm_args* a, pd_stream_t stream);
 
@@ -206,7 +211,10 @@ typedef struct pd_cuboid_attn_args {
                                 is a nearest-neighbour resize of the tokens (several slots read one token) and the un-padding resizes back
                                 (models/utils.py:228-270).  Runs on the generic core. */
   int32_t operand;           /* enum pd_operand: type of qkv_bf16 / out_bf16 (MFMA cores; the generic core reads either) */
-  int32_t reserved;
+  int32_t qkv_fp8_log2;      /* k > 0 (ABI 4; MFMA core, cuboid volume <= 64, head_dim % 32 == 0): qkv_bf16 points to OCP e4m3 BYTES holding
+                                q, k, v * 2^k (ld_qkv counts bytes) -- what an fp8 pd_igemm launch writes with out_fp8_log2 = k; q k^T and attn v
+                                then run on the fp8 MFMA (probabilities as e4m3(P * 256)), fp32 scores / softmax / accumulation
+                                (BASELINE.json configs[4]; cuboid_transformer.py:849-861,947-952).  0: 16-bit / fp32 q, k, v */
 } pd_cuboid_attn_args;
 int pd_cuboid_attention(const pd_cuboid_attn_args* a, pd_stream_t stream);
 

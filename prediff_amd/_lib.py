@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PD_LIB_PATH: another build of the same library (A/B of compiler flags); the default is the in-tree build
 LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libprediff_hip.so")
 
-ABI_VERSION = 3          # pd_abi_version() of the library this binding was written for
+ABI_VERSION = 4          # pd_abi_version() of the library this binding was written for
 
 ACT = {"none": 0, None: 0, "identity": 0, "gelu": 1, "silu": 2, "leaky": 3, "relu": 4}
 
@@ -35,7 +35,8 @@ class IgemmArgs(C.Structure):
                  "rows_per_sample", "ld_rowvec", "ld_res", "res_period", "ld_mul", "act", "ld_out", "ld_outb", "split")] + \
                [("alpha", C.c_float), ("tile", C.c_int32), ("vec_epilogue", C.c_int32), ("a_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("debug_flags", C.c_int32), ("ksplit", C.c_int32),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_elems", C.c_int64), ("fp8", C.c_int32), ("out_fp8_log2", C.c_int32),
-                ("operand", C.c_int32), ("disable_256", C.c_int32), ("min_k_256", C.c_int32), ("splitk_max_tiles", C.c_int32)]
+                ("operand", C.c_int32), ("disable_256", C.c_int32), ("min_k_256", C.c_int32), ("splitk_max_tiles", C.c_int32),
+                ("w_fold", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class CuboidAttnArgs(C.Structure):
@@ -43,7 +44,7 @@ class CuboidAttnArgs(C.Structure):
                 ("qkv_bf16", "qkv_f32", "tok_index", "bias", "mask", "out_bf16", "out_bf16_lo", "out_f32")] + \
                [(n, C.c_int32) for n in ("B", "ntok", "C", "heads", "nc", "vol", "ld_qkv", "ld_out")] + \
                [("scale", C.c_float), ("force_generic", C.c_int32), ("out_fp8_log2", C.c_int32), ("tok_out", C.c_void_p),
-                ("operand", C.c_int32), ("reserved", C.c_int32)]
+                ("operand", C.c_int32), ("qkv_fp8_log2", C.c_int32)]
 
 
 OPERAND = {"bf16": 0, "fp16": 1}            # enum pd_operand
@@ -228,9 +229,18 @@ def igemm(A, W, *, M, N, Cin, lda=None, ldw=None, taps=1, w_tap_stride=0, geom=N
     a.a_batch_stride, a.w_batch_stride = a_batch_stride, w_batch_stride
     a.out_batch_stride, a.outb_batch_stride, a.res_batch_stride = out_batch_stride, outb_batch_stride, res_batch_stride
     a.w_tap_stride = w_tap_stride
-    a.nbatch, a.M, a.N, a.Cin, a.taps = nbatch, M, N, Cin, taps
     a.lda = lda if lda is not None else Cin
     a.ldw = ldw if ldw is not None else Cin
+    if getattr(W, "_pd_fold", False):
+        # packing.fold_weights: W = the `taps` slabs of W_hi followed by the `taps` slabs of W_lo -- two weight products per tap against one
+        # activation gather (precision="fp16x2"); the caller describes the layer as it would for a single product
+        if A_lo is not None or W_lo is not None or fp8:
+            raise PrediffHipError("pd_igemm: folded (hi + lo) weights go with single-rounded 16-bit activations only")
+        a.w_fold = taps
+        w_tap_stride = w_tap_stride or N * a.ldw
+        a.w_tap_stride = w_tap_stride
+        taps = 2 * taps
+    a.nbatch, a.M, a.N, a.Cin, a.taps = nbatch, M, N, Cin, taps
     if geom is None:
         geom = dict(B=1, Ti=1, Hi=1, Wi=M, To=1, Ho=1, Wo=M, KT=1, KH=1, KW=1, st=1, sh=1, sw=1, pt=0, ph=0, pw=0,
                     ut=1, uh=1, uw=1)
@@ -333,9 +343,10 @@ def cast_rows(x, out, out_lo, n_samples, rows_in, row_off, rows_out, Cn, ld_in, 
 
 def cuboid_attention(*, qkv_bf16=None, qkv_f32=None, tok_index, bias, mask, out_bf16=None, out_bf16_lo=None,
                      out_f32=None, B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out, scale, force_generic=False, out_fp8_log2=0, tok_out=None,
-                     opts=None):
+                     qkv_fp8_log2=0, opts=None):
     a = CuboidAttnArgs()
-    a.operand = opts.operand if opts is not None else 0
+    a.operand = 0 if qkv_fp8_log2 else (opts.operand if opts is not None else 0)
+    a.qkv_fp8_log2 = qkv_fp8_log2     # k > 0: qkv_bf16 is an e4m3 byte tensor holding q, k, v * 2^k; q k^T and attn v run on the fp8 MFMA
     a.qkv_bf16, a.qkv_f32, a.tok_index, a.bias, a.mask = ptr(qkv_bf16), ptr(qkv_f32), ptr(tok_index), ptr(bias), ptr(mask)
     a.out_bf16, a.out_bf16_lo, a.out_f32 = ptr(out_bf16), ptr(out_bf16_lo), ptr(out_f32)
     a.B, a.ntok, a.C, a.heads, a.nc, a.vol, a.ld_qkv, a.ld_out = B, ntok, Cn, heads, nc, vol, ld_qkv, ld_out

@@ -156,6 +156,138 @@ __global__ void __launch_bounds__(256) cuboid_attn_mfma_kernel(const pd_cuboid_a
   }
 }
 
+// ------------------------------------------------------------------------------------------------- e4m3 core (precision="fp8")
+// The same core with OCP e4m3 q / k / v (bytes, value * 2^qk): S^T = K Q^T on v_mfma_f32_16x16x32_fp8_fp8 (8 bytes of one row per lane:
+// the bf16 core's operand geometry at half the bytes), the probabilities as e4m3(P * 256) (P in [0, 1]: 2^8 keeps 2^-17 above the
+// subnormal floor and 256 below the format's 448), and O^T = V^T P^T over 32 keys per MFMA.  BASELINE.json configs[4] ("fp8 MFMA
+// attention"): the reference's q k^T and attn v products (cuboid_transformer.py:849-861, 947-952) on e4m3 operands.  A dot product
+// does not care in which order it sums: MFMA position (g, j) of the 32-key block kb stands for key  kb * 32 + (j < 4 ? 4 g + j :
+// 16 + 4 g + j - 4)  -- exactly the keys whose scores the lane already holds in the C layout of the two S^T tiles (no cross-lane
+// movement of P); the V bytes are gathered with the same assignment.  fp32 scores, softmax and accumulation; q / k / v halve the
+// core's HBM bytes (it is a 2 flop / B kernel).  Only in the bf16 translation unit: e4m3 does not depend on the 16-bit operand type.
+#if !PD_IS_F16
+template <int KT>
+__global__ void __launch_bounds__(256) cuboid_attn_mfma_fp8_kernel(const pd_cuboid_attn_args p) {
+  constexpr int KB = (KT + 1) / 2;                                       // 32-key blocks
+  const int lane = threadIdx.x & 63;
+  const int QT = (p.vol + 15) >> 4;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (((b * nc) + c) * heads + h) * QT + qt
+  const int64_t nitems = (int64_t)p.B * p.nc * p.heads * QT;
+  if (item >= nitems) return;
+  const int qt = (int)(item % QT);
+  const int64_t it2 = item / QT;
+  const int h = (int)(it2 % p.heads);
+  const int c = (int)((it2 / p.heads) % p.nc);
+  const int b = (int)(it2 / ((int64_t)p.heads * p.nc));
+  const int hd = p.C / p.heads;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int vol = p.vol;
+  const int query = qt * 16 + l16;
+  const int qtok = query < vol ? p.tok_index[c * vol + query] : -1;
+  const uint8_t* base = (const uint8_t*)p.qkv_bf16 + (int64_t)b * p.ntok * p.ld_qkv + h * hd;
+  const uint8_t* qrow = base + (int64_t)(qtok >= 0 ? qtok : 0) * p.ld_qkv;
+
+  f32x4 s[2 * KB];
+  int ktok[2 * KB];
+#pragma unroll
+  for (int kt = 0; kt < 2 * KB; ++kt) {
+    const int key = kt * 16 + l16;
+    ktok[kt] = (kt < KT && key < vol) ? p.tok_index[c * vol + key] : -1;
+    s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int d0 = 0; d0 < hd; d0 += 32) {
+    long qf = 0;
+    if (qtok >= 0) qf = *(const long*)(qrow + d0 + 8 * g);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      long kf = 0;
+      if (ktok[kt] >= 0) kf = *(const long*)(base + (int64_t)ktok[kt] * p.ld_qkv + p.C + d0 + 8 * g);
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kf, qf, s[kt], 0, 0, 0);
+    }
+  }
+  // lane: query `query`, keys kt*16 + 4g .. +3; q and k both carry 2^qk
+  const float sscale = p.scale * __builtin_amdgcn_ldexpf(1.0f, -2 * p.qkv_fp8_log2);
+  float sc[2 * KB][4];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < 2 * KB; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      float v = -INFINITY;
+      if (kt < KT && key < vol && query < vol) {
+        v = s[kt][r] * sscale + p.bias[((int64_t)h * vol + query) * vol + key];
+        if (p.mask && !p.mask[((int64_t)c * vol + query) * vol + key]) v = -1e18f;
+      }
+      sc[kt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = attn_rows4_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2 * KB; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = expf(sc[kt][r] - mx);   // exp(-inf) = 0 for non-existent keys
+      sum += e;
+      s[kt][r] = e;
+    }
+  sum = attn_rows4_sum(sum);
+  const float inv = sum > 0.f ? 256.f / sum : 0.f;                       // P * 2^8 -> e4m3 (<= 256 < 448: no saturation needed)
+  long pf[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kt = 2 * kb + (j >> 2), r = j & 3;
+      v[j] = s[kt][r] * inv;
+      if (sc[kt][r] <= -1e18f) v[j] = 0.f;   // masked_softmax multiplies by the mask after the softmax
+    }
+    int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
+    int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
+    pf[kb] = (long)(((unsigned long long)(uint32_t)w1 << 32) | (unsigned long long)(uint32_t)w0);
+  }
+
+  // ---- O^T[d][query] = sum_key V[key][d] P[query][key]: A = V^T, lane (l16, g) holds V[key(g, j)][d0 + l16], j = 0..7 ----
+  int vtok[KB][8];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kt = 2 * kb + (j >> 2), key = kt * 16 + 4 * g + (j & 3);
+      vtok[kb][j] = (kt < KT && key < vol) ? p.tok_index[c * vol + key] : -1;
+    }
+  const uint8_t* vbase = base + 2 * p.C + l16;
+  const float oscale = __builtin_amdgcn_ldexpf(1.0f, -8 - p.qkv_fp8_log2);          // P carries 2^8, v carries 2^qk
+  for (int d0 = 0; d0 < hd; d0 += 16) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      unsigned long long vf = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (vtok[kb][j] >= 0) vf |= (unsigned long long)vbase[(int64_t)vtok[kb][j] * p.ld_qkv + d0] << (8 * j);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)vf, pf[kb], o, 0, 0, 0);
+    }
+    // lane: query, d = d0 + 4g + r
+    if (qtok >= 0) {
+      if (p.out_fp8_log2 > 0) {         // e4m3 bytes, value * 2^k, saturating: the A operand of an fp8 proj launch
+        const float f8s = oscale * __builtin_amdgcn_ldexpf(1.0f, p.out_fp8_log2);
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o[0] * f8s, -448.f), 448.f), fminf(fmaxf(o[1] * f8s, -448.f), 448.f), 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o[2] * f8s, -448.f), 448.f), fminf(fmaxf(o[3] * f8s, -448.f), 448.f), w, true);
+        *(int*)((uint8_t*)p.out_bf16 + ((int64_t)b * p.ntok + qtok) * p.ld_out + h * hd + 4 * g + d0) = w;
+      } else {
+        pd_bf16* orow = p.out_bf16 + ((int64_t)b * p.ntok + qtok) * p.ld_out + h * hd + 4 * g;
+        *(uint2*)(orow + d0) = make_uint2(pack_op2(o[0] * oscale, o[1] * oscale), pack_op2(o[2] * oscale, o[3] * oscale));
+      }
+    }
+  }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------- large cuboids (volume > 64)
 // Patterns whose cuboids span the whole grid or a whole frame ("full": 13 x 16 x 16 = 3328 slots; "divided_st": 1 x 16 x 16 = 256;
 // cuboid_transformer_patterns.py:11-16,53-58).  One wave per (sample, cuboid, head, tile of 16 queries) walks the key tiles of 16
@@ -360,6 +492,26 @@ extern "C" int PD_ENTRY(cuboid_attention)(const pd_cuboid_attn_args* pa, pd_stre
   if (a.out_fp8_log2 > 0 && !mfma_ok) {
     pd_set_error("pd_cuboid_attention: an e4m3 output is built for the MFMA cores only (bf16 q/k/v, cuboid volume <= 64, head_dim %% 32 == 0, out_bf16 alone)");
     return PD_ERR_UNSUPPORTED;
+  }
+  if (a.qkv_fp8_log2 > 0) {
+#if !PD_IS_F16
+    // e4m3 q / k / v (precision="fp8"): qkv_bf16 points to BYTES, ld_qkv counts bytes; the 16-bit output (if any) is bfloat16
+    PD_CHECK_ARG(mfma_ok && !a.qkv_f32, "pd_cuboid_attention: e4m3 q/k/v run on the MFMA core only (cuboid volume <= 64, head_dim %% 32 == 0, "
+                 "out_bf16 alone, no separate output token table)");
+    const int kt = (a.vol + 15) / 16;
+    const dim3 grid((unsigned)((nitems * kt + 3) / 4));
+    switch (kt) {
+      case 1: hipLaunchKernelGGL(cuboid_attn_mfma_fp8_kernel<1>, grid, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(cuboid_attn_mfma_fp8_kernel<2>, grid, dim3(256), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(cuboid_attn_mfma_fp8_kernel<3>, grid, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(cuboid_attn_mfma_fp8_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
+    PD_CHECK_LAUNCH();
+    return PD_OK;
+#else
+    pd_set_error("pd_cuboid_attention: e4m3 q/k/v belong to the bfloat16 engine (operand = PD_OPERAND_BF16)");
+    return PD_ERR_UNSUPPORTED;
+#endif
   }
   if (mfma_ok) {
     const int kt = (a.vol + 15) / 16;

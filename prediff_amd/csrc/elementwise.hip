@@ -10,7 +10,7 @@ extern "C" void pd_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* pd_last_error(void) { return g_err; }
-extern "C" int pd_abi_version(void) { return 3; }   // 2: per-call options (pd_call_opts), IEEE-half operand builds, no exported data symbols; 3: pd_call_opts.small_grid
+extern "C" int pd_abi_version(void) { return 4; }   // 2: per-call options (pd_call_opts), IEEE-half operand builds, no exported data symbols; 3: pd_call_opts.small_grid; 4: pd_cuboid_attn_args.qkv_fp8_log2 (was reserved)
 extern "C" int pd_sizeof_igemm_args(void) { return (int)sizeof(pd_igemm_args); }
 extern "C" int pd_sizeof_cuboid_attn_args(void) { return (int)sizeof(pd_cuboid_attn_args); }
 extern "C" int pd_sizeof_call_opts(void) { return (int)sizeof(pd_call_opts); }

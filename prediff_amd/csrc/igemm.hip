@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_kernel(const pd_igemm_args p) 
   const int khw = p.KH * p.KW;
 
   auto set_tap = [&](int tap) {
+    if (p.w_fold > 0 && tap >= p.w_fold) tap -= p.w_fold;     // the W_lo slabs walk the same activation gather as the W_hi slabs
     const int kt = tap / khw, r = tap - kt * khw;
     const int kh = r / p.KW, kw = r - kh * p.KW;
 #pragma unroll
@@ -297,7 +298,9 @@ extern "C" int PD_ENTRY(igemm)(const pd_igemm_args* pa, pd_stream_t stream) {
   PD_CHECK_ARG(a.M > 0 && a.N > 0 && a.taps > 0, "pd_igemm: bad M/N/taps (%d,%d,%d)", a.M, a.N, a.taps);
   PD_CHECK_ARG(a.Cin > 0 && (a.Cin & 63) == 0, "pd_igemm: Cin=%d must be a positive multiple of 64 (zero padded)", a.Cin);
   PD_CHECK_ARG((a.lda & 7) == 0 && (a.ldw & 7) == 0, "pd_igemm: lda/ldw must be multiples of 8 (16 B rows)");
-  PD_CHECK_ARG(a.taps == a.KT * a.KH * a.KW, "pd_igemm: taps != KT*KH*KW");
+  PD_CHECK_ARG(a.w_fold >= 0 && (a.w_fold == 0 || (!a.split && !a.fp8 && a.taps == 2 * a.w_fold)),
+               "pd_igemm: w_fold = %d needs taps = 2 w_fold (W_hi slabs then W_lo slabs), no hi/lo split, no e4m3 operands", a.w_fold);
+  PD_CHECK_ARG((a.w_fold ? a.w_fold : a.taps) == a.KT * a.KH * a.KW, "pd_igemm: taps != KT*KH*KW");
   PD_CHECK_ARG((int64_t)a.B * a.To * a.Ho * a.Wo == a.M, "pd_igemm: M != B*To*Ho*Wo");
   PD_CHECK_ARG((a.ut == 1 || a.ut == 2) && (a.uh == 1 || a.uh == 2) && (a.uw == 1 || a.uw == 2), "pd_igemm: bad upsample");
   if (a.fp8) {
@@ -330,7 +333,7 @@ extern "C" int PD_ENTRY(igemm)(const pd_igemm_args* pa, pd_stream_t stream) {
   }
   int tile = a.tile;
   // a 1-tap, stride-1, unpadded, un-upsampled "convolution" is a plain row-wise linear layer: row m reads A row m
-  const bool pointwise = a.taps == 1 && a.st == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.ph == 0 && a.pw == 0 && a.ut == 1 &&
+  const bool pointwise = (a.taps == 1 || a.w_fold == 1) && a.st == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.ph == 0 && a.pw == 0 && a.ut == 1 &&
                          a.uh == 1 && a.uw == 1 && a.Ti == a.To && a.Hi == a.Ho && a.Wi == a.Wo && a.vT <= 0 && a.vH <= 0 && a.vW <= 0;
   const int kind = pointwise ? 0 : ((a.KT == 1 && a.Ti == 1 && a.To == 1) ? 1 : 2);
   a.ksplit = 1;

@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   // so 2 of 13 tiles drop 9 of their 27 taps -- the zero-padding taps are left out of both DMA streams and of the MFMA loop instead of
   // being streamed as zero rows (bit `tap` of tap_skip; debug_flags bit 8 keeps the dense loop for A/B runs).
   uint32_t tap_skip = 0;
-  if (KIND == 2 && !SK && p.KT > 1 && p.ut == 1 && p.vT <= 0 && p.taps < 32 && khw < 32 && !(p.debug_flags & 8)) {   // (< 32: `tap_skip >> taps` stays a defined shift)
+  if (KIND == 2 && !SK && p.KT > 1 && p.ut == 1 && p.vT <= 0 && p.taps < 32 && khw < 32 && p.w_fold == 0 && !(p.debug_flags & 8)) {   // (< 32: `tap_skip >> taps` stays a defined shift)
     const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
     const int m_last = min(p.M, m0 + BM) - 1;
     const int b_first = m0 / thw_o;
@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 
   const int vT = p.vT > 0 ? p.vT : p.Ti * p.ut, vH = p.vH > 0 ? p.vH : p.Hi * p.uh, vW = p.vW > 0 ? p.vW : p.Wi * p.uw;
   auto set_tap = [&](int hh, int tap) {
+    if (p.w_fold > 0 && tap >= p.w_fold) tap -= p.w_fold;     // the W_lo slabs walk the same activation gather as the W_hi slabs
     const int kt = tap / khw, r = tap - kt * khw;
     const int kh = r / p.KW, kw = r - kh * p.KW;
 #pragma unroll

@@ -38,16 +38,29 @@ def split_bf16(x: torch.Tensor, want_lo: bool, dtype=torch.bfloat16) -> Tuple[to
     return both[0], both[1]
 
 
-def pack_linear(weight: torch.Tensor, split: bool, k_pad: Optional[int] = None, dtype=torch.bfloat16):
+def fold_weights(w: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
+    """fp32 packed weights (taps, N, Kp) -> (2 taps, N, Kp) 16-bit operands: the slabs of W_hi = round(w) followed by the slabs of
+    W_lo = round(w - W_hi) -- pd_igemm_args.w_fold (precision="fp16x2": D = A W_hi^T + A W_lo^T, the weights exact to ~2^-22, the
+    activations rounded once).  The returned tensor is tagged `_pd_fold` for prediff_amd._lib.igemm."""
+    hi = to_operand(w, dtype)
+    lo = to_operand(w - hi.float(), dtype)
+    out = torch.cat([hi, lo], dim=0).contiguous()
+    out._pd_fold = True
+    return out
+
+
+def pack_linear(weight: torch.Tensor, split: bool, k_pad: Optional[int] = None, dtype=torch.bfloat16, fold: bool = False):
     """nn.Linear weight (N, K) -> 16-bit operands (N, Kp)."""
     N, K = weight.shape
     Kp = k_pad if k_pad is not None else pad64(K)
     w = torch.zeros(N, Kp, dtype=torch.float32, device=weight.device)
     w[:, :K] = weight.detach().float()
+    if fold:
+        return fold_weights(w[None], dtype), None
     return split_bf16(w, split, dtype)
 
 
-def pack_conv(weight: torch.Tensor, split: bool, c_pad: Optional[int] = None, dtype=torch.bfloat16):
+def pack_conv(weight: torch.Tensor, split: bool, c_pad: Optional[int] = None, dtype=torch.bfloat16, fold: bool = False):
     """Conv weight (N, C, *kernel) -> 16-bit operands (taps, N, Cp) with taps enumerated kernel-index-major (kt, kh, kw)."""
     N, Cn = weight.shape[:2]
     taps = 1
@@ -56,6 +69,8 @@ def pack_conv(weight: torch.Tensor, split: bool, c_pad: Optional[int] = None, dt
     Cp = c_pad if c_pad is not None else pad64(Cn)
     w = torch.zeros(taps, N, Cp, dtype=torch.float32, device=weight.device)
     w[:, :, :Cn] = weight.detach().float().reshape(N, Cn, taps).permute(2, 0, 1)
+    if fold:
+        return fold_weights(w, dtype), None
     return split_bf16(w, split, dtype)
 
 

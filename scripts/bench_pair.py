@@ -178,6 +178,9 @@ def phases(B=32):
             run = lambda o: L.attn_ffn_pair(x, x, ws, vecs, tok, B, ntok, nc, vol, (Cn // heads) ** -0.5, tok_affine=tabs["affine"], units=Cn, opts=o)
             us = timeit(lambda: run(OPTS))
             x.normal_()
+            if os.environ.get("PD_PHASES_TIME_ONLY"):     # the same micro-benchmark on the PRODUCT library: the reference duration of the trace build's
+                out["layers"].append({"units": Cn, "cuboid": list(cuboid), "launch_us": round(us, 1)})
+                continue
             tr = torch.zeros(256, dtype=torch.int64, device=DEV)
             run(L.CallOpts(os.environ.get("PD_OPERAND", "bf16"), pair_form=OPTS.pair_form, trace=tr.data_ptr()))
             torch.cuda.synchronize()

@@ -110,7 +110,7 @@ def test_v1_ddim50_vs_oracle():
     t_cpu = time.time() - t0
     ref = traj[-1]
     errs = {}
-    for precision in ("fp32", "fp16", "bf16", "fp8_conv", "fp8"):
+    for precision in ("fp32", "fp16x2", "fp16", "bf16", "fp8_conv", "fp8"):
         ldm = _v1_ldm(precision)
         out, inter = ldm.sample(cond=zc.cuda(), batch_size=B, sampler="ddim", ddim_steps=50, eta=0.0, x_T=xT.cuda(),
                                 return_decoded=False, return_intermediates=True)
@@ -121,18 +121,60 @@ def test_v1_ddim50_vs_oracle():
         out2 = ldm.sample(cond=zc.cuda(), batch_size=B, sampler="ddim", ddim_steps=50, eta=0.0, x_T=xT.cuda(), return_decoded=False)
         assert torch.equal(out2, out)
         del ldm
-    print(f"[v1 DDIM-50] rel-L2 vs oracle loop after 50 steps: fp32 {errs['fp32']:.3e}, fp16 (IEEE-half operands: the TF32 class) {errs['fp16']:.3e} "
+    print(f"[v1 DDIM-50] rel-L2 vs oracle loop after 50 steps: fp32 {errs['fp32']:.3e}, fp16x2 (fp16 activations x hi+lo fp16 weights) {errs['fp16x2']:.3e} "
+          f"by step {errs['fp16x2_by_step']}, fp16 (IEEE-half operands: the TF32 class) {errs['fp16']:.3e} "
           f"by step {errs['fp16_by_step']}, bf16 {errs['bf16']:.3e}, fp8_conv (e4m3 Conv3d) "
           f"{errs['fp8_conv']:.3e}, fp8 (e4m3 Conv3d + K >= 512 linears) {errs['fp8']:.3e}; by step (1,10,25,40,50): fp32 {errs['fp32_by_step']} "
           f"bf16 {errs['bf16_by_step']} fp8_conv {errs['fp8_conv_by_step']} fp8 {errs['fp8_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
     _report("v1_ddim50", oracle_cpu_s=round(t_cpu, 1), **errs)
     assert errs["fp32"] < 1e-3
+    # IEEE-half activations x (hi + lo) IEEE-half weights, two MFMA products: the north-star bar with a single-pass activation path
+    # (measured 4e-4: the fp16 engine's 1.3e-3 minus its weight-rounding term, test_v1_fp16_error_budget)
+    assert errs["fp16x2"] < 1e-3 and errs["fp16x2"] < 0.5 * errs["fp16"]
     # IEEE-half operands: 8x finer significands than bf16 (expected ~1.2e-3 where bf16 measures 1.0e-2); the bar below is 2x that
     assert errs["fp16"] < 2.5e-3 and errs["fp16"] < 0.3 * errs["bf16"]
     # guard rails at 2x what is measured (bf16 1.0e-2, fp8 3.8e-2 after all 50 steps: DESIGN.md §4), so that a regression shows
     assert errs["bf16"] < 2e-2 and np.isfinite(errs["bf16"])
     assert errs["fp8_conv"] < 8e-2 and np.isfinite(errs["fp8_conv"])          # report-only operand types (BASELINE config 5): measured
     assert errs["fp8"] < 0.16 and np.isfinite(errs["fp8"])                    # 3.8e-2 (convolutions) / 9.2e-2 (+ the level-1 linears)
+
+
+def test_v1_fp16_error_budget():
+    """Where the fp16 engine's DDIM-50 error (1.3e-3: just over the 1e-3 bar) comes from -- the measurement behind precision="fp16x2"
+    ("a <= 1e-3 engine that is not 3x slower").  The oracle loop is run a second time with every matrix / filter
+    rounded to IEEE half exactly as the engine's weight packs round them: against THAT loop the engine's deviation contains no
+    weight-rounding term -- it is what an engine with exact weights measures against the true oracle -- and the two oracle loops
+    against each other give the weight term alone (fp32 arithmetic on rounded weights)."""
+    B = 1
+    sd = _v1_unet_sd()
+    sd16 = {k: (v.half().float() if (torch.is_floating_point(v) and v.dim() >= 2) else v) for k, v in sd.items()}
+    zc = seeded_input("d50c", (B, 7, 16, 16, 64), 21)
+    xT = seeded_input("d50x", (B, 6, 16, 16, 64), 22)
+    tape = [xT] + [torch.zeros_like(xT)] * 50
+    ac = np.cumprod(1.0 - OD.beta_schedule("linear", 1000)).astype(np.float32)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 32))
+    try:
+        with torch.no_grad():
+            ref = OD.ddim_sample_loop(ac, lambda z, t, c: OU.unet_forward(sd, V1_UNET_CFG, z, t, c), zc, tape, 50, eta=0.0)
+            ref16 = OD.ddim_sample_loop(ac, lambda z, t, c: OU.unet_forward(sd16, V1_UNET_CFG, z, t, c), zc, tape, 50, eta=0.0)
+    finally:
+        torch.set_num_threads(nthr)
+    ldm = _v1_ldm("fp16")
+    out, inter = ldm.sample(cond=zc.cuda(), batch_size=B, sampler="ddim", ddim_steps=50, eta=0.0, x_T=xT.cuda(), return_decoded=False,
+                            return_intermediates=True)
+    steps = (1, 10, 25, 40, 50)
+    e_true = [rel_l2(inter[k], ref[k]) for k in steps]             # activation + weight rounding
+    e_w16 = [rel_l2(inter[k], ref16[k]) for k in steps]            # activation rounding only (the oracle shares the rounded weights)
+    e_wonly = [rel_l2(ref16[k], ref[k]) for k in steps]            # weight rounding only (fp32 arithmetic on rounded weights)
+    print(f"[v1 DDIM-50 fp16 budget] by step {steps}: engine vs oracle {[f'{e:.2e}' for e in e_true]}; engine vs oracle-on-fp16-weights "
+          f"(activation term) {[f'{e:.2e}' for e in e_w16]}; oracle-on-fp16-weights vs oracle (weight term) {[f'{e:.2e}' for e in e_wonly]}")
+    _report("v1_fp16_error_budget", steps=list(steps), engine_vs_oracle=e_true, activation_term=e_w16, weight_term=e_wonly)
+    assert e_true[-1] < 2.5e-3
+    # measured (round 6): 1.31e-3 = 3.9e-4 (activations: fresh rounding noise at every step) (+) 1.28e-3 (weights: ONE fixed perturbation of the
+    # network, the same bias at each of the 50 steps) -- the weight term dominates and grows with the step count, the activation term does
+    # not.  Hence precision="fp16x2": exact (hi + lo) weights, once-rounded activations, two products.
+    assert e_w16[-1] < 0.5 * e_true[-1] and e_w16[-1] < 1e-3 and e_wonly[-1] > e_w16[-1]
 
 
 @pytest.mark.parametrize("kind", ["zeros", "sparse90"])
@@ -384,6 +426,9 @@ def test_v1_aligned_chain_100():
           f"bf16 {errs['bf16']:.3e} {errs['bf16_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
     _report("v1_aligned_chain_100", oracle_cpu_s=round(t_cpu, 1), **errs)
     assert errs["fp32"] < 1e-3
+    # IEEE-half activations x (hi + lo) IEEE-half weights, two MFMA products: the north-star bar with a single-pass activation path
+    # (measured 4e-4: the fp16 engine's 1.3e-3 minus its weight-rounding term, test_v1_fp16_error_budget)
+    assert errs["fp16x2"] < 1e-3 and errs["fp16x2"] < 0.5 * errs["fp16"]
     assert errs["bf16"] < 5e-2 and np.isfinite(errs["bf16"])
 
 

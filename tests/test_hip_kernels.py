@@ -67,6 +67,63 @@ def test_igemm_linear(M, N, K, tile, split):
     assert rel_l2(outb.float(), ref) < 4e-3      # bf16 output rounding
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(3328, 768, 256, 0), (3328, 768, 256, 3), (26624, 512, 2048, 0), (1000, 200, 96, 4), (300, 130, 64, 7),
+                                        (512, 2048, 512, 7), (209, 256, 64, 0)])
+def test_igemm_linear_folded_weights(M, N, K, tile):
+    """pd_igemm_args.w_fold (precision="fp16x2"): D = A W_hi^T + A W_lo^T with IEEE-half operands -- the activations rounded once, the
+    weights exact to ~2^-22 -- against the fp32 product ON THE SAME rounded activations (what is left: fp32 summation order and the
+    2^-22 tail of the weights) and against the one-product fp16 launch (which carries the 2^-12 weight rounding the fold removes)."""
+    from prediff_amd.packing import pack_linear as PL
+    g = torch.Generator(device="cpu").manual_seed(M + 5 * N + K)
+    x = (torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.arange(N)[:, None] * 1e-3).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    Kp = (K + 63) // 64 * 64
+    a16 = torch.zeros(M, Kp, dtype=torch.float16, device=DEV)
+    a16[:, :K] = x.half()
+    opts = L.CallOpts("fp16")
+    wf, _ = PL(w, False, dtype=torch.float16, fold=True)
+    w1, _ = PL(w, False, dtype=torch.float16)
+    assert tuple(wf.shape) == (2, N, Kp) and wf._pd_fold
+    out, out1 = (torch.full((M, N), float("nan"), device=DEV) for _ in range(2))
+    L.igemm(a16, wf, M=M, N=N, Cin=Kp, bias=bias, out_f32=out, tile=tile, opts=opts)
+    L.igemm(a16, w1, M=M, N=N, Cin=Kp, bias=bias, out_f32=out1, tile=tile, opts=opts)
+    ref = a16[:, :K].float().double() @ w.double().t() + bias.double()
+    e2, e1 = rel_l2(out, ref), rel_l2(out1, ref)
+    print(f"[igemm folded weights {M}x{N}x{K} tile {tile}] vs the fp64 product on the same fp16 activations: two products {e2:.2e}, one product {e1:.2e}")
+    assert e2 < 2e-6 and e1 > 20 * e2
+    with pytest.raises(L.PrediffHipError):                 # folded weights with an e4m3 launch: refused by the binding
+        L.igemm(a16, wf, M=M, N=N, Cin=Kp, out_f32=out, fp8=True, opts=opts)
+
+
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout,splitk", [(2, 13, 16, 16, 256, 256, False), (1, 13, 16, 16, 256, 256, True), (2, 13, 8, 8, 512, 512, True),
+                                                     (3, 5, 6, 7, 64, 128, False)])
+def test_igemm_conv3d_folded_weights(B, T, H, W, Cin, Cout, splitk):
+    """The same for the 3x3x3 convolution (54 weight slabs over 27 activation gathers; 256 x 256 kernel, its split-K form, 128 x 128)."""
+    from prediff_amd.packing import pack_conv as PC
+    g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
+    x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).to(DEV)
+    w[:, :, 0, 1, 2] += 0.02                                # asymmetric taps
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    a16 = x.reshape(-1, Cin).half().contiguous()
+    wf, _ = PC(w, False, dtype=torch.float16, fold=True)
+    w1, _ = PC(w, False, dtype=torch.float16)
+    assert tuple(wf.shape) == (54, Cout, Cin)
+    M = B * T * H * W
+    opts = L.CallOpts("fp16")
+    ws = torch.empty(16 * 1024 * 1024, device=DEV) if splitk else None
+    out, out1 = (torch.full((M, Cout), float("nan"), device=DEV) for _ in range(2))
+    kw = dict(M=M, N=Cout, Cin=Cin, taps=27, w_tap_stride=Cout * Cin, geom=L.conv_geom(B, (T, H, W), (3, 3, 3)), bias=bias, splitk_ws=ws, opts=opts)
+    L.igemm(a16, wf, out_f32=out, **kw)
+    L.igemm(a16, w1, out_f32=out1, **kw)
+    ref = F.conv3d(a16.float().double().reshape(B, T, H, W, Cin).permute(0, 4, 1, 2, 3), w.double(), bias.double(), padding=1)
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(M, Cout)
+    e2, e1 = rel_l2(out, ref), rel_l2(out1, ref)
+    print(f"[igemm conv3d folded weights B={B} {T}x{H}x{W} {Cin}->{Cout} splitk={splitk}] vs fp64 on the same fp16 activations: two products {e2:.2e}, one {e1:.2e}")
+    assert e2 < 2e-6 and e1 > 20 * e2
+
+
 def test_igemm_rowvec_alpha_mul_period():
     M, N, K = 512, 128, 128
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -400,6 +457,8 @@ def _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, B, qdtyp
     vol, nc = tabs["vol"], tabs["nc"]
     if qdtype == "bf16":
         qkv = bf(qkv)
+    if qdtype == "fp8":          # the oracle sees exactly the e4m3 values the kernel reads (q, k, v * 16 -> e4m3 -> / 16)
+        qkv = (qkv * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn).float() / 16.0
     # ---- oracle statement of the core on the same q/k/v (cuboid_transformer.py:839-861,947-962) ----
     cub, sh = tabs["cuboid"], tabs["shift"]
     pad = tabs["pad"]
@@ -429,6 +488,11 @@ def _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, B, qdtyp
     if qdtype == "bf16":
         out = torch.zeros(B, ntok, Cn, dtype=torch.bfloat16, device=DEV)
         L.cuboid_attention(qkv_bf16=qkv.to(torch.bfloat16).to(DEV), out_bf16=out, **kw)
+        return out.float().cpu(), ref
+    if qdtype == "fp8":
+        q8 = (qkv * 16.0).to(torch.float8_e4m3fn).to(DEV).contiguous()
+        out = torch.zeros(B, ntok, Cn, dtype=torch.bfloat16, device=DEV)
+        L.cuboid_attention(qkv_bf16=q8, qkv_fp8_log2=4, out_bf16=out, **kw)
         return out.float().cpu(), ref
     out = torch.zeros(B, ntok, Cn, device=DEV)
     L.cuboid_attention(qkv_f32=qkv.to(DEV), out_f32=out, **kw)
@@ -462,6 +526,29 @@ def test_attention_mfma_multi_tile_bf16(shape, cuboid, shift, strategy, padding_
     assert rel_l2(out, ref) < 6e-3
     out_g, _ = _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, 2, "bf16", True)
     assert rel_l2(out, out_g) < 6e-3          # MFMA core (bf16 probabilities) vs the fp32 VALU kernel on the same bf16 q/k/v
+
+
+@pytest.mark.parametrize("case", [c + ((0, 0, 0), LLL, "zeros") for c in [(a[0], a[1]) for a in AXIAL]] + [m[:5] for m in MULTI_TILE],
+                         ids=lambda c: "x".join(map(str, c[0])) + "_" + "x".join(map(str, c[1])) + "_" + c[4])
+def test_attention_mfma_fp8_core(case):
+    """q k^T and attn v on the fp8 MFMA (pd_cuboid_attn_args.qkv_fp8_log2 > 0; BASELINE.json configs[4] "fp8 MFMA attention",
+    cuboid_transformer.py:849-861,947-952): e4m3 q / k / v and e4m3(P * 256) probabilities, fp32 scores / softmax / accumulation, against
+    the oracle's fp32 statement of the core ON THE SAME e4m3 q / k / v -- what is left is the 3-mantissa-bit rounding of the
+    probabilities (<= 2^-4 per entry, averaged over the keys) -- and against the bf16 core.  Axial cuboids of the SEVIR-LR grid
+    (volumes 13 / 16 / 8, head_dim 64 and 128), the full-resolution volumes 25 / 48 / 24 (two and three key tiles), shifted / masked /
+    padded / dilated cuboids of 32 and 64 slots."""
+    shape, cuboid, shift, strategy, padding_type = case
+    Cn, heads = next(((a[2], a[3]) for a in AXIAL if (a[0], a[1]) == (shape, cuboid)), None) or \
+        next((m[5], m[6]) for m in MULTI_TILE if m[:5] == case)
+    out, ref = _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, 2, "fp8", False)
+    assert bool(torch.isfinite(out).all())
+    e = rel_l2(out, ref)
+    out_b, ref_b = _attn_case(shape, cuboid, shift, strategy, padding_type, Cn, heads, 2, "bf16", False)
+    e_b = rel_l2(out, ref_b)          # vs the oracle on UNquantised q / k / v: the whole fp8 error of the core
+    print(f"[attention core fp8 {shape} {cuboid} C={Cn}] rel-L2 vs oracle on the same e4m3 q/k/v {e:.3e}; vs oracle on fp32 q/k/v {e_b:.3e}")
+    assert e < 4e-2 and e_b < 0.12
+    # rows the cuboids do not cover (none here) / empty slots must not have been written with garbage: every token is finite and the
+    # masked / padded cases agree with the reference's masked_softmax semantics to the same tolerance (asserted above)
 
 
 # cuboids of more than 64 slots ("full" / "divided_st" patterns): online-softmax kernel, incl. a shifted + masked and a padded case

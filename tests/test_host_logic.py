@@ -169,7 +169,7 @@ def test_c_abi_exports_every_declared_symbol():
                  "pd_f16_ffn_fused", "pd_f16_attn_block_fused_ex", "pd_f16_conv2d_gn_silu", "pd_f16_cast_rows", "pd_f16_softmax_rows",
                  "pd_f16_patch_merge_layernorm_ex"):
         assert hasattr(so, name) and name not in declared, name
-    assert L.lib().pd_abi_version() == L.ABI_VERSION == 3
+    assert L.lib().pd_abi_version() == L.ABI_VERSION == 4
     assert ctypes.sizeof(L.CallOpts) == so.pd_sizeof_call_opts()
     assert ctypes.sizeof(L.IgemmArgs) % 8 == 0
 
