@@ -45,8 +45,12 @@ typedef struct pd_call_opts {
   int32_t small_grid;               /* != 0: the caller allows kernel choices that depend on the launch size (the engine's small-batch mode; results
                                        then are not bit-identical across batch sizes).  pd_groupnorm_silu: finer channel chunks (twice the workgroups)
                                        at <= 1024 rows per sample when the default chunks would leave more than half of the CUs idle */
+  int32_t w_fold;                   /* ABI 4.  pd_attn_ffn_pair / pd_attn_ffn_pair_split: != 0 = the weight stream holds W_hi AND W_lo chunks
+                                       (packing.pack_pair_block(fold=True): twice the chunks; precision="fp16x2"), two MFMA products per k-step
+                                       against the once-rounded activations.  One 16-slot group per wave only (pair_form 2 is refused) */
+  int32_t reserved1;
   unsigned long long* trace;        /* device buffer for per-phase clock stamps of the fused kernels (pd_ffn_fused, pd_attn_block_fused_ex,
-                                       pd_attn_ffn_pair in a -DPD_PAIR_DEBUG=1 build), or NULL (production) */
+                                       pd_attn_ffn_pair in a -DPD_PAIR_TRACE=1 / -DPD_PAIR_DEBUG=1 build), or NULL (production) */
 } pd_call_opts;
 int pd_sizeof_call_opts(void);
 

@@ -55,7 +55,7 @@ class CallOpts(C.Structure):
     passes it on every launch: nothing is process-global.  All-zero = bfloat16 operands, production settings.  `igemm_*` are host-side
     defaults the `igemm` wrapper copies into pd_igemm_args (the library's own struct has no such members)."""
     _fields_ = [(n, C.c_int32) for n in ("operand", "attn_block_table_ids", "ffn_rows128", "groupnorm_two_launches", "pair_form",
-                                         "ffn_debug_flags", "attn_block_debug_flags", "small_grid")] + [("trace", C.c_void_p)]
+                                         "ffn_debug_flags", "attn_block_debug_flags", "small_grid", "w_fold", "reserved1")] + [("trace", C.c_void_p)]
 
     def __init__(self, operand="bf16", **kw):
         super().__init__()

@@ -185,14 +185,22 @@ __device__ __forceinline__ s16x4 pk_pack4(const f32x4& a) {
 // bursts at the tile boundaries); their fp32 summation order differs from MODE 0's (partials added instead of one running accumulator),
 // so the engine uses them only where it may choose kernels by launch size (split_k: the small-batch mode).
 constexpr int PAIR_NSPL = 4;
-template <int NC, int CW, int NWV = 4, int MODE = 0>
+// WP (round 6, precision="fp16x2"): weight products per k-step.  2 = every matrix of the stream is followed by its LOW part (W = W_hi + W_lo in
+// the 16-bit operand type, packing.pack_pair_block(fold=True)): each group of chunks (a head's Wq / Wk / Wv / proj slice, a hidden slice of W1 /
+// W2) comes twice, and the second pass multiplies the SAME activation fragments into the SAME accumulators -- the chunk loops simply run
+// NQ = WP * CW^2 (NW = WP * CW) chunks per matrix with the operand index folded (SUB mod the single-product count); nothing else changes:
+// no new registers, the same tile-boundary schedule (its constants count row instructions and DMA pieces, not what a chunk holds).
+template <int NC, int CW, int NWV = 4, int MODE = 0, int WP = 1>
 __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace pairk;
   using GG = G<CW>;
-  constexpr int C = GG::C, CT = GG::CT, KS = GG::KS, DT = GG::DT, HS = GG::HS, NQ = GG::NQ, NW = GG::NW, NJ = GG::NJ;
+  constexpr int C = GG::C, CT = GG::CT, KS = GG::KS, DT = GG::DT, HS = GG::HS, NJ = GG::NJ;
+  constexpr int NQ1 = GG::NQ, NW1 = GG::NW;         // chunks of one product of a head matrix / of a hidden slice: the operand index wraps here
+  constexpr int NQ = NQ1 * WP, NW = NW1 * WP;       // chunks the loops run per head matrix / hidden slice
+  static_assert(WP == 1 || (WP == 2 && NC == 1), "folded weights: one 16-slot group per wave (the two-group FFN tail is written for one chunk per slice)");
   constexpr int T_LN1G = GG::T_LN1G, T_LN1B = GG::T_LN1B, T_BP = GG::T_BP, T_LN2G = GG::T_LN2G, T_LN2B = GG::T_LN2B, T_B2 = GG::T_B2,
-                T_B1 = GG::T_B1, T_RB = GG::T_RB, T_FLOATS = GG::T_FLOATS, RING_OFF = GG::RING_OFF, CH_ALL = GG::CH_ALL;
+                T_B1 = GG::T_B1, T_RB = GG::T_RB, T_FLOATS = GG::T_FLOATS, RING_OFF = GG::RING_OFF, CH_ALL = GG::CH_ALL * WP;
   static_assert(NC * CW <= 2, "a wave holds 32 x 256 or 16 x 512 fp32 row values");
   static_assert(NWV == 4 || (NWV == 8 && NC == 1 && CW == 1), "eight waves (two per SIMD, 256 registers each): 16 x 256 rows per wave only");
   static_assert(MODE == 0 || (NC == 1 && NWV == 4 && NJ % PAIR_NSPL == 0 && HEADS == PAIR_NSPL), "split forms: one group per wave, four waves");
@@ -341,22 +349,22 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #define PK_MFMA_T(ACC, AF, SUB) /* ... a head's Wq / Wk ([HD x C], transposed product): feature tile i % DT, k-step SUB * 32 / DT + i / DT */ \
   if (PK_MFMA_ON) {                                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
-      ACC[c_][i % DT] = mfma_16x16x32(wf, AF[c_][(SUB) * (32 / DT) + i / DT], ACC[c_][i % DT]); \
+      ACC[c_][i % DT] = mfma_16x16x32(wf, AF[c_][((SUB) % NQ1) * (32 / DT) + i / DT], ACC[c_][i % DT]); \
   }
 #define PK_MFMA_V(ACC, AF, SUB) /* ... a head's Wv (plain product: lane = feature, 4 consecutive tokens) */             \
   if (PK_MFMA_ON) {                                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
-      ACC[c_][i % DT] = mfma_16x16x32(AF[c_][(SUB) * (32 / DT) + i / DT], wf, ACC[c_][i % DT]); \
+      ACC[c_][i % DT] = mfma_16x16x32(AF[c_][((SUB) % NQ1) * (32 / DT) + i / DT], wf, ACC[c_][i % DT]); \
   }
 #define PK_MFMA_H(ACC, AF, SUB) /* ... W1_j ([64 x C]): hidden tile i & 3, k-step 8 SUB + i / 4 */                      \
   if (PK_MFMA_ON) {                                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
-      ACC[c_][i & 3] = mfma_16x16x32(wf, AF[c_][(SUB) * 8 + (i >> 2)], ACC[c_][i & 3]); \
+      ACC[c_][i & 3] = mfma_16x16x32(wf, AF[c_][((SUB) % NW1) * 8 + (i >> 2)], ACC[c_][i & 3]); \
   }
-#define PK_MFMA_OUT(OF, SUB) /* ... a [C outputs x k] slice of Wproj / W2 (x^T += W act^T): column tile i % CT, k-step SUB * 32 / CT + i / CT */ \
+#define PK_MFMA_OUT(OF, SUB, N1) /* ... a [C outputs x k] slice of Wproj / W2 (x^T += W act^T): column tile i % CT, k-step (SUB mod N1) * 32 / CT + i / CT */ \
   if (PK_MFMA_ON) {                                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_)                                                                \
-      acc[c_][i % CT] = mfma_16x16x32(wf, OF[c_][(SUB) * (32 / CT) + i / CT], acc[c_][i % CT]); \
+      acc[c_][i % CT] = mfma_16x16x32(wf, OF[c_][((SUB) % (N1)) * (32 / CT) + i / CT], acc[c_][i % CT]); \
   }
 
   // rows of a tile's 16-slot groups for this lane = (slot q, column group g), as byte offsets into x / out.  A group holds ONE cuboid,
@@ -622,7 +630,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) t[c][dt] = z4;
 #define PK_Q_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(SUB), 0, (void)0, (void)0, PK_MFMA_T(t, af, SUB), PK_ST_HOOK_T(SUB))
-      PK_Q_CHUNK(0) PK_Q_CHUNK(1) PK_Q_CHUNK(2) PK_Q_CHUNK(3)
+      PK_Q_CHUNK(0) PK_Q_CHUNK(1) PK_Q_CHUNK(2) PK_Q_CHUNK(3) PK_Q_CHUNK(4) PK_Q_CHUNK(5) PK_Q_CHUNK(6) PK_Q_CHUNK(7)
 #if PD_PAIR_DEBUG
       if (h == 0) { for (int c = 0; c < NC; ++c) dump4(1, c, t[c][0], t[c][1], t[c][2], t[c][3]); }
 #endif
@@ -638,7 +646,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #define PK_K_CHUNK(SUB)                                                                                                      \
   if constexpr ((SUB) == 0) PK_CHUNK(PK_SYNC_T(NQ + (SUB)), 1, PK_LDS_F4(rb, vrb_h, 0), PK_LANDED(rb), PK_MFMA_T(t, af, SUB), PK_ST_HOOK_T(NQ + (SUB))) \
   else if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_T(t, af, SUB), PK_ST_HOOK_T(NQ + (SUB)))
-      PK_K_CHUNK(0) PK_K_CHUNK(1) PK_K_CHUNK(2) PK_K_CHUNK(3)
+      PK_K_CHUNK(0) PK_K_CHUNK(1) PK_K_CHUNK(2) PK_K_CHUNK(3) PK_K_CHUNK(4) PK_K_CHUNK(5) PK_K_CHUNK(6) PK_K_CHUNK(7)
       PK_DRAIN();
       PK_TRACE();   // k done
       // ---------------- S^T = K Q^T, softmax over the keys (registers + two row swaps) ----------------
@@ -682,7 +690,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
       PK_TRACE();   // softmax done
       // ---------------- v = a Wv_h^T (plain product: lane = feature, 4 consecutive tokens -> the A operand of O^T = V^T P^T) -------
 #define PK_V_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(2 * NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_V(t, af, SUB), (void)0)
-      PK_V_CHUNK(0) PK_V_CHUNK(1) PK_V_CHUNK(2) PK_V_CHUNK(3)
+      PK_V_CHUNK(0) PK_V_CHUNK(1) PK_V_CHUNK(2) PK_V_CHUNK(3) PK_V_CHUNK(4) PK_V_CHUNK(5) PK_V_CHUNK(6) PK_V_CHUNK(7)
       PK_DRAIN();
       op8 of[NC][HS];
 #pragma unroll
@@ -702,8 +710,8 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
       if constexpr (FM == 1) add_vec(xn, T_BP);   // the finished rows have left: acc <- x + b_proj, the accumulator of every head's proj
       PK_TRACE();   // v + PV done
       // ---------------- x^T += Wp[:, head h] O_h^T ----------------
-#define PK_P_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(3 * NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_OUT(of, SUB), (void)0)
-      PK_P_CHUNK(0) PK_P_CHUNK(1) PK_P_CHUNK(2) PK_P_CHUNK(3)
+#define PK_P_CHUNK(SUB) if constexpr ((SUB) < NQ) PK_CHUNK(PK_SYNC_T(3 * NQ + (SUB)), 0, (void)0, (void)0, PK_MFMA_OUT(of, SUB, NQ1), (void)0)
+      PK_P_CHUNK(0) PK_P_CHUNK(1) PK_P_CHUNK(2) PK_P_CHUNK(3) PK_P_CHUNK(4) PK_P_CHUNK(5) PK_P_CHUNK(6) PK_P_CHUNK(7)
     };
     if constexpr (MODE == 1) {
       head(std::integral_constant<int, 0>{}, slice);        // this workgroup's head; FM = 0: no row traffic in its hooks, plain wait counts
@@ -776,13 +784,22 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #define PK_W1_SLICE(ACC, BADDR, HOOK_A, TAIL_A, HOOK_B, TAIL_B)                                                             \
   PK_CHUNK(PK_SYNC(PK_VMC0), 4, PK_B1_FETCH(BADDR), PK_B1_LANDED(), PK_MFMA_H(ACC, af, 0), HOOK_A)                           \
   TAIL_A;                                                                                                                  \
-  if constexpr (NW == 2) { PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_H(ACC, af, 1), HOOK_B) TAIL_B; }
+  if constexpr (NW >= 2) { PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_H(ACC, af, 1), HOOK_B) TAIL_B; }          \
+  if constexpr (NW == 4) {                                                                                                 \
+    PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_H(ACC, af, 2), (void)0)                                          \
+    PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_H(ACC, af, 3), (void)0)                                          \
+  }
 #define PK_W2_SLICE(HOOK_A, TAIL_A, HOOK_B, TAIL_B)                                                                        \
-  PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), HOOK_A)                                              \
+  PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0, NW1), HOOK_A)                                         \
   TAIL_A;                                                                                                                  \
-  if constexpr (NW == 2) { PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1), HOOK_B) TAIL_B; }
+  if constexpr (NW >= 2) { PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1, NW1), HOOK_B) TAIL_B; }       \
+  if constexpr (NW == 4) {                                                                                                 \
+    PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 2, NW1), (void)0)                                       \
+    PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 3, NW1), (void)0)                                       \
+  }
   // gelu of ONE group per wave (NC == 1) spread over a span of chunks: SP = 32 / 16 groups per value when the span is 2 / ... chunks
-  constexpr int SP1 = CW == 2 ? 2 : 1;             // spans of one slice (W1_1, W2_{NJ-2}): NW chunks
+  static_assert(NW == 1 || NW == 2 || NW == 4, "hidden slices of one, two or four chunks");
+  constexpr int SP1 = NW >= 2 ? 2 : 1;             // spans of one slice (W1_1, W2_{NJ-2}): the gelu of a slice is done within its first two chunks
   constexpr int SP2 = 2 * SP1;                     // spans of two slices (W2_j, W1_{j+2})
     // b1 of slice 0: plain wait (the fragment prologue in flight is older and simply lands first)
     PK_B1_FETCH(vb1)
@@ -849,19 +866,24 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
     // (the LayerNorm fragments are dead: xn takes their registers)
     if constexpr (NW == 1) {
       if constexpr (NC == 2) {
-        PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), { PK_GELU_GROUP(hn, 0, NC, gi) PK_LD_HOOK(1) })
+        PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0, NW1), { PK_GELU_GROUP(hn, 0, NC, gi) PK_LD_HOOK(1) })
         PK_GELU_TAIL(hn, 0, NC)
       } else {
-        PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), { PK_GELU_SP(hn, 1, gi) PK_LD_HOOK(1) })
+        PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0, NW1), { PK_GELU_SP(hn, 1, gi) PK_LD_HOOK(1) })
         PK_GELU_SP(hn, 1, 16) PK_GELU_SP(hn, 1, 17)
       }
       PK_PACK_H(hn)
-      PK_CHUNK(PK_SYNC(VMC_E0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), PK_LD_HOOK(0))
+      PK_CHUNK(PK_SYNC(VMC_E0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0, NW1), PK_LD_HOOK(0))
     } else {
       PK_W2_SLICE(PK_GELU_SP(hn, 2, gi), (void)0, PK_GELU_SP(hn, 2, 16 + gi), PK_GELU_SP(hn, 2, 32))
       PK_PACK_H(hn)
-      PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0), PK_LD_HOOK(1))
-      PK_CHUNK(PK_SYNC(VMC_E0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1), PK_LD_HOOK(0))
+      // the tile's LAST two chunks carry the loads of the next tile's rows (four chunks per slice: two plain ones first)
+      if constexpr (NW == 4) {
+        PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 0, NW1), (void)0)
+        PK_CHUNK(PK_SYNC(PK_VMC0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, 1, NW1), (void)0)
+      }
+      PK_CHUNK(PK_SYNC(VMC_E1), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, NW - 2, NW1), PK_LD_HOOK(1))
+      PK_CHUNK(PK_SYNC(VMC_E0), 0, (void)0, (void)0, PK_MFMA_OUT(hfr, NW - 1, NW1), PK_LD_HOOK(0))
     }
     PK_DRAIN();                                     // (the next tile's LayerNorm follows)
     PK_TRACE();   // FFN done
@@ -885,14 +907,14 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #endif
 }
 
-template <int NC, int CW, int NWV = 4, int MODE = 0>
+template <int NC, int CW, int NWV = 4, int MODE = 0, int WP = 1>
 static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   using namespace pairk;
   constexpr int LDS_BYTES = G<CW>::LDS_BYTES;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW, NWV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW, NWV, MODE, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_ffn_pair: hipFuncSetAttribute(%d) failed: %s", LDS_BYTES, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -905,7 +927,7 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   constexpr int WPT = MODE ? PAIR_NSPL : 1;
   const int per_wg = (a.ntiles * WPT + ncu - 1) / ncu;
   const int grid = (a.ntiles + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL((pair_kernel<NC, CW, NWV, MODE>), dim3((unsigned)grid, (unsigned)WPT), dim3(NWV * 64), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((pair_kernel<NC, CW, NWV, MODE, WP>), dim3((unsigned)grid, (unsigned)WPT), dim3(NWV * 64), LDS_BYTES, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -969,7 +991,7 @@ static int pair_fill_args(pd_pair_args_k& a, const float* x, float* out, const v
   a.x = x; a.out = out; a.wstream = wstream; a.vecs = vecs; a.tok_index = tok_index;
   a.slab_in = nullptr; a.slab_out = nullptr; a.wstream2 = nullptr; a.w2bytes = 0;
   a.scale = scale; a.eps1 = eps_attn; a.eps2 = eps_ffn;
-  a.wbytes = (uint32_t)((units == 256 ? G<1>::CH_ALL : G<2>::CH_ALL) * CHUNK);
+  a.wbytes = (uint32_t)((units == 256 ? G<1>::CH_ALL : G<2>::CH_ALL) * CHUNK) * (uint32_t)((opts && opts->w_fold) ? 2 : 1);
   a.xbytes = (uint32_t)((int64_t)B * ntok * (units * 4));
   a.trace = opts ? opts->trace : nullptr;          // (clock stamps: -DPD_PAIR_TRACE=1 / -DPD_PAIR_DEBUG=1 builds only)
 #if PD_PAIR_DEBUG
@@ -1000,9 +1022,10 @@ extern "C" int PD_ENTRY(attn_ffn_pair)(const float* x, float* out, const void* w
   const int rc = pair_fill_args(a, x, out, wstream, vecs, tok_index, tok_affine, B, ntok, nc, vol, units, scale, eps_attn, eps_ffn, opts);
   if (rc != PD_OK) return rc;
   const int64_t groups = (int64_t)B * a.gps;
+  const bool fold = opts && opts->w_fold;            // W_hi + W_lo chunks in the stream (twice as many): two products per k-step
   if (units == 512) {                               // one group per wave: 64-row tiles
     a.ntiles = (int)((groups + 3) / 4);
-    return launch_pair<1, 2>(a, (hipStream_t)stream);
+    return fold ? launch_pair<1, 2, 4, 0, 2>(a, (hipStream_t)stream) : launch_pair<1, 2>(a, (hipStream_t)stream);
   }
   // 128-row tiles once that leaves no CU idle -- as two groups per wave (four waves, every weight fragment feeds two MFMAs) or as
   // eight waves of one group (two waves per SIMD, 256 registers each: one wave's LayerNorm / softmax / GELU / row traffic runs beside
@@ -1010,11 +1033,13 @@ extern "C" int PD_ENTRY(attn_ffn_pair)(const float* x, float* out, const void* w
   // half the MFMAs per streamed chunk -- the small-batch form
   const int force = opts ? opts->pair_form : 0;      // A/B: 1 / 2 = 16-slot groups per wave (four waves), 8 = eight waves of one group
   const int nc_wave = force ? force : ((groups + 7) / 8 > pd_num_cus() / 2 ? PD_PAIR_BIG_FORM : 1);
+  PD_CHECK_ARG(!(fold && nc_wave == 2), "pd_attn_ffn_pair: folded weights (w_fold) run one 16-slot group per wave (pair_form 1 or 8)");
   if (nc_wave == 8) {
     a.ntiles = (int)((groups + 7) / 8);
-    return launch_pair<1, 1, 8>(a, (hipStream_t)stream);
+    return fold ? launch_pair<1, 1, 8, 0, 2>(a, (hipStream_t)stream) : launch_pair<1, 1, 8>(a, (hipStream_t)stream);
   }
   a.ntiles = (int)((groups + 4 * nc_wave - 1) / (4 * nc_wave));
+  if (fold) return launch_pair<1, 1, 4, 0, 2>(a, (hipStream_t)stream);
   return nc_wave == 2 ? launch_pair<2, 1>(a, (hipStream_t)stream) : launch_pair<1, 1>(a, (hipStream_t)stream);
 }
 
@@ -1050,8 +1075,9 @@ extern "C" int PD_ENTRY(attn_ffn_pair_split)(const float* x, float* out, const v
   float* slab_f = ws + PAIR_NSPL * n;                // the four FFN partials
   hipStream_t s = (hipStream_t)stream;
   // 1: (tile, head) -> proj partial of that head
+  const bool fold = opts && opts->w_fold;
   a.slab_out = slab_a;
-  int r = launch_pair<1, 2, 4, 1>(a, s);
+  int r = fold ? launch_pair<1, 2, 4, 1, 2>(a, s) : launch_pair<1, 2, 4, 1>(a, s);
   if (r != PD_OK) return r;
   // 2a: x' = x + b_proj + the four partials in order, once per row (over partial 0)
   const int64_t n4 = n / 4;
@@ -1065,8 +1091,8 @@ extern "C" int PD_ENTRY(attn_ffn_pair_split)(const float* x, float* out, const v
   a.slab_in = nullptr;
   a.slab_out = slab_f;
   a.wstream2 = wffn_split;
-  a.w2bytes = (uint32_t)(2 * G<2>::NJ * G<2>::NW * CHUNK);
-  r = launch_pair<1, 2, 4, 2>(a, s);
+  a.w2bytes = (uint32_t)(2 * G<2>::NJ * G<2>::NW * CHUNK) * (fold ? 2u : 1u);
+  r = fold ? launch_pair<1, 2, 4, 2, 2>(a, s) : launch_pair<1, 2, 4, 2>(a, s);
   if (r != PD_OK) return r;
   // 3: out = the four FFN partials in order
   hipLaunchKernelGGL(pair_split_sum_kernel, dim3(sum_blocks), dim3(256), 0, s, (const float4*)slab_f, (float4*)out, n4);

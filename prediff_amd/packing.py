@@ -139,27 +139,38 @@ def pair_cuboids_per_group(vol: int) -> int:
     return 2 if vol >= 1 and 2 * vol <= 16 else 1
 
 
-def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+def _hi_lo(t: torch.Tensor, dtype):
+    """fp32 -> (round(t), round(t - round(t))) in the 16-bit operand type: the two weight images of a folded stream"""
+    hi = to_operand(t.detach().float(), dtype)
+    return hi, to_operand(t.detach().float() - hi.float(), dtype)
+
+
+def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16, fold: bool = False) -> torch.Tensor:
     """The weight stream of pd_attn_ffn_pair for units C = 256 (4 heads of 64, hidden 1024) or 512 (4 heads of 128, hidden 2048):
     chunks of 32 KB = 32 fragments in consumption order.  With CW = C / 256, HD = C / 4, DT = HD / 16, CT = C / 16:
       per head h: Wq_h, Wk_h, Wv_h ([HD x C], CW^2 chunks each: fragment i of chunk s = feature tile i % DT, k-step s * 32 / DT + i / DT),
                   Wproj[:, HD h : HD h + HD] ([C x HD], CW^2 chunks: column tile i % CT, k-step s * 32 / CT + i / CT);
       then the 64-wide hidden slices W1_0, W1_1, (W2_j, W1_{j+2}) for j = 0 .. hidden/64 - 3, W2_{n-2}, W2_{n-1}
       (W1_j = rows 64 j .. of (hidden, C), CW chunks: hidden tile i & 3, k-step 8 s + i / 4;  W2_j = columns 64 j .. of (C, hidden), CW
-      chunks: column tile i % CT, k-step s * 32 / CT + i / CT): gelu(h_j) runs beside the chunks between W1_j and W2_j."""
+      chunks: column tile i % CT, k-step s * 32 / CT + i / CT): gelu(h_j) runs beside the chunks between W1_j and W2_j.
+    fold (precision="fp16x2", pd_call_opts.w_fold): every such group of chunks is followed by the same group of the LOW parts
+    (W = W_hi + W_lo in the operand type): twice the chunks, the kernel multiplies both into the same accumulators."""
     Cn = wproj.shape[0]
     assert Cn in (256, 512)
     CW, hid = Cn // 256, 4 * Cn
     assert tuple(wqkv.shape) == (3 * Cn, Cn) and tuple(wproj.shape) == (Cn, Cn) and tuple(w1.shape) == (hid, Cn) and tuple(w2.shape) == (Cn, hid)
     HD, CT = Cn // 4, Cn // 16
     DT, HS = HD // 16, HD // 32
-    bf = lambda t: to_operand(t.detach(), dtype)
-    fq, fp, f1, f2 = _mfma_frags(bf(wqkv)), _mfma_frags(bf(wproj)), _mfma_frags(bf(w1)), _mfma_frags(bf(w2))
+    parts = [_hi_lo(t, dtype) if fold else (to_operand(t.detach(), dtype),) for t in (wqkv, wproj, w1, w2)]
+    fq, fp, f1, f2 = ([_mfma_frags(x) for x in pr] for pr in parts)          # per matrix: [hi] or [hi, lo] fragment tensors
 
-    def tile_chunks(fr, F0, nF, K0, nK):
-        """fragments [F0, F0 + nF) x [K0, K0 + nK) -> chunks of 32 with i = nF * k_local + f"""
-        v = fr[F0:F0 + nF, K0:K0 + nK].permute(1, 0, 2, 3).reshape(nF * nK, 64, 8)
-        return list(v.reshape(nF * nK // 32, 32, 64, 8))
+    def tile_chunks(frs, F0, nF, K0, nK):
+        """fragments [F0, F0 + nF) x [K0, K0 + nK) -> chunks of 32 with i = nF * k_local + f (the hi image, then the lo image)"""
+        out = []
+        for fr in frs:
+            v = fr[F0:F0 + nF, K0:K0 + nK].permute(1, 0, 2, 3).reshape(nF * nK, 64, 8)
+            out += list(v.reshape(nF * nK // 32, 32, 64, 8))
+        return out
 
     chunks = []
     for h in range(4):
@@ -175,22 +186,25 @@ def pack_pair_block(wqkv: torch.Tensor, wproj: torch.Tensor, w1: torch.Tensor, w
         if j + 2 < nj:
             chunks += w1s(j + 2)
     out = torch.stack(chunks).contiguous()
-    assert out.shape[0] == 16 * CW * CW + 2 * nj * CW and out.numel() * 2 == out.shape[0] * PAIR_CHUNK_BYTES
+    assert out.shape[0] == (16 * CW * CW + 2 * nj * CW) * (2 if fold else 1) and out.numel() * 2 == out.shape[0] * PAIR_CHUNK_BYTES
     return out
 
 
-def pack_pair_ffn_split(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16, nsplit: int = 4) -> torch.Tensor:
+def pack_pair_ffn_split(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16, nsplit: int = 4, fold: bool = False) -> torch.Tensor:
     """The FFN part of pack_pair_block's stream re-ordered for pd_attn_ffn_pair_split (units 512): `nsplit` independent sub-streams, one
     per quarter q of the hidden units (64-wide slices j = q n .. q n + n - 1, n = hidden / 64 / nsplit), each in the software-pipelined
     order of the kernel's FFN loop: W1_0', W1_1', (W2_j', W1_{j+2}') for j' = 0 .. n - 3, W2_{n-2}', W2_{n-1}' (primes = local slices)."""
     Cn, hid = w2.shape
     assert Cn in (256, 512) and tuple(w1.shape) == (hid, Cn) and hid == 4 * Cn
     CT = Cn // 16
-    f1, f2 = _mfma_frags(to_operand(w1.detach(), dtype)), _mfma_frags(to_operand(w2.detach(), dtype))
+    f1, f2 = ([_mfma_frags(x) for x in (_hi_lo(t, dtype) if fold else (to_operand(t.detach(), dtype),))] for t in (w1, w2))
 
-    def tile_chunks(fr, F0, nF, K0, nK):
-        v = fr[F0:F0 + nF, K0:K0 + nK].permute(1, 0, 2, 3).reshape(nF * nK, 64, 8)
-        return list(v.reshape(nF * nK // 32, 32, 64, 8))
+    def tile_chunks(frs, F0, nF, K0, nK):
+        out = []
+        for fr in frs:
+            v = fr[F0:F0 + nF, K0:K0 + nK].permute(1, 0, 2, 3).reshape(nF * nK, 64, 8)
+            out += list(v.reshape(nF * nK // 32, 32, 64, 8))
+        return out
 
     nj = hid // 64
     n = nj // nsplit
@@ -206,7 +220,7 @@ def pack_pair_ffn_split(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16
             if j + 2 < n:
                 chunks += w1s(j0 + j + 2)
     out = torch.stack(chunks).contiguous()
-    assert out.shape[0] == 2 * nj * (Cn // 256) and out.numel() * 2 == out.shape[0] * PAIR_CHUNK_BYTES
+    assert out.shape[0] == 2 * nj * (Cn // 256) * (2 if fold else 1) and out.numel() * 2 == out.shape[0] * PAIR_CHUNK_BYTES
     return out
 
 
