@@ -384,7 +384,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="latent trajectories (ensemble members) per GPU")
     ap.add_argument("--streams", type=int, default=2, help="lanes: the batch advances as this many equal sub-batches on concurrent HIP streams")
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp16x2", "fp32", "fp8", "fp8_conv"],
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp16x2", "fp16x2_lin", "fp32", "fp8", "fp8_conv"],
                     help="operand type; default: the one BASELINE.json quotes the workload on (v1: bf16, fullres: fp8)")
     ap.add_argument("--config", default="v1", choices=sorted(WORKLOADS), help="v1 = BASELINE configs[1] (the metric); fullres = configs[4] geometry, bf16")
     ap.add_argument("--no-graph", action="store_true")
@@ -644,7 +644,7 @@ def main():
         line = {
             "metric": "denoising_steps_per_sec", "value": round(value, 2), "unit": "steps/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16", "fp16x2": "fp16x2", "fp32": "bf16x3", "fp8": "fp8", "fp8_conv": "fp8"}[args.precision],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16", "fp16x2": "fp16x2", "fp16x2_lin": "fp16x2 (Conv3d: one product)", "fp32": "bf16x3", "fp8": "fp8", "fp8_conv": "fp8"}[args.precision],
             "data": "synthetic (seeded random weights of the v1 architecture, N(0,1) latents/context)",
             "config": {"workload": WL["label"],
                        **({"operands": "e4m3 x e4m3 (scaled K=128 MFMA) for the 3x3x3 Conv3d launches and for the K >= 512 linears of the blocks that do not run "

@@ -133,9 +133,9 @@ class AutoencoderKL(nn.Module):
         super().__init__()
         if act_fn not in ("silu", "swish"):
             raise NotImplementedError(f"act_fn={act_fn!r}: only SiLU is fused in the GroupNorm kernel")
-        if precision not in ("bf16", "fp16", "fp16x2", "fp32", "fp8", "fp8_conv"):
-            raise ValueError("precision must be 'bf16', 'fp16', 'fp16x2', 'fp32', 'fp8' or 'fp8_conv'")
-        if precision == "fp16x2":
+        if precision not in ("bf16", "fp16", "fp16x2", "fp16x2_lin", "fp32", "fp8", "fp8_conv"):
+            raise ValueError("precision must be 'bf16', 'fp16', 'fp16x2', 'fp16x2_lin', 'fp32', 'fp8' or 'fp8_conv'")
+        if precision in ("fp16x2", "fp16x2_lin"):
             # the denoiser's folded-weight engine (exact weights against the error that ACCUMULATES over the sampling steps); the VAE runs once
             # per sample, its weight rounding does not accumulate: it keeps the one-product fp16 engine
             precision = "fp16"

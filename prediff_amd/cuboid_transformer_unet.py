@@ -328,9 +328,10 @@ class CuboidTransformerUNet(nn.Module):
             raise NotImplementedError(f"norm_layer={norm_layer!r}")
         if downsample_type != "patch_merge" or upsample_type != "upsample":
             raise NotImplementedError
-        if precision not in ("bf16", "fp16", "fp16x2", "fp32", "fp8", "fp8_conv"):
+        if precision not in ("bf16", "fp16", "fp16x2", "fp16x2_lin", "fp32", "fp8", "fp8_conv"):
             raise ValueError("precision must be 'bf16' (throughput), 'fp16' (the same engine on IEEE-half operands: TF32-class accuracy at the "
-                             "bf16 rate), 'fp16x2' (IEEE-half activations x hi + lo IEEE-half weights: two MFMA products, inside the 1e-3 bar), "
+                             "bf16 rate), 'fp16x2' (IEEE-half activations x hi + lo IEEE-half weights: two MFMA products, inside the 1e-3 bar; "
+                             "'fp16x2_lin': the same with the 3x3x3 convolutions on one product), "
                              "'fp32' (hi/lo split, fp32-class accuracy), 'fp8_conv' (bf16 engine with e4m3 operands for the 3x3x3 "
                              "convolutions) or 'fp8' (e4m3 for the convolutions and the K >= 512 token linears)")
         # "fp16": every kernel of the "bf16" engine with IEEE half as the 16-bit operand type (the library's pd_f16_* builds): 11-bit
@@ -342,8 +343,11 @@ class CuboidTransformerUNet(nn.Module):
         # (a fixed perturbation of the network: the same bias at every step, it accumulates coherently) and only 3.9e-4 of activation
         # rounding (fresh noise at every step) -- tests/test_hip_configs.py::test_v1_fp16_error_budget measures both terms.  Exact weights
         # at 2x the GEMM work (not the 3x of the hi/lo engine) therefore sit inside the north-star 1e-3 bar.
-        self.w_fold = precision == "fp16x2"
-        self.operand = "fp16" if precision in ("fp16", "fp16x2") else "bf16"
+        # "fp16x2_lin": every weight folded EXCEPT the 3x3x3 convolutions' (60 % of the FLOPs, 3.1e-4 of the 8.8e-4 weight term of a forward --
+        # the per-group sweep on the oracle): their rounding stays, the step costs ~1.25x instead of ~1.75x the fp16 engine's.
+        self.w_fold = precision in ("fp16x2", "fp16x2_lin")
+        self.w_fold_conv3d = precision == "fp16x2"
+        self.operand = "fp16" if precision in ("fp16", "fp16x2", "fp16x2_lin") else "bf16"
         # per-call options handed to every launch of this module (operand type + A/B switches: bench.py / scripts set attributes here;
         # nothing is process-global, two modules in one process do not see each other's settings)
         self.opts = L.CallOpts(self.operand)
@@ -356,7 +360,7 @@ class CuboidTransformerUNet(nn.Module):
         self.fp8_conv = precision in ("fp8", "fp8_conv")
         self.fp8_linear = precision == "fp8"
         self.fp8_attn_core = True     # precision="fp8": q k^T and attn v of the un-fused attention layers on the fp8 MFMA (e4m3 q, k, v, P)
-        self.precision = "bf16" if (self.fp8_conv or precision in ("fp16", "fp16x2")) else precision     # "bf16" = the single-pass 16-bit-operand engine
+        self.precision = "bf16" if (self.fp8_conv or precision in ("fp16", "fp16x2", "fp16x2_lin")) else precision     # "bf16" = the single-pass 16-bit-operand engine
         self.precision_name = precision
         self.fuse_ffn = True          # bf16 mode: fused LN->FFN kernel where the shape allows (units <= 256)
         self.fuse_attn = True         # bf16 mode: fused LN->QKV->attention->proj kernel (head_dim 64, cuboid volume <= 64)
@@ -365,8 +369,14 @@ class CuboidTransformerUNet(nn.Module):
         # and the launch has at least `pair_min_tiles` tiles of 128 rows (0: always -- the library switches to one cuboid per wave, 64-row
         # tiles, when 128-row tiles would leave CUs idle: 48 vs 54 us per pair at 4 trajectories, 73 vs 84 at 8)
         self.fuse_pair = os.environ.get("PD_FUSE_PAIR", "1") != "0"
-        if self.w_fold:      # the round-3 fused token kernels stream ONE weight image: where the pair kernel (which has the folded form) does not
-            self.fuse_ffn = self.fuse_attn = False      # apply, the folded engine runs LayerNorm / pd_igemm / attention core launches
+        if self.w_fold:
+            # the round-3 fused token kernels stream ONE weight image: the folded engine runs LayerNorm / pd_igemm (w_fold) / attention core
+            # launches.  The pair kernel has a folded form too (WP = 2: every chunk group twice), measured SLOWER than those launches at
+            # 64 trajectories -- 839 vs 891 steps/s (profiles/r06_b_bench_fp16x2*.json): at twice the MFMA work the GEMM-tiled kernels' 0.4-0.5 of
+            # peak beats the pair kernel's 0.3, and the HBM round trips it saves were never the bottleneck -- so it is opt-in (fuse_pair = True)
+            self.fuse_ffn = self.fuse_attn = False
+            self.fuse_pair = os.environ.get("PD_FUSE_PAIR_FOLD", "0") == "1"
+            self.fold_pair_small = os.environ.get("PD_FUSE_PAIR_FOLD_SMALL", "1") != "0"      # ... but on in the small-batch mode (<= 16 trajectories per launch)
             self.opts.w_fold = 1
         self.pair_min_tiles = int(os.environ.get("PD_PAIR_MIN_TILES", "0"))
         self.pair_units = {int(u) for u in os.environ.get("PD_PAIR_UNITS", "256,512").split(",") if u}   # A/B: block widths handed to it
@@ -535,7 +545,7 @@ class CuboidTransformerUNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ packing
     def _params_key(self, device):
-        return (str(device), self.precision, self.operand, self.fp8_conv, self.fp8_linear, self.w_fold) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (str(device), self.precision, self.operand, self.fp8_conv, self.fp8_linear, self.w_fold, self.w_fold_conv3d) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _packers(self, P: Dict[str, object], device):
         """The per-module packing functions (writing into P): lin, conv, norm, resblock, stack.  `_pack` runs them over the whole
@@ -554,7 +564,8 @@ class CuboidTransformerUNet(nn.Module):
                 P[name + ".w8"] = pack_linear_fp8(m.weight.to(device))                   # (e4m3 (N, K), scale)
 
         def conv(name, m):
-            P[name + ".w"] = pack_conv(m.weight.to(device), split, dtype=self.op_dtype, fold=self.w_fold)
+            k3d = m.weight.dim() == 5 and tuple(m.weight.shape[2:]) == (3, 3, 3)
+            P[name + ".w"] = pack_conv(m.weight.to(device), split, dtype=self.op_dtype, fold=self.w_fold and (self.w_fold_conv3d or not k3d))
             P[name + ".b"] = f32(m.bias) if m.bias is not None else None
 
         def norm(name, m):
@@ -929,7 +940,12 @@ class CuboidTransformerUNet(nn.Module):
         """StackCuboidSelfAttentionBlock.forward, eval branch (cuboid_transformer.py:1147-1156 / 1176-1186)."""
         tabs = self._tables_dev[dev][level]
         for a, at in enumerate(blk.attn_l):
-            pair = P.get(f"{name}.pair{a}") if (self.fuse_pair and (self.w_fold or (self.fuse_attn and self.fuse_ffn))) else None
+            if self.w_fold:
+                # folded weights: the pair kernel's WP = 2 forms win where launches are latency bound (the small-batch mode: 497 vs 467 steps/s at
+                # 4 trajectories) and lose to the GEMM-tiled launches at full occupancy (839 vs 891 at 64); `fuse_pair` forces them everywhere
+                pair = P.get(f"{name}.pair{a}") if (self.fuse_pair or (self.fold_pair_small and self._splitk_mode(B))) else None
+            else:
+                pair = P.get(f"{name}.pair{a}") if (self.fuse_pair and self.fuse_attn and self.fuse_ffn) else None
             geo = self._geom[level][a]
             # (split_k = False is the batch-split-reproducible mode: no kernel choice may depend on the per-launch batch, so the pair
             #  kernel -- row-local, bit-identical at every batch size -- then runs whatever the tile count)

@@ -20,20 +20,28 @@ def shard_members(num_members: int, rank: int, world: int) -> List[int]:
     return list(range(rank, num_members, world))
 
 
+NOISE_CHUNK_STEPS = 32      # draws of one member fetched per generator call (one launch per member per 32 steps instead of one per step)
+
+
 def member_noise_fn(latent_shape: Sequence[int], members: Sequence[int], base_seed: int, device) -> Callable[[int], torch.Tensor]:
     """noise(step) -> (len(members), *latent_shape): draw `step` of member k comes from Generator(base_seed + k), always in
-    the order step 0 (= x_T), 1, 2, ...  so a member's trajectory is the same on any rank / world size / batch split."""
+    the order step 0 (= x_T), 1, 2, ...  so a member's trajectory is the same on any rank / world size / batch split.
+    The draws are fetched NOISE_CHUNK_STEPS steps at a time per member (a member's stream is one sequence of chunk-sized draws from its own
+    generator, whatever else is in the batch): 64 members cost 64 small launches per 32 steps, not per step."""
     gens = []
     for k in members:
         g = torch.Generator(device=device)
         g.manual_seed(int(base_seed) + int(k))
         gens.append(g)
-    state = {"next": 0}
+    state = {"next": 0, "base": 0, "chunk": None}
 
     def noise(step: int) -> torch.Tensor:
         assert step == state["next"], "member noise must be drawn in step order"
         state["next"] += 1
-        return torch.stack([torch.randn(tuple(latent_shape), generator=g, device=device) for g in gens])
+        if state["chunk"] is None or step >= state["base"] + NOISE_CHUNK_STEPS:
+            state["base"] = step
+            state["chunk"] = torch.stack([torch.randn((NOISE_CHUNK_STEPS,) + tuple(latent_shape), generator=g, device=device) for g in gens])
+        return state["chunk"][:, step - state["base"]].contiguous()
     return noise
 
 

@@ -1,0 +1,59 @@
+"""Heavy-tailed weights (prediff_amd.seeding.heavy_tailed_state_dict) through engine variants vs the oracle: which path loses what.
+usage: python scripts/debug_heavy.py [B]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _templates as TP  # noqa: E402
+from _cases import V1_UNET_CFG  # noqa: E402
+from _weights import heavy_tailed_state_dict, seeded_input, seeded_state_dict  # noqa: E402
+from oracle import unet as OU  # noqa: E402
+from prediff_amd.cuboid_transformer_unet import CuboidTransformerUNet  # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+tmpl = TP.unet_template(V1_UNET_CFG, "v1_unet_schema.json")
+x2 = torch.cat([seeded_input("v1x", (1, 6, 16, 16, 64), 2), seeded_input("v1x2", (1, 6, 16, 16, 64), 4)])
+c2 = torch.cat([seeded_input("v1c", (1, 7, 16, 16, 64), 3), seeded_input("v1c2", (1, 7, 16, 16, 64), 5)])
+t2 = torch.tensor([500, 3])
+rep = B // 2
+xb, tb, cb = (v.repeat((rep,) + (1,) * (v.dim() - 1)).cuda() for v in (x2, t2, c2))
+for kind, sd in (("gauss", seeded_state_dict(tmpl, 1234)), ("heavy", heavy_tailed_state_dict(tmpl, 77))):
+    ref = OU.unet_forward(sd, V1_UNET_CFG, x2, t2, c2)
+    sd16 = {k: (v.half().float() if (torch.is_floating_point(v) and v.dim() >= 2) else v) for k, v in sd.items()}
+    ref16 = OU.unet_forward(sd16, V1_UNET_CFG, x2, t2, c2)
+    print(f"[{kind}] oracle on fp16-rounded weights vs oracle: {rel(ref16, ref):.3e}")
+    for name, prec, sw in (("fp16 pair", "fp16", {}), ("fp16 round-3 fused", "fp16", dict(fuse_pair=False)),
+                           ("fp16 unfused", "fp16", dict(fuse_pair=False, fuse_attn=False, fuse_ffn=False)),
+                           ("fp16x2 pair-fold", "fp16x2", dict(fuse_pair=True)), ("fp16x2 unfused", "fp16x2", dict(fuse_pair=False)),
+                           ("fp32", "fp32", {})):
+        net = CuboidTransformerUNet(**V1_UNET_CFG, precision=prec)
+        for k, v in sw.items():
+            setattr(net, k, v)
+        net.load_state_dict(sd, strict=True)
+        out = net.cuda()(xb, tb, cb)[:2]
+        print(f"[{kind} B={B}] {name:22s} vs oracle {rel(out, ref):.3e}   vs oracle-on-fp16-weights {rel(out, ref16):.3e}   finite {bool(torch.isfinite(out).all())}")
+        del net
+    # weights that ARE fp16 numbers: W_lo = 0 exactly, so the folded engine computes what the fp16 engine computes (up to kernel choice /
+    # summation order) -- how far apart the two land is the amplification of fp32 round-off by this network, not a property of the fold
+    outs = {}
+    for name, prec, sw in (("fp16 unfused", "fp16", dict(fuse_pair=False, fuse_attn=False, fuse_ffn=False)), ("fp16x2 unfused", "fp16x2", dict(fuse_pair=False)),
+                           ("fp16 pair", "fp16", {}), ("fp16x2 pair-fold", "fp16x2", dict(fuse_pair=True))):
+        net = CuboidTransformerUNet(**V1_UNET_CFG, precision=prec)
+        for k, v in sw.items():
+            setattr(net, k, v)
+        net.load_state_dict(sd16, strict=True)
+        outs[name] = net.cuda()(xb, tb, cb)[:2]
+        del net
+    print(f"[{kind} B={B}] fp16-representable weights: fp16x2 unfused vs fp16 unfused {rel(outs['fp16x2 unfused'], outs['fp16 unfused']):.3e}; "
+          f"fp16x2 pair-fold vs fp16 pair {rel(outs['fp16x2 pair-fold'], outs['fp16 pair']):.3e}; fp16 unfused vs fp16 pair {rel(outs['fp16 unfused'], outs['fp16 pair']):.3e}; "
+          f"each vs oracle16: " + ", ".join(f"{k} {rel(v, ref16):.3e}" for k, v in outs.items()))

@@ -67,9 +67,10 @@ def test_igemm_linear(M, N, K, tile, split):
     assert rel_l2(outb.float(), ref) < 4e-3      # bf16 output rounding
 
 
+@pytest.mark.parametrize("heavy", [False, True])
 @pytest.mark.parametrize("M,N,K,tile", [(3328, 768, 256, 0), (3328, 768, 256, 3), (26624, 512, 2048, 0), (1000, 200, 96, 4), (300, 130, 64, 7),
                                         (512, 2048, 512, 7), (209, 256, 64, 0)])
-def test_igemm_linear_folded_weights(M, N, K, tile):
+def test_igemm_linear_folded_weights(M, N, K, tile, heavy):
     """pd_igemm_args.w_fold (precision="fp16x2"): D = A W_hi^T + A W_lo^T with IEEE-half operands -- the activations rounded once, the
     weights exact to ~2^-22 -- against the fp32 product ON THE SAME rounded activations (what is left: fp32 summation order and the
     2^-22 tail of the weights) and against the one-product fp16 launch (which carries the 2^-12 weight rounding the fold removes)."""
@@ -77,6 +78,11 @@ def test_igemm_linear_folded_weights(M, N, K, tile):
     g = torch.Generator(device="cpu").manual_seed(M + 5 * N + K)
     x = (torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(DEV)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.arange(N)[:, None] * 1e-3).to(DEV)
+    if heavy:        # Student-t(3) entries spanning six decades (W_lo down in the fp16 subnormals), 30x outlier rows and activation channels
+        t3 = torch.randn(N, K, generator=g) / torch.sqrt((torch.randn(3, N, K, generator=g) ** 2).mean(0))
+        w = (t3 / math.sqrt(3 * K)).to(DEV)
+        w[::37] *= 30.0
+        x[:, ::29] *= 30.0
     bias = torch.randn(N, generator=g).to(DEV)
     Kp = (K + 63) // 64 * 64
     a16 = torch.zeros(M, Kp, dtype=torch.float16, device=DEV)
