@@ -613,9 +613,15 @@ def main():
     if not args.no_extra and not args.no_graph and args.config == "v1" and args.precision == "bf16" and world == 1:
         ldm_bf16 = ldm
         ldm = v1_model("fp16x2", device, args.config)
-        kx2 = min(args.steps, 10)
-        elx2, Sx2 = timed_steps(B, args.streams, kx2, 2)
-        fp16x2_line = {"value": round(B * kx2 / elx2, 2), "unit": "steps/s",
+        kx2 = min(args.steps, 20)
+        elx2, Sx2 = timed_steps(B, args.streams, kx2, 5)      # (its graphs hold ~3x the nodes of the pair-kernel engines': the first replays are slow)
+        ldm_x2 = ldm
+        ldm = v1_model("fp16x2_lin", device, args.config)
+        ell, _ = timed_steps(B, args.streams, kx2, 5)
+        del ldm
+        ldm = ldm_x2
+        fp16x2_line = {"value": round(B * kx2 / elx2, 2), "unit": "steps/s", "value_fp16x2_lin": round(B * kx2 / ell, 2),
+                       "fp16x2_lin": "the same with the 3x3x3 convolutions on one product (their weight rounding is 3.1e-4 of the 8.8e-4 weight term of a forward)",
                        "dtype": "fp16 activations x fp16 hi+lo weights (two products), fp32 accumulate", "steps": kx2,
                        "ms_per_step": round(elx2 / kx2 * 1e3, 4), "trajectories_per_gpu": B, "lanes": Sx2,
                        "parity": "v1 DDIM-50 vs the oracle loop < 1e-3 asserted (tests/test_hip_configs.py::test_v1_ddim50_vs_oracle; "

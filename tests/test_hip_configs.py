@@ -66,7 +66,7 @@ def _v1_ldm(precision, vae=False):
 
 
 # ------------------------------------------------------------------------------------------------ config 1
-@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2", "fp16", "bf16"])
 def test_nbody_standin(golden, precision):
     g = golden("nbody")
     net = CuboidTransformerUNet(**NBODY_UNET_CFG, precision=precision)
@@ -83,7 +83,8 @@ def test_nbody_standin(golden, precision):
     print(f"[nbody {precision}] rel-L2 vs reference modules: {e}")
     _report("nbody_standin", precision=precision, **e)
     assert dec.shape == (1, 10, 64, 64, 1)
-    tol = {"fp32": 1e-3, "fp16": 6e-3, "bf16": 5e-2}[precision]          # (measured bf16: 9e-3; fp16 is asked to be 8x finer with margin)
+    tol = {"fp32": 1e-3, "fp16x2": 4e-3, "fp16": 6e-3, "bf16": 5e-2}[precision]          # (measured bf16: 9e-3; fp16 is asked to be 8x finer with margin;
+    # fp16x2: the denoiser's weights exact, the VAE -- which runs once -- on the one-product fp16 engine)
     assert max(e.values()) < tol
 
 
@@ -305,7 +306,8 @@ def test_fullres_forward():
     t_cpu = time.time() - t0
     # "fp8_conv" / "fp8": e4m3 operands (3 mantissa bits: report-only accuracy, BASELINE config 5) for the convolutions / also for the
     # K >= 512 linears; bounds at 2x what is measured (bf16 7.4e-3, fp8_conv 4.3e-2)
-    for precision, tol in (("fp32", 1e-4), ("bf16", 1.5e-2), ("fp8_conv", 8e-2), ("fp8", 0.14)):
+    # "fp16x2": the folded-weight engine on this geometry (no pair kernel: LayerNorm / folded pd_igemm / multi-key-tile attention core launches)
+    for precision, tol in (("fp32", 1e-4), ("fp16x2", 1.5e-3), ("bf16", 1.5e-2), ("fp8_conv", 8e-2), ("fp8", 0.14)):
         net = CuboidTransformerUNet(**FULLRES_UNET_CFG, precision=precision)
         net.load_state_dict(sd, strict=True)
         net = net.cuda()
@@ -414,7 +416,7 @@ def test_v1_aligned_chain_100():
     t_cpu = time.time() - t0
     ref = traj[-1]
     errs = {}
-    for precision in ("fp32", "bf16"):
+    for precision in ("fp32", "fp16x2", "bf16"):
         ldm = _v1_ldm(precision)
         al = make_alignment()
         al.model.cuda()
@@ -426,12 +428,10 @@ def test_v1_aligned_chain_100():
         errs[precision + "_by_step"] = [round(rel_l2(inter[k], traj[k]), 6) for k in (1, 25, 50, 75, 100) if k < len(inter)]
         del ldm, al
     print(f"[v1 aligned chain, 100 steps] rel-L2 vs the oracle loop: fp32 {errs['fp32']:.3e} {errs['fp32_by_step']}, "
-          f"bf16 {errs['bf16']:.3e} {errs['bf16_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
+          f"fp16x2 {errs['fp16x2']:.3e} {errs['fp16x2_by_step']}, bf16 {errs['bf16']:.3e} {errs['bf16_by_step']}; oracle loop {t_cpu:.0f} s on CPU")
     _report("v1_aligned_chain_100", oracle_cpu_s=round(t_cpu, 1), **errs)
     assert errs["fp32"] < 1e-3
-    # IEEE-half activations x (hi + lo) IEEE-half weights, two MFMA products: the north-star bar with a single-pass activation path
-    # (measured 4e-4: the fp16 engine's 1.3e-3 minus its weight-rounding term, test_v1_fp16_error_budget)
-    assert errs["fp16x2"] < 1e-3 and errs["fp16x2"] < 0.5 * errs["fp16"]
+    assert errs["fp16x2"] < 1e-3          # the folded-weight engine holds the bar on the guided ancestral chain too (denoiser fp16x2, guidance fp32-class)
     assert errs["bf16"] < 5e-2 and np.isfinite(errs["bf16"])
 
 

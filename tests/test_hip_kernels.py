@@ -102,15 +102,21 @@ def test_igemm_linear_folded_weights(M, N, K, tile, heavy):
         L.igemm(a16, wf, M=M, N=N, Cin=Kp, out_f32=out, fp8=True, opts=opts)
 
 
+@pytest.mark.parametrize("heavy", [False, True])
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout,splitk", [(2, 13, 16, 16, 256, 256, False), (1, 13, 16, 16, 256, 256, True), (2, 13, 8, 8, 512, 512, True),
                                                      (3, 5, 6, 7, 64, 128, False)])
-def test_igemm_conv3d_folded_weights(B, T, H, W, Cin, Cout, splitk):
+def test_igemm_conv3d_folded_weights(B, T, H, W, Cin, Cout, splitk, heavy):
     """The same for the 3x3x3 convolution (54 weight slabs over 27 activation gathers; 256 x 256 kernel, its split-K form, 128 x 128)."""
     from prediff_amd.packing import pack_conv as PC
     g = torch.Generator(device="cpu").manual_seed(B + T + Cin)
     x = torch.randn(B, T, H, W, Cin, generator=g).to(DEV)
     w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).to(DEV)
     w[:, :, 0, 1, 2] += 0.02                                # asymmetric taps
+    if heavy:        # Student-t(3) filters, 30x outlier output channels, 30x activation channels (what a GroupNorm with outlier gains hands over)
+        t3 = torch.randn(w.shape, generator=g) / torch.sqrt((torch.randn((3,) + tuple(w.shape), generator=g) ** 2).mean(0))
+        w = (t3 / math.sqrt(3 * 27 * Cin)).to(DEV)
+        w[::19] *= 30.0
+        x[..., ::23] *= 30.0
     bias = torch.randn(Cout, generator=g).to(DEV)
     a16 = x.reshape(-1, Cin).half().contiguous()
     wf, _ = PC(w, False, dtype=torch.float16, fold=True)
