@@ -611,24 +611,30 @@ def main():
     #      north-star 1e-3 bar over DDIM-50 with a single-pass activation path (round 6) ----
     fp16x2_line = None
     if not args.no_extra and not args.no_graph and args.config == "v1" and args.precision == "bf16" and world == 1:
-        ldm_bf16 = ldm
-        ldm = v1_model("fp16x2", device, args.config)
-        kx2 = min(args.steps, 20)
-        elx2, Sx2 = timed_steps(B, args.streams, kx2, 5)      # (its graphs hold ~3x the nodes of the pair-kernel engines': the first replays are slow)
-        ldm_x2 = ldm
-        ldm = v1_model("fp16x2_lin", device, args.config)
-        ell, _ = timed_steps(B, args.streams, kx2, 5)
-        del ldm
-        ldm = ldm_x2
-        fp16x2_line = {"value": round(B * kx2 / elx2, 2), "unit": "steps/s", "value_fp16x2_lin": round(B * kx2 / ell, 2),
-                       "fp16x2_lin": "the same with the 3x3x3 convolutions on one product (their weight rounding is 3.1e-4 of the 8.8e-4 weight term of a forward)",
-                       "dtype": "fp16 activations x fp16 hi+lo weights (two products), fp32 accumulate", "steps": kx2,
-                       "ms_per_step": round(elx2 / kx2 * 1e3, 4), "trajectories_per_gpu": B, "lanes": Sx2,
-                       "parity": "v1 DDIM-50 vs the oracle loop < 1e-3 asserted (tests/test_hip_configs.py::test_v1_ddim50_vs_oracle; "
-                                 "its error budget: ::test_v1_fp16_error_budget)"}
-        del ldm
-        ldm = ldm_bf16
-        torch.cuda.empty_cache()
+        # each in its OWN process (this script with --precision ... --no-extra): measured inside this process, after the other engines' graphs and
+        # workspaces have come and gone, the un-fused token path of these engines ran 15-20 % slower than in a fresh one (715-733 vs 870 steps/s;
+        # profiles/r06_c_bench_headline.json vs r06_d_bench_fp16x2*.json) -- the line reports what a user's process gets
+        import subprocess
+
+        def own_process(prec):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--precision", prec, "--no-extra", "--no-cpu-baseline", "--steps", str(min(args.steps, 20)),
+                                    "--warmup", "5", "--batch", str(B), "--streams", str(args.streams)], capture_output=True, text=True, timeout=600)
+                d = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+                return d
+            except Exception:
+                return None
+        dx2, dlin = own_process("fp16x2"), own_process("fp16x2_lin")
+        if dx2 is not None:
+            fp16x2_line = {"value": dx2["value"], "unit": "steps/s", "dtype": "fp16 activations x fp16 hi+lo weights (two products), fp32 accumulate",
+                           "steps": dx2["steps"], "ms_per_step": dx2["ms_per_step"], "trajectories_per_gpu": B, "lanes": dx2["config"].get("lanes"),
+                           "measured": "own process (bench.py --precision fp16x2 --no-extra)",
+                           "parity": "v1 DDIM-50 vs the oracle loop 3.7e-4, < 1e-3 asserted (tests/test_hip_configs.py::test_v1_ddim50_vs_oracle; "
+                                     "its error budget: ::test_v1_fp16_error_budget)"}
+            if dlin is not None:
+                fp16x2_line["fp16x2_lin"] = {"value": dlin["value"], "ms_per_step": dlin["ms_per_step"],
+                                             "what": "the same with the 3x3x3 convolutions on one product (their weight rounding is 3.1e-4 of the 8.8e-4 "
+                                                     "weight term of a forward); DDIM-50 5.4e-4, < 1e-3 asserted"}
 
     if rank == 0:
         n_gpus = world

@@ -329,6 +329,15 @@ int pd_attn_ffn_pair_split(const float* x, float* out, const void* wstream, cons
                            const int32_t* tok_index, const int32_t* tok_affine, int B, int ntok, int nc, int vol, int units, float scale,
                            float eps_attn, float eps_ffn, float* ws, int64_t ws_floats, const pd_call_opts* opts, pd_stream_t stream);
 
+/* PositionwiseFFN.forward alone (pre-norm LayerNorm -> Linear -> GELU -> Linear -> + x, cuboid_transformer.py:182-208) on the pair kernel's FFN
+ * half (ABI 4): for blocks whose attention layer pd_attn_ffn_pair cannot take (cuboid volume > 16, masks: the full-resolution grid), units 256
+ * (hidden 1024) or 512 (hidden 2048), GELU.  x, out: (rows, units) fp32 (may alias); wffn: the FFN chunks in the pair kernel's order
+ * (packing.pack_pair_ffn_split(..., nsplit = 1)); vecs: the pair kernel's fp32 tables (packing.pack_pair_vecs; only LayerNorm-2, b1, b2 are read).
+ * Rows are independent: any row count (a last partial group of 16 is masked). */
+int pd_ffn_rows_supported(int C, int hidden, int act);
+int pd_ffn_rows(const float* x, float* out, const void* wffn, const float* vecs, int64_t rows, int units, float eps,
+                const pd_call_opts* opts, pd_stream_t stream);
+
 /* SEVIRSkillScore.update (datasets/sevir/evaluation.py:193-239): hits / misses / false alarms of (pred / divisor) vs
  * (target / divisor) at every threshold (>=, NaN in either input counts nowhere), accumulated into counts[thr][t][3]
  * (int64, keep_seq) or counts[thr][3].  Tensors are (outer, T, inner) fp32 in [0,1]; divisor = fp32(1/255). */

@@ -144,6 +144,8 @@ _PROTOS = {
     "pd_attn_ffn_pair": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float] * 3 + [C.POINTER(CallOpts), C.c_void_p]),
     "pd_attn_ffn_pair_split_ws_floats": (C.c_int64, [C.c_int] * 3),
     "pd_attn_ffn_pair_split": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_float] * 3 + [C.c_void_p, C.c_int64, C.POINTER(CallOpts), C.c_void_p]),
+    "pd_ffn_rows_supported": (C.c_int, [C.c_int] * 3),
+    "pd_ffn_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_float, C.POINTER(CallOpts), C.c_void_p]),
     "pd_sevir_skill_counts": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -471,3 +473,13 @@ def attn_ffn_pair_split(x, out, wstream, wffn_split, vecs, tok_index, B, ntok, n
     _check(lib().pd_attn_ffn_pair_split(ptr(x), ptr(out), ptr(wstream), ptr(wffn_split), ptr(vecs), ptr(tok_index),
                                         C.cast(aff, C.c_void_p) if aff is not None else None, B, ntok, nc, vol, units, scale, eps_attn, eps_ffn,
                                         ptr(ws), ws.numel(), _opts_ref(opts), stream_ptr()), "pd_attn_ffn_pair_split")
+
+
+def ffn_rows_supported(Cn, Hd, act="gelu"):
+    return bool(lib().pd_ffn_rows_supported(Cn, Hd, ACT[act]))
+
+
+def ffn_rows(x, out, wffn, vecs, rows, units, eps=1e-5, opts=None):
+    """PositionwiseFFN alone on the pair kernel's FFN half (csrc/pair_block.hip MODE 2, one hidden slice): x (rows, units) fp32 -> out (may alias).
+    wffn: packing.pack_pair_ffn_split(w1, w2, nsplit=1); vecs: packing.pack_pair_vecs (LayerNorm-2, b1, b2 are read)."""
+    _check(lib().pd_ffn_rows(ptr(x), ptr(out), ptr(wffn), ptr(vecs), rows, units, eps, _opts_ref(opts), stream_ptr()), "pd_ffn_rows")

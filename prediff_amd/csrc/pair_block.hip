@@ -190,7 +190,10 @@ constexpr int PAIR_NSPL = 4;
 // W2) comes twice, and the second pass multiplies the SAME activation fragments into the SAME accumulators -- the chunk loops simply run
 // NQ = WP * CW^2 (NW = WP * CW) chunks per matrix with the operand index folded (SUB mod the single-product count); nothing else changes:
 // no new registers, the same tile-boundary schedule (its constants count row instructions and DMA pieces, not what a chunk holds).
-template <int NC, int CW, int NWV = 4, int MODE = 0, int WP = 1>
+// NSPL (MODE 2): hidden slices the FFN is cut into.  4 = the split form of the pair; **1 = the FFN alone** (pd_ffn_rows, round 6): LayerNorm ->
+// W1 -> GELU -> W2 -> + x over ALL hidden units of arbitrary rows (any 16 consecutive rows make a group), straight to `out` -- for blocks
+// whose attention the pair kernel cannot take (cuboid volumes > 16: the full-resolution grid), where the FFN alone is 2/3 of the pair's FLOPs.
+template <int NC, int CW, int NWV = 4, int MODE = 0, int WP = 1, int NSPL = 4>
 __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace pairk;
@@ -203,9 +206,11 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
                 T_B1 = GG::T_B1, T_RB = GG::T_RB, T_FLOATS = GG::T_FLOATS, RING_OFF = GG::RING_OFF, CH_ALL = GG::CH_ALL * WP;
   static_assert(NC * CW <= 2, "a wave holds 32 x 256 or 16 x 512 fp32 row values");
   static_assert(NWV == 4 || (NWV == 8 && NC == 1 && CW == 1), "eight waves (two per SIMD, 256 registers each): 16 x 256 rows per wave only");
-  static_assert(MODE == 0 || (NC == 1 && NWV == 4 && NJ % PAIR_NSPL == 0 && HEADS == PAIR_NSPL), "split forms: one group per wave, four waves");
+  static_assert(MODE == 0 || (NC == 1 && (NWV == 4 || (MODE == 2 && NSPL == 1)) && NJ % NSPL == 0 && HEADS == PAIR_NSPL),
+                "split forms: one group per wave, four waves (the FFN-alone form also with eight)");
+  static_assert(MODE == 2 || NSPL == PAIR_NSPL, "NSPL belongs to MODE 2");
   // the slice of a split form and its window of the weight stream
-  constexpr int CH_HEAD = 4 * NQ, CH_FQ = 2 * (NJ / PAIR_NSPL) * NW, NJL = MODE == 2 ? NJ / PAIR_NSPL : NJ;
+  constexpr int CH_HEAD = 4 * NQ, CH_FQ = 2 * (NJ / NSPL) * NW, NJL = MODE == 2 ? NJ / NSPL : NJ;
   const int slice = MODE ? (int)blockIdx.y : 0;
   const int kid_base = MODE == 1 ? slice * CH_HEAD : MODE == 2 ? slice * CH_FQ : 0;
   const int kid_end = MODE == 1 ? kid_base + CH_HEAD : MODE == 2 ? kid_base + CH_FQ : CH_ALL;
@@ -752,7 +757,7 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
     // has the chunks between W1_j and W2_j to itself, as three software-pipelined stages (polynomial | exp, +1 | rcp, mul) of one value
     // per fragment group: independent short chains beside the MFMAs instead of one 9-deep dependent chain per value (a lone wave hides
     // no VALU latency).
-    const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4) + (MODE == 2 ? (uint32_t)slice * (uint32_t)(GG::HID / PAIR_NSPL * 4) : 0u);   // (b1 of this slice's hidden units)
+    const uint32_t vb1 = vtab + (uint32_t)(T_B1 * 4) + (MODE == 2 ? (uint32_t)slice * (uint32_t)(GG::HID / NSPL * 4) : 0u);   // (b1 of this slice's hidden units)
     f32x4 hc[NC][4], hn[NC][4], b1n[4];
     float ga[16 * NC], gd[16 * NC];
 #define PK_HV(H, v) H[(v) >> 4][((v) >> 2) & 3][(v) & 3]
@@ -907,14 +912,14 @@ __global__ void __launch_bounds__(NWV * 64, 1) pair_kernel(const pd_pair_args_k 
 #endif
 }
 
-template <int NC, int CW, int NWV = 4, int MODE = 0, int WP = 1>
+template <int NC, int CW, int NWV = 4, int MODE = 0, int WP = 1, int NSPL = 4>
 static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   using namespace pairk;
   constexpr int LDS_BYTES = G<CW>::LDS_BYTES;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW, NWV, MODE, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<NC, CW, NWV, MODE, WP, NSPL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       pd_set_error("pd_attn_ffn_pair: hipFuncSetAttribute(%d) failed: %s", LDS_BYTES, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -924,10 +929,10 @@ static int launch_pair(const pd_pair_args_k& a, hipStream_t s) {
   // persistent: every workgroup takes the same number of tiles (the last few one less), one workgroup per CU
   // (split forms: PAIR_NSPL workgroups per tile -- blockIdx.y = the slice)
   const int ncu = pd_num_cus();
-  constexpr int WPT = MODE ? PAIR_NSPL : 1;
+  constexpr int WPT = MODE == 2 ? NSPL : MODE == 1 ? PAIR_NSPL : 1;
   const int per_wg = (a.ntiles * WPT + ncu - 1) / ncu;
   const int grid = (a.ntiles + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL((pair_kernel<NC, CW, NWV, MODE, WP>), dim3((unsigned)grid, (unsigned)WPT), dim3(NWV * 64), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((pair_kernel<NC, CW, NWV, MODE, WP, NSPL>), dim3((unsigned)grid, (unsigned)WPT), dim3(NWV * 64), LDS_BYTES, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -1098,6 +1103,46 @@ extern "C" int PD_ENTRY(attn_ffn_pair_split)(const float* x, float* out, const v
   hipLaunchKernelGGL(pair_split_sum_kernel, dim3(sum_blocks), dim3(256), 0, s, (const float4*)slab_f, (float4*)out, n4);
   PD_CHECK_LAUNCH();
   return PD_OK;
+}
+
+// ---- the FFN alone on the pair kernel's FFN half (MODE 2, NSPL = 1): PositionwiseFFN.forward (cuboid_transformer.py:182-208) for rows whose
+//      attention layer the pair kernel cannot take ----------------------------------------------------------------------------------------------
+#if !PD_IS_F16
+extern "C" int pd_ffn_rows_supported(int C, int hidden, int act) { return ((C == 256 && hidden == 1024) || (C == 512 && hidden == 2048)) && act == PD_ACT_GELU; }
+extern "C" int pd_f16_ffn_rows(const float*, float*, const void*, const float*, int64_t, int, float, const pd_call_opts*, pd_stream_t);
+#endif
+
+extern "C" int PD_ENTRY(ffn_rows)(const float* x, float* out, const void* wffn, const float* vecs, int64_t rows, int units, float eps,
+                                  const pd_call_opts* opts, pd_stream_t stream) {
+  using namespace pairk;
+  PD_FORWARD_F16(PD_OPTS_F16(opts), pd_f16_ffn_rows(x, out, wffn, vecs, rows, units, eps, opts, stream));
+  PD_CHECK_ARG(x && out && wffn && vecs, "pd_ffn_rows: null pointer");
+  PD_CHECK_ARG(units == 256 || units == 512, "pd_ffn_rows: units %d (256 or 512)", units);
+  PD_CHECK_ARG(rows > 0 && rows < (1ll << 31) && rows * (int64_t)(units * 4) < 0xFFFFF000ll, "pd_ffn_rows: bad row count / x larger than a 4 GiB buffer descriptor");
+  PD_CHECK_ARG(!(opts && opts->w_fold), "pd_ffn_rows: no folded-weight form");
+  pd_pair_args_k a;
+  // rows as 16-slot groups of consecutive rows: group c, slot s -> row 16 c + s (the affine token form with one "sample" holding every row);
+  // a last partial group gets out-of-range rows (loads return zero, stores are dropped)
+  const int32_t aff[4] = {1, 16, 0, 1};
+  const int groups = (int)((rows + 15) / 16);
+  const int rc = pair_fill_args(a, x, out, wffn, vecs, nullptr, aff, 1, (int)rows, groups, 16, units, 1.0f, eps, eps, opts);
+  if (rc != PD_OK) return rc;
+  a.slab_in = nullptr;
+  a.slab_out = out;                                  // slice 0 of one: the result itself
+  a.wstream2 = wffn;
+  a.w2bytes = (uint32_t)(2 * (units == 256 ? G<1>::NJ * G<1>::NW : G<2>::NJ * G<2>::NW) * CHUNK);
+  hipStream_t s = (hipStream_t)stream;
+  if (units == 512) {
+    a.ntiles = (groups + 3) / 4;
+    return launch_pair<1, 2, 4, 2, 1, 1>(a, s);
+  }
+  // 128-row tiles (eight waves, two per SIMD) once they leave no CU idle, else 64-row tiles
+  if ((groups + 7) / 8 > pd_num_cus() / 2) {
+    a.ntiles = (groups + 7) / 8;
+    return launch_pair<1, 1, 8, 2, 1, 1>(a, s);
+  }
+  a.ntiles = (groups + 3) / 4;
+  return launch_pair<1, 1, 4, 2, 1, 1>(a, s);
 }
 
 }  // namespace PD_NS

@@ -369,6 +369,10 @@ class CuboidTransformerUNet(nn.Module):
         # and the launch has at least `pair_min_tiles` tiles of 128 rows (0: always -- the library switches to one cuboid per wave, 64-row
         # tiles, when 128-row tiles would leave CUs idle: 48 vs 54 us per pair at 4 trajectories, 73 vs 84 at 8)
         self.fuse_pair = os.environ.get("PD_FUSE_PAIR", "1") != "0"
+        # round 6: the FFN of a block whose attention the pair kernel cannot take (cuboid volume > 16, masks: the full-resolution grid) on the pair
+        # kernel's FFN half alone (pd_ffn_rows: x read once, written once; units 256 / 512, GELU) instead of pd_ffn_fused / the LayerNorm + two
+        # GEMM launches (incl. their e4m3 form: at the full-resolution level-1 shapes those launches are HBM bound at 8 % of the fp8 peak)
+        self.fuse_ffn_rows = os.environ.get("PD_FFN_ROWS", "1") != "0"
         if self.w_fold:
             # the round-3 fused token kernels stream ONE weight image: the folded engine runs LayerNorm / pd_igemm (w_fold) / attention core
             # launches.  The pair kernel has a folded form too (WP = 2: every chunk group twice), measured SLOWER than those launches at
@@ -605,6 +609,7 @@ class CuboidTransformerUNet(nn.Module):
                 norm(n + ".ln", ff.layer_norm); lin(n + ".fc1", ff.ffn_1, fp8_ok=not ff.gated); lin(n + ".fc2", ff.ffn_2, fp8_ok=not ff.gated)
                 if ff.gated:
                     lin(n + ".gate", ff.ffn_1_gate)
+
             if self.precision == "bf16" and blk.use_inter_ffn:
                 for a, (at, ff) in enumerate(zip(blk.attn_l, blk.ffn_l)):
                     geo = self._geom[level][a]
@@ -621,6 +626,17 @@ class CuboidTransformerUNet(nn.Module):
                             # units 512: the FFN chunks once more in quarter-major order, for the small-grid (split) form of the pair
                             pack_pair_ffn_split(ff.ffn_1.weight.to(device), ff.ffn_2.weight.to(device), dtype=self.op_dtype, fold=self.w_fold)
                             if at.dim == 512 else None)
+
+            # ... and where the pair kernel cannot take the block (cuboid volume > 16, masks, padding: the full-resolution grid), its FFN half alone
+            for a, ff in enumerate(blk.ffn_l):
+                n = f"{name}.ffn{a}"
+                Cf, Hf = ff.ffn_1.in_features, ff.ffn_1.out_features
+                if (self.precision == "bf16" and not self.w_fold and not ff.gated and f"{name}.pair{a}" not in P
+                        and L.ffn_rows_supported(Cf, Hf, ff.activation_name)):
+                    zc = torch.zeros(Cf, device=device)
+                    P[n + ".rows"] = (pack_pair_ffn_split(ff.ffn_1.weight.to(device), ff.ffn_2.weight.to(device), dtype=self.op_dtype, nsplit=1),
+                                      pack_pair_vecs(zc, zc, None, P[n + ".ln.g"], P[n + ".ln.beta"], P[n + ".fc2.b"], P[n + ".fc1.b"],
+                                                     torch.zeros(4, 16, 16, device=device)), float(ff.layer_norm.eps))
 
         return dict(f32=f32, lin=lin, conv=conv, norm=norm, resblock=resblock, stack=stack)
 
@@ -903,6 +919,10 @@ class CuboidTransformerUNet(nn.Module):
         ld = pad64(C)
         Hd = ff.ffn_1.out_features
         ldh = pad64(Hd)
+        if self.precision == "bf16" and self.fuse_ffn_rows and (name + ".rows") in P and ld == C:
+            wf, vecs, eps = P[name + ".rows"]
+            L.ffn_rows(x, x, wf, vecs, B * S, C, eps, opts=self.opts)
+            return
         if self.precision == "bf16" and self.fuse_ffn and not ff.gated and L.ffn_fused_supported(C, Hd):
             # one launch, hidden activations never leave the CU (csrc/ffn.hip)
             L.ffn_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".fc1.w"][0], P[name + ".fc1.b"], P[name + ".fc2.w"][0],

@@ -1380,6 +1380,59 @@ def test_attn_ffn_pair_split_vs_oracle(name, B, operand):
         assert torch.equal(t[0], out[B - 1])
 
 
+@pytest.mark.parametrize("operand", ["bf16", "fp16"])
+@pytest.mark.parametrize("Cn,rows", [(256, 3328 * 2), (256, 57600), (256, 1000), (512, 832 * 2), (512, 14400 * 2), (512, 77)])
+def test_ffn_rows_vs_oracle(Cn, rows, operand):
+    """pd_ffn_rows -- PositionwiseFFN.forward (cuboid_transformer.py:182-208) on the pair kernel's FFN half alone (MODE 2 with one hidden slice),
+    for blocks whose attention the pair kernel cannot take -- against the oracle's statement of the layer, against the launches it replaces
+    (pd_ffn_fused at units 256), in place, twice (bit-equal), with row counts that are / are not multiples of the 16-row groups and of the
+    64- / 128-row tiles (the last partial group is masked), and at the full-resolution row counts (57 600 / 2 x 14 400)."""
+    from oracle import unet as OU
+    from prediff_amd.packing import pack_pair_ffn_split, pack_pair_vecs
+    opts = L.CallOpts(operand)
+    odt, tol = opts.dtype, {"bf16": 6e-3, "fp16": 1e-3}[operand]
+    Hd = 4 * Cn
+    g = torch.Generator(device="cpu").manual_seed(Cn + rows)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    sd = {"layer_norm.weight": 1 + r(Cn, sc=.1), "layer_norm.bias": r(Cn, sc=.1), "ffn_1.weight": r(Hd, Cn, sc=Cn ** -0.5), "ffn_1.bias": r(Hd, sc=.1),
+          "ffn_2.weight": r(Cn, Hd, sc=Hd ** -0.5), "ffn_2.bias": r(Cn, sc=.1)}
+    x = r(rows, Cn)
+    assert L.ffn_rows_supported(Cn, Hd) and not L.ffn_rows_supported(128, 512) and not L.ffn_rows_supported(256, 1024, act="leaky")
+    y_ref = OU.positionwise_ffn(sd, "", x[None], "gelu")[0]
+    d = lambda t: t.to(DEV)
+    wf = pack_pair_ffn_split(d(sd["ffn_1.weight"]), d(sd["ffn_2.weight"]), dtype=odt, nsplit=1)
+    zc = torch.zeros(Cn, device=DEV)
+    vecs = pack_pair_vecs(zc, zc, None, d(sd["layer_norm.weight"]), d(sd["layer_norm.bias"]), d(sd["ffn_2.bias"]), d(sd["ffn_1.bias"]), torch.zeros(4, 16, 16, device=DEV))
+    xd = d(x).contiguous()
+    out = torch.full_like(xd, float("nan"))
+    L.ffn_rows(xd, out, wf, vecs, rows, Cn, 1e-5, opts=opts)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()), "a row was not written (or written with garbage)"
+    e = rel_l2((out - xd).cpu(), y_ref - x)
+    print(f"[ffn_rows units {Cn} rows {rows} {operand}] update rel-L2 vs oracle {e:.3e}")
+    assert e < tol and rel_l2(out.cpu(), y_ref) < tol
+    for _ in range(2):                                   # in place, twice: bit-identical
+        t = xd.clone()
+        L.ffn_rows(t, t, wf, vecs, rows, Cn, 1e-5, opts=opts)
+        torch.cuda.synchronize()
+        assert torch.equal(t, out)
+    # rows are independent: a prefix alone gives the same rows
+    k = min(rows, 48)
+    t = torch.full((k, Cn), float("nan"), device=DEV)
+    L.ffn_rows(xd[:k].contiguous(), t, wf, vecs, k, Cn, 1e-5, opts=opts)
+    torch.cuda.synchronize()
+    assert torch.equal(t, out[:k])
+    if Cn == 256:
+        w1_p, _ = pack_linear(d(sd["ffn_1.weight"]), False, dtype=odt)
+        w2_p, _ = pack_linear(d(sd["ffn_2.weight"]), False, dtype=odt)
+        t = xd.clone()
+        L.ffn_fused(t, t, d(sd["layer_norm.weight"]), d(sd["layer_norm.bias"]), w1_p, d(sd["ffn_1.bias"]), w2_p, d(sd["ffn_2.bias"]), rows, Cn, Hd, act="gelu", opts=opts)
+        torch.cuda.synchronize()
+        assert rel_l2(out - xd, t - xd) < 1.5e-3
+    with pytest.raises(L.PrediffHipError):
+        L.ffn_rows(xd, out, wf, vecs, rows, Cn, 1e-5, opts=L.CallOpts(operand, w_fold=1))
+
+
 def test_attn_ffn_pair_rejects_what_it_does_not_run():
     assert not L.attn_ffn_pair_supported(128, 2, 512, 16)
     assert not L.attn_ffn_pair_supported(256, 4, 1024, 25)
