@@ -919,7 +919,9 @@ class CuboidTransformerUNet(nn.Module):
         ld = pad64(C)
         Hd = ff.ffn_1.out_features
         ldh = pad64(Hd)
-        if self.precision == "bf16" and self.fuse_ffn_rows and (name + ".rows") in P and ld == C:
+        # (not where the layer has e4m3 operands -- precision="fp8", K >= 512: measured at full resolution, 89.5 steps/s with the e4m3 FFN launches
+        #  at level 1 vs 87.8 with this kernel there; bf16: 71.2 with it vs 69.0 without, profiles/r06_f_fullres_*.json)
+        if self.precision == "bf16" and self.fuse_ffn_rows and (name + ".rows") in P and ld == C and (name + ".fc1.w8") not in P:
             wf, vecs, eps = P[name + ".rows"]
             L.ffn_rows(x, x, wf, vecs, B * S, C, eps, opts=self.opts)
             return

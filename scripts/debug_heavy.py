@@ -35,12 +35,24 @@ for kind, sd in (("gauss", seeded_state_dict(tmpl, 1234)), ("heavy", heavy_taile
     for name, prec, sw in (("fp16 pair", "fp16", {}), ("fp16 round-3 fused", "fp16", dict(fuse_pair=False)),
                            ("fp16 unfused", "fp16", dict(fuse_pair=False, fuse_attn=False, fuse_ffn=False)),
                            ("fp16x2 pair-fold", "fp16x2", dict(fuse_pair=True)), ("fp16x2 unfused", "fp16x2", dict(fuse_pair=False)),
+                           ("fp16x2_lin unfused", "fp16x2_lin", dict(fuse_pair=False, fold_pair_small=False)),
+                           ("fp16x2 unfused (no small pair)", "fp16x2", dict(fuse_pair=False, fold_pair_small=False)),
+                           ("fp16x2, W_lo zeroed", "fp16x2", dict(fuse_pair=False, fold_pair_small=False, _zero_lo=True)),
                            ("fp32", "fp32", {})):
         net = CuboidTransformerUNet(**V1_UNET_CFG, precision=prec)
+        sw = dict(sw)
+        zero_lo = sw.pop("_zero_lo", False)
         for k, v in sw.items():
             setattr(net, k, v)
         net.load_state_dict(sd, strict=True)
-        out = net.cuda()(xb, tb, cb)[:2]
+        net = net.cuda()
+        if zero_lo:        # the folded K loop with W_lo = 0: must land where the one-product engine does (same hi slabs, zeros added)
+            Pk = net._ensure_packed(torch.device("cuda"))
+            for k_, v_ in Pk.items():
+                w_ = v_[0] if isinstance(v_, tuple) and len(v_) == 2 and torch.is_tensor(v_[0]) else None
+                if w_ is not None and getattr(w_, "_pd_fold", False):
+                    w_[w_.shape[0] // 2:].zero_()
+        out = net(xb, tb, cb)[:2]
         print(f"[{kind} B={B}] {name:22s} vs oracle {rel(out, ref):.3e}   vs oracle-on-fp16-weights {rel(out, ref16):.3e}   finite {bool(torch.isfinite(out).all())}")
         del net
     # weights that ARE fp16 numbers: W_lo = 0 exactly, so the folded engine computes what the fp16 engine computes (up to kernel choice /

@@ -110,8 +110,7 @@ _HEAVY = {}
 HEAVY_BOUND = {"fp32": 2e-4, "fp16x2": 1e-2, "bf16": 6e-2, "fp16": 7e-3, "fp8_conv": 0.3}
 
 
-@pytest.mark.parametrize("B", [2, 32])
-@pytest.mark.parametrize("precision", ["fp32", "fp16x2", "bf16", "fp16", "fp8_conv"])
+@pytest.mark.parametrize("precision,B", [("fp32", 2), ("fp16x2", 2), ("fp16x2", 32), ("bf16", 2), ("bf16", 32), ("fp16", 2), ("fp16", 32), ("fp8_conv", 2)])
 def test_v1_unet_heavy_tailed_weights(precision, B):
     """Robustness of the 16-bit / 8-bit engines on checkpoint-like weights (no trained checkpoint exists offline and
     every other parity case uses Gaussian fan-in-scaled weights): Student-t(3) matrices / filters with two 30x outlier output channels
@@ -155,7 +154,7 @@ def test_v1_unet_heavy_tailed_weights(precision, B):
         f.write(json.dumps(dict(test="v1_unet_heavy_tailed", precision=precision, B=B, **errs)) + "\n")
     assert errs["heavy_max"] < HEAVY_BOUND[precision]
     _HEAVY[("ratio", precision, B)] = errs["heavy_max"] / errs["gauss"]
-    r32 = _HEAVY.get(("ratio", "fp32", B))
+    r32 = _HEAVY.get(("ratio", "fp32", 2))          # (the fp32-class engine's loss factor, measured at 2 trajectories: it does not depend on the batch)
     if r32 is not None and precision != "fp32":
         print(f"[v1 heavy-tailed {precision} B={B}] loss factor {errs['heavy_max'] / errs['gauss']:.2f} (fp32-class engine: {r32:.2f})")
         # (e4m3: 3 mantissa bits meet the outlier channels' dynamic range -- reported, bounded above;  fp16x2: its Gaussian figure has no
