@@ -47,7 +47,7 @@ for kind, sd in (("gauss", seeded_state_dict(tmpl, 1234)), ("heavy", heavy_taile
         net.load_state_dict(sd, strict=True)
         net = net.cuda()
         if zero_lo:        # the folded K loop with W_lo = 0: must land where the one-product engine does (same hi slabs, zeros added)
-            Pk = net._ensure_packed(torch.device("cuda"))
+            Pk = net._ensure_packed(xb.device)          # (the key of the pack holds str(device): the forward's own device object)
             for k_, v_ in Pk.items():
                 w_ = v_[0] if isinstance(v_, tuple) and len(v_) == 2 and torch.is_tensor(v_[0]) else None
                 if w_ is not None and getattr(w_, "_pd_fold", False):
