@@ -55,6 +55,28 @@ for kind, sd in (("gauss", seeded_state_dict(tmpl, 1234)), ("heavy", heavy_taile
         out = net(xb, tb, cb)[:2]
         print(f"[{kind} B={B}] {name:22s} vs oracle {rel(out, ref):.3e}   vs oracle-on-fp16-weights {rel(out, ref16):.3e}   finite {bool(torch.isfinite(out).all())}")
         del net
+    # does W_lo do what it should?  (folded engine) - (the same engine with W_lo zeroed) must be  oracle(w) - oracle(GEMM weights rounded to fp16)
+    GEMM_KEYS = ("in_layers.2.weight", "out_layers.3.weight", "skip_connection.weight", "qkv.weight", "proj.weight", "ffn_1.weight", "ffn_2.weight",
+                 "reduction.weight", ".conv.weight", "final_proj.weight")
+    sdg = {k: (v.half().float() if (torch.is_floating_point(v) and v.dim() >= 2 and any(k.endswith(e) or e in k for e in GEMM_KEYS)) else v) for k, v in sd.items()}
+    refg = OU.unet_forward(sdg, V1_UNET_CFG, x2, t2, c2)
+    res = {}
+    for zero in (False, True):
+        net = CuboidTransformerUNet(**V1_UNET_CFG, precision="fp16x2")
+        net.fuse_pair, net.fold_pair_small = False, False
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda()
+        if zero:
+            for k_, v_ in net._ensure_packed(xb.device).items():
+                w_ = v_[0] if isinstance(v_, tuple) and len(v_) == 2 and torch.is_tensor(v_[0]) else None
+                if w_ is not None and getattr(w_, "_pd_fold", False):
+                    w_[w_.shape[0] // 2:].zero_()
+        res[zero] = net(xb, tb, cb)[:2].double().cpu()
+        del net
+    d_eng, d_or = res[False] - res[True], (ref - refg).double()
+    cos = float((d_eng * d_or).sum() / (d_eng.norm() * d_or.norm()))
+    print(f"[{kind} B={B}] effect of W_lo: engine (folded - lo zeroed) norm {float(d_eng.norm() / ref.double().norm()):.3e}, oracle (exact - GEMM weights rounded) norm "
+          f"{float(d_or.norm() / ref.double().norm()):.3e}, cosine {cos:.3f}, rel diff {float((d_eng - d_or).norm() / d_or.norm()):.3f}")
     # weights that ARE fp16 numbers: W_lo = 0 exactly, so the folded engine computes what the fp16 engine computes (up to kernel choice /
     # summation order) -- how far apart the two land is the amplification of fp32 round-off by this network, not a property of the fold
     outs = {}
