@@ -475,8 +475,10 @@ def main():
         CONV3D_KERNEL_LABEL = "igemm_kernel<128,128,64,2,false,2,2,1> (Conv3d 3x3x3 implicit GEMM)"
         AB_OPTS["igemm_disable_256"] = 1
     ldm = v1_model(args.precision, device, args.config)
-    ldm.torch_nn_module.fuse_ffn = not args.no_fused_ffn
-    ldm.torch_nn_module.fuse_attn = not args.no_fused_attn
+    if args.no_fused_ffn:
+        ldm.torch_nn_module.fuse_ffn = False
+    if args.no_fused_attn:
+        ldm.torch_nn_module.fuse_attn = False
     if args.no_pair:
         ldm.torch_nn_module.fuse_pair = False
     if args.ensemble_e2e:

@@ -855,8 +855,8 @@ class CuboidTransformerUNet(nn.Module):
             # the reference pads AFTER the LayerNorm (cuboid_transformer.py:829), so a padded token's q/k/v equal the qkv bias;
             # the HIP kernels give padded slots q = k = v = 0.  Unreachable through CuboidTransformerUNet (qkv_bias is always False).
             raise NotImplementedError("qkv_bias=True together with a padded (non-divisible) shape is not supported by the HIP path")
-        if (self.precision == "bf16" and self.fuse_attn and at.use_final_proj and ld == C and tabs.get("tok_out") is None
-                and L.attn_block_fused_supported(C, at.num_heads, geo["vol"])):
+        if (self.precision == "bf16" and self.fuse_attn and not self.w_fold and at.use_final_proj and ld == C and tabs.get("tok_out") is None
+                and L.attn_block_fused_supported(C, at.num_heads, geo["vol"])):      # (never with folded weights: this kernel streams ONE weight image)
             # one launch, q/k/v/attention output never leave the CU (csrc/attn_block.hip)
             L.attn_block_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".qkv.w"][0], P[name + ".qkv.b"],
                                P[name + ".proj.w"][0], P[name + ".proj.b"], tabs["tok"], P[name + ".bias"], tabs["mask"],
@@ -925,7 +925,7 @@ class CuboidTransformerUNet(nn.Module):
             wf, vecs, eps = P[name + ".rows"]
             L.ffn_rows(x, x, wf, vecs, B * S, C, eps, opts=self.opts)
             return
-        if self.precision == "bf16" and self.fuse_ffn and not ff.gated and L.ffn_fused_supported(C, Hd):
+        if self.precision == "bf16" and self.fuse_ffn and not self.w_fold and not ff.gated and L.ffn_fused_supported(C, Hd):
             # one launch, hidden activations never leave the CU (csrc/ffn.hip)
             L.ffn_fused(x, x, P[name + ".ln.g"], P[name + ".ln.beta"], P[name + ".fc1.w"][0], P[name + ".fc1.b"], P[name + ".fc2.w"][0],
                         P[name + ".fc2.b"], B * S, C, Hd, act=ff.activation_name, opts=self.opts)

@@ -73,6 +73,8 @@ for kind, sd in (("gauss", seeded_state_dict(tmpl, 1234)), ("heavy", heavy_taile
                     w_[w_.shape[0] // 2:].zero_()
         res[zero] = net(xb, tb, cb)[:2].double().cpu()
         del net
+    print(f"[{kind} B={B}] activation-rounding term alone: folded engine vs oracle {rel(res[False], ref):.3e}; lo-zeroed engine vs oracle on GEMM-rounded weights "
+          f"{rel(res[True], refg):.3e}; lo-zeroed engine vs oracle {rel(res[True], ref):.3e}")
     d_eng, d_or = res[False] - res[True], (ref - refg).double()
     cos = float((d_eng * d_or).sum() / (d_eng.norm() * d_or.norm()))
     print(f"[{kind} B={B}] effect of W_lo: engine (folded - lo zeroed) norm {float(d_eng.norm() / ref.double().norm()):.3e}, oracle (exact - GEMM weights rounded) norm "
