@@ -613,9 +613,8 @@ def main():
     #      north-star 1e-3 bar over DDIM-50 with a single-pass activation path (round 6) ----
     fp16x2_line = None
     if not args.no_extra and not args.no_graph and args.config == "v1" and args.precision == "bf16" and world == 1:
-        # each in its OWN process (this script with --precision ... --no-extra): measured inside this process, after the other engines' graphs and
-        # workspaces have come and gone, the un-fused token path of these engines ran 15-20 % slower than in a fresh one (715-733 vs 870 steps/s;
-        # profiles/r06_c_bench_headline.json vs r06_d_bench_fp16x2*.json) -- the line reports what a user's process gets
+        # each in its own process (this script with --precision ... --no-extra): what a user's process running that engine gets, with nothing of
+        # the other engines' graphs and workspaces around
         import subprocess
 
         def own_process(prec):
@@ -631,7 +630,7 @@ def main():
             fp16x2_line = {"value": dx2["value"], "unit": "steps/s", "dtype": "fp16 activations x fp16 hi+lo weights (two products), fp32 accumulate",
                            "steps": dx2["steps"], "ms_per_step": dx2["ms_per_step"], "trajectories_per_gpu": B, "lanes": dx2["config"].get("lanes"),
                            "measured": "own process (bench.py --precision fp16x2 --no-extra)",
-                           "parity": "v1 DDIM-50 vs the oracle loop 3.7e-4, < 1e-3 asserted (tests/test_hip_configs.py::test_v1_ddim50_vs_oracle; "
+                           "kernels": "folded-weight forms of pd_igemm (w_fold) and of the pair kernel (WP = 2)", "parity": "v1 DDIM-50 vs the oracle loop 3.7e-4, < 1e-3 asserted (tests/test_hip_configs.py::test_v1_ddim50_vs_oracle; "
                                      "its error budget: ::test_v1_fp16_error_budget)"}
             if dlin is not None:
                 fp16x2_line["fp16x2_lin"] = {"value": dlin["value"], "ms_per_step": dlin["ms_per_step"],

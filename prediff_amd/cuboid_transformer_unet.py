@@ -374,13 +374,11 @@ class CuboidTransformerUNet(nn.Module):
         # GEMM launches (incl. their e4m3 form: at the full-resolution level-1 shapes those launches are HBM bound at 8 % of the fp8 peak)
         self.fuse_ffn_rows = os.environ.get("PD_FFN_ROWS", "1") != "0"
         if self.w_fold:
-            # the round-3 fused token kernels stream ONE weight image: the folded engine runs LayerNorm / pd_igemm (w_fold) / attention core
-            # launches.  The pair kernel has a folded form too (WP = 2: every chunk group twice), measured SLOWER than those launches at
-            # 64 trajectories -- 839 vs 891 steps/s (profiles/r06_b_bench_fp16x2*.json): at twice the MFMA work the GEMM-tiled kernels' 0.4-0.5 of
-            # peak beats the pair kernel's 0.3, and the HBM round trips it saves were never the bottleneck -- so it is opt-in (fuse_pair = True)
+            # the round-3 fused token kernels (pd_attn_block_fused, pd_ffn_fused) stream ONE weight image: never with folded weights.  The pair kernel has
+            # the folded forms (WP = 2: every chunk group twice) and wins at every batch size -- 832 vs 724 steps/s at 64 trajectories, 491 vs 385 at 4
+            # (profiles/r06_j_*.json; PD_FUSE_PAIR_FOLD=0 / fuse_pair = False runs LayerNorm / folded pd_igemm / attention core launches instead)
             self.fuse_ffn = self.fuse_attn = False
-            self.fuse_pair = os.environ.get("PD_FUSE_PAIR_FOLD", "0") == "1"
-            self.fold_pair_small = os.environ.get("PD_FUSE_PAIR_FOLD_SMALL", "1") != "0"      # ... but on in the small-batch mode (<= 16 trajectories per launch)
+            self.fuse_pair = os.environ.get("PD_FUSE_PAIR_FOLD", "1") != "0"
             self.opts.w_fold = 1
         self.pair_min_tiles = int(os.environ.get("PD_PAIR_MIN_TILES", "0"))
         self.pair_units = {int(u) for u in os.environ.get("PD_PAIR_UNITS", "256,512").split(",") if u}   # A/B: block widths handed to it
@@ -963,9 +961,7 @@ class CuboidTransformerUNet(nn.Module):
         tabs = self._tables_dev[dev][level]
         for a, at in enumerate(blk.attn_l):
             if self.w_fold:
-                # folded weights: the pair kernel's WP = 2 forms win where launches are latency bound (the small-batch mode: 497 vs 467 steps/s at
-                # 4 trajectories) and lose to the GEMM-tiled launches at full occupancy (839 vs 891 at 64); `fuse_pair` forces them everywhere
-                pair = P.get(f"{name}.pair{a}") if (self.fuse_pair or (self.fold_pair_small and self._splitk_mode(B))) else None
+                pair = P.get(f"{name}.pair{a}") if self.fuse_pair else None        # (the folded forms of the pair kernel; no fused round-3 fallback)
             else:
                 pair = P.get(f"{name}.pair{a}") if (self.fuse_pair and self.fuse_attn and self.fuse_ffn) else None
             geo = self._geom[level][a]
