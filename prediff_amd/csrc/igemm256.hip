@@ -107,8 +107,12 @@ constexpr int KBUF = 4 * HT;    // one K-tile buffer: A half 0, A half 1, W half
 // products in the same order per accumulator (bit-identical), half the barriers.  Measured at 32 trajectories, interleaved on one box
 // (profiles/r05_g_two_phase_ab.txt): Conv3d level 0 392 / 401 -> 385 / 377 us, level 1 320 / 325 -> 311 / 310 us, 4096^3 GEMM 108.4 -> 105.6 us,
 // headline 1532 -> 1555 steps/s.
-template <int KIND, int RT, bool SK = false, bool F8 = false, bool SP = false, bool P2 = true>
+// WF (round 6): folded weights (pd_igemm_args.w_fold, precision="fp16x2") -- the weight slabs of W_lo walk the activation gather of the W_hi slabs.
+// A template flag, not a run-time test: the one-product instantiations -- the headline's Conv3d kernel -- keep the instruction stream they had
+// (the run-time form added 12 scalar instructions to every K-tile of the hot loop and cost the kernel 2-5 %).
+template <int KIND, int RT, bool SK = false, bool F8 = false, bool SP = false, bool P2 = true, bool WF = false>
 __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
+  static_assert(!WF || (!F8 && !SP), "folded weights: 16-bit operands, no hi/lo split");
   static_assert(!SP || (!SK && !F8), "the hi/lo form: bf16 operands, no K-slices");
   constexpr uint32_t EB = F8 ? 1u : 2u;           // bytes per operand element
   constexpr int KSH = F8 ? 7 : SP ? 5 : 6;        // log2(elements per 128 B K-tile row)
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   // so 2 of 13 tiles drop 9 of their 27 taps -- the zero-padding taps are left out of both DMA streams and of the MFMA loop instead of
   // being streamed as zero rows (bit `tap` of tap_skip; debug_flags bit 8 keeps the dense loop for A/B runs).
   uint32_t tap_skip = 0;
-  if (KIND == 2 && !SK && p.KT > 1 && p.ut == 1 && p.vT <= 0 && p.taps < 32 && khw < 32 && p.w_fold == 0 && !(p.debug_flags & 8)) {   // (< 32: `tap_skip >> taps` stays a defined shift)
+  if (KIND == 2 && !SK && p.KT > 1 && p.ut == 1 && p.vT <= 0 && p.taps < 32 && khw < 32 && !WF && !(p.debug_flags & 8)) {   // (< 32: `tap_skip >> taps` stays a defined shift)
     const int hw_o = p.Ho * p.Wo, thw_o = p.To * hw_o;
     const int m_last = min(p.M, m0 + BM) - 1;
     const int b_first = m0 / thw_o;
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
 
   const int vT = p.vT > 0 ? p.vT : p.Ti * p.ut, vH = p.vH > 0 ? p.vH : p.Hi * p.uh, vW = p.vW > 0 ? p.vW : p.Wi * p.uw;
   auto set_tap = [&](int hh, int tap) {
-    if (p.w_fold > 0 && tap >= p.w_fold) tap -= p.w_fold;     // the W_lo slabs walk the same activation gather as the W_hi slabs
+    if constexpr (WF) { if (tap >= p.w_fold) tap -= p.w_fold; }     // the W_lo slabs walk the same activation gather as the W_hi slabs
     const int kt = tap / khw, r = tap - kt * khw;
     const int kh = r / p.KW, kw = r - kh * p.KW;
 #pragma unroll
@@ -512,13 +516,13 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const pd_igemm
   }
 }
 
-template <int KIND, bool F8 = false>
+template <int KIND, bool F8 = false, bool WF = false>
 static int launch256_splitk(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, 8, true, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, 8, true, F8, false, true, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -526,7 +530,7 @@ static int launch256_splitk(const pd_igemm_args& a, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL((igemm256_kernel<KIND, 8, true, F8>), dim3(tiles, a.ksplit, 1), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((igemm256_kernel<KIND, 8, true, F8, false, true, WF>), dim3(tiles, a.ksplit, 1), dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   const int64_t total = (int64_t)a.M * (a.N >> 2);
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
@@ -554,17 +558,18 @@ int pd_igemm256_launch_splitk(const pd_igemm_args& a, int kind, hipStream_t s) {
 #if !PD_IS_F16
   if (a.fp8) return kind == 0 ? launch256_splitk<0, true>(a, s) : launch256_splitk<2, true>(a, s);
 #endif
+  if (a.w_fold > 0) return kind == 0 ? launch256_splitk<0, false, true>(a, s) : launch256_splitk<2, false, true>(a, s);
   return kind == 0 ? launch256_splitk<0>(a, s) : launch256_splitk<2>(a, s);
 }
 
-template <int KIND, int RT, bool F8 = false, bool SP = false, bool P2 = true>
+template <int KIND, int RT, bool F8 = false, bool SP = false, bool P2 = true, bool WF = false>
 static int launch256(const pd_igemm_args& a, hipStream_t s) {
   constexpr int lds = 2 * KBUF;
   constexpr int BM = RT == 8 ? 256 : 16 * RT + 96;
   static bool attr_set_dev[PD_MAX_DEVICES];
   bool& attr_set = attr_set_dev[pd_cur_device()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT, false, F8, SP, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm256_kernel<KIND, RT, false, F8, SP, P2, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       pd_set_error("pd_igemm: hipFuncSetAttribute(%d) failed: %s", lds, hipGetErrorString(e));
       return PD_ERR_LAUNCH;
@@ -573,7 +578,7 @@ static int launch256(const pd_igemm_args& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + 255) / 256);
   dim3 grid(tiles, 1, a.nbatch > 0 ? a.nbatch : 1);
-  hipLaunchKernelGGL((igemm256_kernel<KIND, RT, false, F8, SP, P2>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((igemm256_kernel<KIND, RT, false, F8, SP, P2, WF>), grid, dim3(512), lds, s, a);
   PD_CHECK_LAUNCH();
   return PD_OK;
 }
@@ -601,6 +606,7 @@ int pd_igemm256_launch(const pd_igemm_args& a, int kind, hipStream_t s) {
   if (a.fp8 && (a.debug_flags & 64)) return kind == 0 ? launch256<0, 8, true, false, false>(a, s) : launch256<2, 8, true, false, false>(a, s);
   if (a.fp8) return kind == 0 ? launch256<0, 8, true>(a, s) : launch256<2, 8, true>(a, s);
 #endif
+  if (a.w_fold > 0) return kind == 0 ? launch256<0, 8, false, false, true, true>(a, s) : launch256<2, 8, false, false, true, true>(a, s);
   if (a.debug_flags & 64) return kind == 0 ? launch256<0, 8, false, false, false>(a, s) : launch256<2, 8, false, false, false>(a, s);   // (A/B: four phases)
   return kind == 0 ? launch256<0, 8>(a, s) : launch256<2, 8>(a, s);
 }

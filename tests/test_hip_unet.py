@@ -163,6 +163,30 @@ def test_v1_unet_heavy_tailed_weights(precision, B):
             assert errs["heavy_max"] / errs["gauss"] < 2.0 * max(r32, 1.0)
 
 
+@pytest.mark.parametrize("name", ["axial", "v1"])
+def test_folded_engine_never_runs_one_product_kernels(name):
+    """precision="fp16x2": the round-3 fused token kernels (pd_attn_block_fused, pd_ffn_fused) stream ONE weight image -- handed a folded
+    operand they would silently read W_hi only.  The engine must refuse them whatever the A/B flags say (bench.py once re-enabled them and
+    measured a faster, one-product engine): a forward with the flags forced on equals the forward with them off bit for bit, and differs
+    from the one-product fp16 engine."""
+    cfg = V1_UNET_CFG if name == "v1" else TINY_UNET_CFGS[name]
+    sd = seeded_state_dict(TP.unet_template(cfg, "v1_unet_schema.json" if name == "v1" else "tiny_unet_schema.json", None if name == "v1" else name), 31)
+    x = seeded_input("fx", (2,) + tuple(cfg["target_shape"]), 2).cuda()
+    cond = seeded_input("fc", (2,) + tuple(cfg["input_shape"]), 3).cuda()
+    t = torch.tensor([7, 431]).cuda()
+    outs = {}
+    for key, prec, flags in (("off", "fp16x2", False), ("on", "fp16x2", True), ("fp16", "fp16", None)):
+        net = CuboidTransformerUNet(**cfg, precision=prec)
+        net.load_state_dict(sd, strict=True)
+        if flags is not None:
+            net.fuse_pair = False                    # the LayerNorm / folded pd_igemm / attention-core launches
+            net.fuse_attn = net.fuse_ffn = flags
+        outs[key] = net.cuda()(x, t, cond)
+        del net
+    assert torch.equal(outs["on"], outs["off"])
+    assert rel_l2(outs["off"], outs["fp16"]) > 1e-5          # (the folded engine is not the one-product engine)
+
+
 def test_repack_after_weight_update():
     cfg = TINY_UNET_CFGS["axial"]
     net = CuboidTransformerUNet(**cfg).cuda()
