@@ -214,10 +214,12 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   char* const dma_dst = smem + wave * (8 * 128);   // + half * HT + i * (64 * 128) + buffer * KBUF  (lane * 16 is implicit)
 
   const int vT = p.vT > 0 ? p.vT : p.Ti * p.ut, vH = p.vH > 0 ? p.vH : p.Hi * p.uh, vW = p.vW > 0 ? p.vW : p.Wi * p.uw;
-  auto set_tap = [&](int hh, int tap) {
-    if constexpr (WF) { if (tap >= p.w_fold) tap -= p.w_fold; }     // the W_lo slabs walk the same activation gather as the W_hi slabs
-    const int kt = tap / khw, r = tap - kt * khw;
-    const int kh = r / p.KW, kw = r - kh * p.KW;
+  // (kt, kh, kw) of the A stream's current tap: kept as three wave-uniform counters that next_a() advances -- the two integer divisions of
+  // tap -> (kt, kh, kw) by run-time divisors were ~70 scalar instructions in the hot loop at every tap change (round 6: the loop's time follows its
+  // scalar instruction count more than its MFMA count suggests -- 12 added ones had cost the kernel 3 %)
+  int a_kt = 0, a_kh = 0, a_kw = 0;
+  auto set_tap = [&](int hh) {
+    const int kt = a_kt, kh = a_kh, kw = a_kw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const uint32_t c = acoord[hh][i];
@@ -235,12 +237,20 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   int a_kc = SK ? kt0 - a_tap * kchunks : 0, w_kc = a_kc;
   int w_tap = a_tap;
   uint32_t w_tap_b = (uint32_t)a_tap * w_tap_stride_b;     // byte offset of the current W tap
+  if (KIND != 0) {                                         // coordinates of the first tap (the only divisions: once per workgroup)
+    int t0 = a_tap;
+    if constexpr (WF) { if (t0 >= p.w_fold) t0 -= p.w_fold; }
+    a_kt = t0 / khw;
+    const int r0 = t0 - a_kt * khw;
+    a_kh = r0 / p.KW;
+    a_kw = r0 - a_kh * p.KW;
+  }
   if (SK && KIND != 0 && a_kc != 0) {                      // a slice that starts inside a tap: issue_a only sets a tap up at its first chunk
-    set_tap(0, a_tap);
-    set_tap(1, a_tap);
+    set_tap(0);
+    set_tap(1);
   }
   auto issue_a = [&](int hh, int buf) {    // A half hh of the A stream's current K-tile
-    if (KIND != 0 && a_kc == 0) set_tap(hh, a_tap);
+    if (KIND != 0 && a_kc == 0) set_tap(hh);
     const int ka = __builtin_amdgcn_readfirstlane(a_kc * (int)KB);
     char* dst = dma_dst + buf * KBUF + hh * HT;
     BLDS16(rA, dst, aoff[hh][0], ka);
@@ -249,7 +259,19 @@ __global__ void __launch_bounds__(512) igemm256_kernel(const pd_igemm_args p) {
   auto next_a = [&]() {
     if (++a_kc == kchunks) {
       a_kc = 0;
-      do { ++a_tap; } while ((tap_skip >> a_tap) & 1u);    // (a_tap <= taps < 32 and bit `taps` is never set: the loop stops at the end)
+      do {                                                 // (a_tap <= taps < 32 and bit `taps` is never set: the loop stops at the end)
+        ++a_tap;
+        if (KIND != 0) {
+          if (++a_kw == p.KW) {
+            a_kw = 0;
+            if (++a_kh == p.KH) {
+              a_kh = 0;
+              ++a_kt;
+              if constexpr (WF) { if (a_kt == p.KT) a_kt = 0; }      // the W_lo slabs walk the same activation gather as the W_hi slabs
+            }
+          }
+        }
+      } while ((tap_skip >> a_tap) & 1u);
     }
   };
   auto issue_w = [&](int buf) {            // both W halves of the W stream's current K-tile
