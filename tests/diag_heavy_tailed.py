@@ -1,5 +1,5 @@
 """Heavy-tailed weights (prediff_amd.seeding.heavy_tailed_state_dict) through engine variants vs the oracle: which path loses what.
-usage: python scripts/debug_heavy.py [B]"""
+usage: python tests/diag_heavy_tailed.py [B]   (a diagnostic of the test tree, not a pytest module: it uses the oracle as the checker)"""
 import os
 import sys
 

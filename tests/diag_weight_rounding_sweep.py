@@ -1,6 +1,6 @@
 """CPU (oracle only, no GPU): which weights carry the fp16 weight-rounding term of a denoiser forward -- the measurement behind
 precision="fp16x2_lin" (DESIGN.md section 5).  Rounds one group of the v1 denoiser's matrices / filters to IEEE half at a time (everything else
-exact, fp32 arithmetic) and reports the rel-L2 of the forward against the exact one.  usage: python scripts/sweep_weight_rounding.py"""
+exact, fp32 arithmetic) and reports the rel-L2 of the forward against the exact one.  usage: python tests/diag_weight_rounding_sweep.py   (a diagnostic of the test tree, not a pytest module)"""
 import sys, time, torch
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
