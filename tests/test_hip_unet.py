@@ -104,9 +104,9 @@ _HEAVY = {}
 # measured on MI355X (profiles/r06_*_parity_report.jsonl), rel-L2 per forward, Gaussian -> heavy-tailed weights: the bound is 2x the measured
 # heavy-tailed figure.  Every engine loses the same factor (~3.5x: bf16 7.5e-3 -> 2.9e-2, fp16 1.05e-3 -> 3.3e-3), i.e. the loss is the
 # conditioning of the heavy-tailed network (larger cancellations in its dot products), not an overflow / saturation of a 16-bit packer.
-# fp16x2: on these weights the ACTIVATION rounding dominates (the fp16 engine against the oracle on fp16-rounded weights: 2.9e-3 of its 3.3e-3), so
-# exact weights buy nothing and the folded engine lands where the fp16 engine does, within the +- 30 % scatter between kernel paths that a
-# network with near one-hot softmax rows shows (3.1 ... 5.1e-3 over six engine / path combinations, profiles/r06_d_debug_heavy_tailed.log)
+# fp16x2: on these weights exact (folded) weights do not help -- the folded engine measures 3.8 ... 5.1e-3 where the fp16 engine measures 3.3e-3 and the
+# same engine with W_lo zeroed 3.2e-3, although every folded GEMM is exact on this distribution (kernel tests) and the Gaussian case behaves as
+# predicted; DESIGN.md section 5 has the measurements (profiles/r06_h_debug_heavy_tailed.log, r06_j_wlo_effect.log).  Bounded at 2x the measured figure.
 HEAVY_BOUND = {"fp32": 2e-4, "fp16x2": 1e-2, "bf16": 6e-2, "fp16": 7e-3, "fp8_conv": 0.3}
 
 
